@@ -1,0 +1,223 @@
+"""ctypes/numpy binding of the CPU oracle (oracle/vgl_oracle.c).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py may import this module.  The product package
+(vectorgraphlibrary_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libvgl_oracle.so")
+
+
+def build(force=False):
+    """Compile the C restatement (gcc) if the shared object is missing or stale."""
+    src = os.path.join(_HERE, "vgl_oracle.c")
+    hdr = os.path.join(_HERE, "vgl_oracle.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libvgl_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class BfsStats(C.Structure):
+    _fields_ = [("levels", C.c_int32), ("edges_examined", C.c_int64),
+                ("frontier_total", C.c_int64), ("discovered", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        p = C.c_void_p
+        i32, i64, u64 = C.c_int32, C.c_int64, C.c_uint64
+        L.vgo_splitmix64.restype = u64
+        L.vgo_splitmix64.argtypes = [u64]
+        L.vgo_relabel.restype = C.c_uint32
+        L.vgo_relabel.argtypes = [C.c_uint32, C.c_int, u64]
+        L.vgo_gen_rmat.argtypes = [C.c_int, i64, i64, u64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, p, p]
+        L.vgo_gen_uniform.argtypes = [C.c_int, i64, i64, u64, p, p]
+        L.vgo_gen_weights.argtypes = [i64, i64, u64, p]
+        L.vgo_coo_to_csr.argtypes = [i32, i64, p, p, p, p, p]
+        L.vgo_degree_renumber.argtypes = [i32, p, p, p]
+        L.vgo_bfs_top_down.argtypes = [i32, p, p, i32, p, C.POINTER(BfsStats), C.c_int]
+        L.vgo_bfs_seq.argtypes = [i32, p, p, i32, p]
+        L.vgo_sssp_bellman_ford.restype = i32
+        L.vgo_sssp_bellman_ford.argtypes = [i32, p, p, p, i32, p, C.c_int]
+        L.vgo_sssp_dijkstra.argtypes = [i32, p, p, p, i32, p]
+        L.vgo_indegree_noloops.argtypes = [i32, i64, p, p, p]
+        L.vgo_pagerank.argtypes = [i32, p, p, p, C.c_int, C.c_int, p, C.c_int]
+        L.vgo_cc_sv.restype = i32
+        L.vgo_cc_sv.argtypes = [i32, p, p, p, C.c_int]
+        L.vgo_cc_seq_bfs.argtypes = [i32, p, p, p]
+        L.vgo_fnv1a64.restype = u64
+        L.vgo_fnv1a64.argtypes = [p, i64]
+        L.vgo_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+RMAT_ABCD = (57, 19, 19, 5)   # vgl_runtime.hpp:36 / graph_generation.hpp:94
+
+
+def gen_rmat(scale, edge_factor, seed, relabel=True, first_edge=0, count=None):
+    V = 1 << scale
+    E = V * edge_factor if count is None else count
+    src = np.empty(E, np.int32)
+    dst = np.empty(E, np.int32)
+    a, b, c, d = RMAT_ABCD
+    lib().vgo_gen_rmat(scale, first_edge, E, seed, a, b, c, d, int(relabel), _p(src), _p(dst))
+    return src, dst
+
+
+def gen_uniform(scale, edge_factor, seed, first_edge=0, count=None):
+    V = 1 << scale
+    E = V * edge_factor if count is None else count
+    src = np.empty(E, np.int32)
+    dst = np.empty(E, np.int32)
+    lib().vgo_gen_uniform(scale, first_edge, E, seed, _p(src), _p(dst))
+    return src, dst
+
+
+def gen_weights(E, seed, first_edge=0):
+    w = np.empty(E, np.float32)
+    lib().vgo_gen_weights(first_edge, E, seed, _p(w))
+    return w
+
+
+def symmetrize(src, dst):
+    """undirected input for CC: every edge followed (as a block) by its reverse (graph_generation.hpp:41-49)"""
+    return np.concatenate([src, dst]), np.concatenate([dst, src])
+
+
+def coo_to_csr(V, src, dst, want_perm=True):
+    E = len(src)
+    src = np.ascontiguousarray(src, np.int32)
+    dst = np.ascontiguousarray(dst, np.int32)
+    rowptr = np.empty(V + 1, np.int64)
+    adj = np.empty(E, np.int32)
+    perm = np.empty(E, np.int64) if want_perm else None
+    lib().vgo_coo_to_csr(V, E, _p(src), _p(dst), _p(rowptr), _p(adj), _p(perm) if want_perm else None)
+    return rowptr, adj, perm
+
+
+def degree_renumber(rowptr):
+    V = len(rowptr) - 1
+    fwd = np.empty(V, np.int32)
+    bwd = np.empty(V, np.int32)
+    lib().vgo_degree_renumber(V, _p(rowptr), _p(fwd), _p(bwd))
+    return fwd, bwd
+
+
+def bfs_top_down(rowptr, adj, source, parallel=False):
+    V = len(rowptr) - 1
+    levels = np.empty(V, np.int32)
+    st = BfsStats()
+    lib().vgo_bfs_top_down(V, _p(rowptr), _p(adj), source, _p(levels), C.byref(st), int(parallel))
+    return levels, dict(levels=st.levels, edges_examined=st.edges_examined,
+                        frontier_total=st.frontier_total, discovered=st.discovered)
+
+
+def bfs_seq(rowptr, adj, source):
+    V = len(rowptr) - 1
+    levels = np.empty(V, np.int32)
+    lib().vgo_bfs_seq(V, _p(rowptr), _p(adj), source, _p(levels))
+    return levels
+
+
+def sssp_bellman_ford(rowptr, adj, w, source, parallel=False):
+    V = len(rowptr) - 1
+    dist = np.empty(V, np.float32)
+    iters = lib().vgo_sssp_bellman_ford(V, _p(rowptr), _p(adj), _p(w), source, _p(dist), int(parallel))
+    return dist, iters
+
+
+def sssp_dijkstra(rowptr, adj, w, source):
+    V = len(rowptr) - 1
+    dist = np.empty(V, np.float32)
+    lib().vgo_sssp_dijkstra(V, _p(rowptr), _p(adj), _p(w), source, _p(dist))
+    return dist
+
+
+def indegree_noloops(rowptr, adj):
+    V = len(rowptr) - 1
+    indeg = np.empty(V, np.int32)
+    lib().vgo_indegree_noloops(V, len(adj), _p(rowptr), _p(adj), _p(indeg))
+    return indeg
+
+
+def pagerank(rowptr, adj, iterations, dangling_mode=1, parallel=False, indeg=None):
+    V = len(rowptr) - 1
+    if indeg is None:
+        indeg = indegree_noloops(rowptr, adj)
+    ranks = np.empty(V, np.float32)
+    lib().vgo_pagerank(V, _p(rowptr), _p(adj), _p(indeg), iterations, dangling_mode, _p(ranks), int(parallel))
+    return ranks
+
+
+def cc_sv(rowptr, adj, parallel=False):
+    V = len(rowptr) - 1
+    comp = np.empty(V, np.int32)
+    passes = lib().vgo_cc_sv(V, _p(rowptr), _p(adj), _p(comp), int(parallel))
+    return comp, passes
+
+
+def cc_seq_bfs(rowptr, adj):
+    V = len(rowptr) - 1
+    comp = np.empty(V, np.int32)
+    lib().vgo_cc_seq_bfs(V, _p(rowptr), _p(adj), _p(comp))
+    return comp
+
+
+def fnv1a64(a):
+    a = np.ascontiguousarray(a)
+    return int(lib().vgo_fnv1a64(_p(a), a.nbytes))
+
+
+def max_threads():
+    return int(lib().vgo_max_threads())
+
+
+def pick_source(rowptr, seed, k=0):
+    """deterministic stand-in for VGL_Graph::select_random_nz_vertex: first vertex at or after a
+    hashed position that has at least one outgoing edge."""
+    V = len(rowptr) - 1
+    v = int(lib().vgo_splitmix64((seed + 0x9999 + k) & 0xFFFFFFFFFFFFFFFF) % V)
+    for _ in range(V):
+        if rowptr[v + 1] > rowptr[v]:
+            return v
+        v = (v + 1) % V
+    raise ValueError("graph has no edges")
+
+
+def same_partition(a, b):
+    """verify_results.h:198-254 equal_components: label bijection between two labelings"""
+    fwd, bwd = {}, {}
+    for x, y in zip(a.tolist(), b.tolist()):
+        if fwd.setdefault(x, y) != y or bwd.setdefault(y, x) != x:
+            return False
+    return True
+
+
+def write_el_container(path, V, src, dst):
+    """EdgesContainer binary format (edges_container.h:58-77): int V; long long E; int type=4; src[E]; dst[E]"""
+    with open(path, "wb") as f:
+        f.write(np.int32(V).tobytes())
+        f.write(np.int64(len(src)).tobytes())
+        f.write(np.int32(4).tobytes())
+        f.write(np.ascontiguousarray(src, np.int32).tobytes())
+        f.write(np.ascontiguousarray(dst, np.int32).tobytes())
