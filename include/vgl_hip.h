@@ -1,0 +1,190 @@
+/*
+ * vgl_hip.h -- C ABI of libvgl_hip.so, the MI355X (gfx950) backend for VectorGraphLibrary's
+ * frontier-driven advance / compute / reduce / generate_new_frontier hot path.
+ *
+ * Boundary: the reference selects a backend at compile time as a C++ template class
+ * (architecture_independent_api.h:33-43; member list vgl_compute_api/template/
+ * graph_abstractions_template.h:44-104; recipe manuals/add_new_architecture.txt:1-7).
+ * This C ABI is the layer that class binds to (see INTEGRATION.md and
+ * vectorgraphlibrary_amd/hip/graph_abstractions_hip.h): plain pointers and sizes, opaque
+ * handles, `int` status (0 = ok) + vgl_hip_last_error().  All device pointers are raw HIP
+ * device pointers owned by the caller unless stated; every call is ordered on the context's
+ * stream and returns after the work is ENQUEUED unless it has a host-visible result, in which
+ * case it synchronises the stream (the reference GPU backend is synchronous per primitive:
+ * vgl_compute_api/gpu/advance_csr.hpp:204).
+ *
+ * Vertex ids are int32, edge offsets int64, properties 4-byte.
+ */
+#ifndef VGL_HIP_H
+#define VGL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGL_HIP_ABI_VERSION 1
+
+typedef struct vgl_hip_ctx vgl_hip_ctx;
+typedef struct vgl_hip_graph vgl_hip_graph;
+typedef struct vgl_hip_frontier vgl_hip_frontier;
+
+/* ---- context / errors (replaces VGL_RUNTIME::init_library cudaSetDevice path, vgl_runtime.hpp:5-25,
+ *      and the throw "literal" convention, apps/bfs/bfs.cpp:53-61) ---- */
+int vgl_hip_abi_version(void);
+const char *vgl_hip_last_error(void);
+/* stream: a hipStream_t created by the caller (e.g. torch's current stream) or NULL for a private one */
+int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out);
+int vgl_hip_ctx_destroy(vgl_hip_ctx *ctx);
+int vgl_hip_ctx_sync(vgl_hip_ctx *ctx);
+void *vgl_hip_ctx_stream(vgl_hip_ctx *ctx);
+
+/* ---- device memory (replaces MemoryAPI::allocate_array / move_array_to_device, memory_API.hpp:4-15,100-110) ---- */
+int vgl_hip_malloc(vgl_hip_ctx *ctx, size_t bytes, void **dptr);
+int vgl_hip_free(vgl_hip_ctx *ctx, void *dptr);
+int vgl_hip_memcpy_h2d(vgl_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int vgl_hip_memcpy_d2h(vgl_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int vgl_hip_memset(vgl_hip_ctx *ctx, void *dst, int byte_value, size_t bytes);
+
+/* ---- synthetic inputs on the device (GraphGenerationAPI::R_MAT / random_uniform,
+ *      graph_generation.hpp:5-51,94-187; weights common_generator.hpp:23-36).  Counter-based, so
+ *      any [first_edge, first_edge+count) slice can be produced independently on any rank. ---- */
+int vgl_hip_gen_rmat(vgl_hip_ctx *ctx, int scale, int64_t first_edge, int64_t count, uint64_t seed,
+                     int a, int b, int c, int d, int relabel, int32_t *d_src, int32_t *d_dst);
+int vgl_hip_gen_uniform(vgl_hip_ctx *ctx, int scale, int64_t first_edge, int64_t count, uint64_t seed,
+                        int32_t *d_src, int32_t *d_dst);
+int vgl_hip_gen_weights(vgl_hip_ctx *ctx, int64_t first_edge, int64_t count, uint64_t seed, float *d_w);
+
+/* ---- COO -> CSR on the device, stable in input order (CSRGraph::import, csr/import.hpp:3-68).
+ *      Only edges with row_begin <= src < row_end are kept (edge-cut shard, vect_csr/get_api.hpp:66-94);
+ *      d_rowptr has (row_end-row_begin+1) entries rebased to 0, d_adj / d_perm have capacity `count`.
+ *      d_perm (optional) receives the INPUT edge index of every CSR position (edges_reorder_indexes).
+ *      *kept_out = number of edges kept.  Synchronises. ---- */
+int vgl_hip_coo_to_csr(vgl_hip_ctx *ctx, int32_t V, int64_t count, const int32_t *d_src, const int32_t *d_dst,
+                       int32_t row_begin, int32_t row_end,
+                       int64_t *d_rowptr, int32_t *d_adj, int64_t *d_perm, int64_t *kept_out);
+/* out[i] = in[perm[i]] for 4-byte elements (EdgesArray weights follow the CSR order,
+ * csr_edges_array.hpp:31-40) */
+int vgl_hip_gather_u32(vgl_hip_ctx *ctx, int64_t n, const int64_t *d_perm, const void *d_in, void *d_out);
+/* edge-balanced contiguous vertex ranges (VectorCSRGraph::get_mpi_thresholds, vect_csr/get_api.hpp:66-94):
+ * bounds[p] .. bounds[p+1] own ~E/parts edges each.  Host array of parts+1 entries.  Synchronises. */
+int vgl_hip_partition_rows(vgl_hip_ctx *ctx, int32_t V, const int64_t *d_rowptr, int parts, int32_t *bounds_host);
+
+/* ---- graph handle: borrows the caller's device CSR (CSRGraph, csr/csr_graph.h:22-87; VGL_Graph holds an
+ *      outgoing and an incoming container, vgl_graph.h:7-79).  Rows [row_begin,row_end) are present in each
+ *      direction (whole graph: 0..V).  The incoming direction may be NULL when only push algorithms run.
+ *      Creation builds the per-tile row tables the edge-balanced kernels use (derived data, owned). ---- */
+int vgl_hip_graph_create(vgl_hip_ctx *ctx, int32_t V, int32_t row_begin, int32_t row_end,
+                         const int64_t *d_out_rowptr, const int32_t *d_out_adj, int64_t out_edges,
+                         const int64_t *d_in_rowptr, const int32_t *d_in_adj, int64_t in_edges,
+                         vgl_hip_graph **out);
+int vgl_hip_graph_destroy(vgl_hip_ctx *ctx, vgl_hip_graph *g);
+
+/* ---- frontier (BaseFrontier, base_frontier.h:5-62; sparsity enum framework_types.h:156-160) ---- */
+#define VGL_HIP_FRONTIER_DENSE 0
+#define VGL_HIP_FRONTIER_SPARSE 1
+#define VGL_HIP_FRONTIER_ALL_ACTIVE 2
+int vgl_hip_frontier_create(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier **out);
+int vgl_hip_frontier_destroy(vgl_hip_ctx *ctx, vgl_hip_frontier *f);
+int vgl_hip_frontier_set_all_active(vgl_hip_ctx *ctx, vgl_hip_frontier *f);      /* frontier/.../modification.hpp set_all_active */
+int vgl_hip_frontier_clear(vgl_hip_ctx *ctx, vgl_hip_frontier *f);
+int vgl_hip_frontier_add_vertex(vgl_hip_ctx *ctx, vgl_hip_frontier *f, int32_t v); /* only into an empty frontier (modification.hpp:33-36) */
+int vgl_hip_frontier_info(vgl_hip_ctx *ctx, vgl_hip_frontier *f, int32_t *size, int64_t *neighbours, int *sparsity);
+int32_t *vgl_hip_frontier_ids(vgl_hip_frontier *f);    /* device, ascending ids, `size` valid entries when SPARSE */
+int32_t *vgl_hip_frontier_flags(vgl_hip_frontier *f);  /* device, int32[V] 0/1 */
+/* generate_new_frontier from a caller-filled flags array (generate_new_frontier_worker(CSRGraph&),
+ * multicore/generate_new_frontier.hpp:113-164 + copy_if_indexes, copy_if.hpp:128-191): counts, Σdegree,
+ * ALL_ACTIVE when size == V else SPARSE with ascending-id compaction.  d_flags may alias the frontier's own flags.
+ * dense_threshold > 0 selects the VectCSR rule (size > threshold*V => DENSE, flags only; generate_new_frontier.hpp:67-91). */
+int vgl_hip_gnf_from_flags(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_flags, double dense_threshold,
+                           vgl_hip_frontier *f);
+/* same with the predicate (d_values[v] == value) evaluated in-kernel (BFS on_next_level, bfs.hpp:40-45) */
+int vgl_hip_gnf_equal_i32(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_values, int32_t value,
+                          double dense_threshold, vgl_hip_frontier *f);
+
+/* ---- reduce (reduce_worker_sum, multicore/reduce.hpp:6-60; only REDUCE_SUM is live).
+ *      Sums d_values[v] over the frontier's active vertices; deterministic (fixed tree). Synchronises. ---- */
+int vgl_hip_reduce_sum_i32(vgl_hip_ctx *ctx, vgl_hip_frontier *f, const int32_t *d_values, int64_t *result);
+int vgl_hip_reduce_sum_f32(vgl_hip_ctx *ctx, vgl_hip_frontier *f, const float *d_values, double *result);
+/* number of v with a[v] != b[v] (SSSP reduce_changes, shortest_paths.hpp:143-152) */
+int vgl_hip_count_not_equal_u32(vgl_hip_ctx *ctx, int32_t n, const void *d_a, const void *d_b, int64_t *result);
+
+/* ---- fused algorithm fast paths (operators of algorithms/{bfs,sssp,pr,cc}) ---- */
+typedef struct {
+    int32_t levels;            /* frontiers expanded */
+    int32_t td_steps, bu_steps;
+    int64_t edges_examined;    /* adjacency entries actually read by advance kernels */
+    int64_t frontier_total;    /* sum of |F_l| */
+    int64_t discovered;        /* vertices reached, incl. source */
+    int64_t algorithmic_bytes; /* 8*m_ex + 20*n_front + 4*n_disc + 4*V (+ V/8 per bottom-up level) */
+} vgl_hip_bfs_stats;
+#define VGL_HIP_BFS_TOP_DOWN 0           /* BFS::fast_vgl_top_down, bfs.hpp:6-51 */
+#define VGL_HIP_BFS_DIRECTION_OPT 1      /* + bottom-up steps; switch rule change_state.hpp:100-141 (ALPHA 15, BETA 18) */
+int vgl_hip_bfs_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t source, int mode,
+                    int32_t *d_levels, vgl_hip_bfs_stats *stats);
+
+typedef struct {
+    int32_t iterations;
+    int64_t edges_relaxed;     /* edges streamed by relax kernels */
+    int64_t algorithmic_bytes; /* 12*edges_relaxed + 28*V*iterations */
+} vgl_hip_sssp_stats;
+#define VGL_HIP_SSSP_ALL_ACTIVE 0        /* vgl_dijkstra_all_active_push, shortest_paths.hpp:85-163: every iteration streams all edges */
+#define VGL_HIP_SSSP_ACTIVE_TILES 1      /* same fixed point, skips edge tiles whose sources did not change */
+int vgl_hip_sssp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode,
+                     float *d_dist, vgl_hip_sssp_stats *stats);
+
+typedef struct {
+    int32_t iterations;
+    double ranks_sum;          /* reduce_ranks_sum of the last iteration (pr.hpp:130-134) */
+    int64_t algorithmic_bytes; /* (8*E + 28*V) * iterations */
+} vgl_hip_pr_stats;
+/* vgl_page_rank, pr.hpp:7-149 (f32, d = 0.85, fixed iteration count, reversed-graph definition).
+ * d_indeg_noloops: int32[V] = in-degree minus self loops (pr.hpp:31-65), or NULL to have it computed. */
+int vgl_hip_pr_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_indeg_noloops, int iterations,
+                   float *d_ranks, vgl_hip_pr_stats *stats);
+
+typedef struct {
+    int32_t hook_passes;
+    int64_t algorithmic_bytes; /* (8*E + 12*V) per hook pass + 12*V per jump pass */
+} vgl_hip_cc_stats;
+/* vgl_shiloach_vishkin, shiloach_vishkin.hpp:7-88: labels = min id that reaches each vertex */
+int vgl_hip_cc_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc_stats *stats);
+
+/* ---- super-step pieces for the edge-cut multi-GPU path (one process per GPU; the exchange between steps is an
+ *      RCCL collective issued by the host side, replacing common/mpi_exchange.hpp:110-150,222-271) ---- */
+int vgl_hip_bfs_init(vgl_hip_ctx *ctx, int32_t V, int32_t source, int32_t *d_levels);
+/* expand the owned part of level `level`: frontier = owned rows with levels == level.  Writes levels[dst] = level+1
+ * anywhere in the replicated array.  local_frontier/local_edges are host outputs.  Synchronises. */
+int vgl_hip_bfs_step_top_down(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_levels, int32_t level,
+                              int64_t *local_frontier, int64_t *local_edges);
+/* bitmap (V bits, little-endian within uint64 words) of vertices with d_levels == level */
+int vgl_hip_levels_to_bitmap(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_levels, int32_t level, uint64_t *d_bits);
+/* OR `parts` bitmaps (each V/64 words, contiguous) and set levels[v] = level where a bit is set and v is unvisited;
+ * *newly = number of vertices that now have d_levels == level.  Synchronises. */
+int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *ctx, int32_t V, int parts, const uint64_t *d_bits_all,
+                              int32_t *d_levels, int32_t level, int64_t *newly);
+int vgl_hip_sssp_init(vgl_hip_ctx *ctx, int32_t V, int32_t source, float *d_dist);
+/* one all-active push relaxation over the owned rows; *changed = 1 if any distance decreased. Synchronises. */
+int vgl_hip_sssp_relax_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, float *d_dist, int *changed);
+int vgl_hip_cc_init(vgl_hip_ctx *ctx, int32_t V, int32_t *d_comp);
+int vgl_hip_cc_hook_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_comp, int *changed);
+int vgl_hip_cc_jump(vgl_hip_ctx *ctx, int32_t V, int32_t *d_comp);
+/* PageRank pieces: prepare (contrib = old*rdeg, dangling sum over ALL vertices) and pull over the owned rows only;
+ * ranks of owned rows are written, the caller all-gathers owned slices (EXCHANGE_PRIVATE_DATA, pr.hpp:127). */
+int vgl_hip_pr_setup(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_indeg_noloops, float *d_ranks, float *d_rdeg);
+int vgl_hip_pr_iteration_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_indeg_noloops, const float *d_rdeg,
+                               float *d_ranks, float *d_contrib_scratch);
+/* in-degree without self loops from an out-CSR shard (adds into d_indeg; zero it first; allreduce(sum) across shards) */
+int vgl_hip_indegree_noloops_add(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_indeg);
+
+/* ---- kernel timing hooks for bench.py's roofline line: when enabled every launch of the named dominant kernels
+ *      is bracketed by hipEvents on the context stream; totals are read back afterwards. ---- */
+int vgl_hip_timing_enable(vgl_hip_ctx *ctx, int enable);
+int vgl_hip_timing_reset(vgl_hip_ctx *ctx);
+/* kernel_name: "bfs_bottom_up", "bfs_top_down", "gnf", "sssp_relax", "pr_pull", "cc_hook"; returns launches and total ms */
+int vgl_hip_timing_get(vgl_hip_ctx *ctx, const char *kernel_name, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,356 @@
+"""GPU parity tests (run with -m gpu on a MI355X): the HIP path through the C ABI against the CPU oracle on the same
+seeded inputs and against the committed golden vectors of the genuine reference.  Integer / f32-distance results are
+required to be bit-exact; PageRank within 1e-6 relative of the oracle (tolerance from BASELINE.json north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+PR_RTOL = 1e-6
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b.astype(np.float64)), 1e-300)))
+
+
+def build_case(ctx, O, kind, scale, ef, seed, symmetric=False):
+    from vectorgraphlibrary_amd import api
+    V = 1 << scale
+    gen_d = ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform
+    gen_h = O.gen_rmat if kind == "rmat" else O.gen_uniform
+    src, dst = gen_d(scale, ef, seed)
+    hs, hd = gen_h(scale, ef, seed)
+    assert (src.cpu().numpy() == hs).all() and (dst.cpu().numpy() == hd).all(), "device generator != oracle generator"
+    if symmetric:
+        import torch
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+        hs, hd = O.symmetrize(hs, hd)
+    g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True)
+    rowptr, adj, perm = O.coo_to_csr(V, hs, hd)
+    assert (g.out_rowptr.cpu().numpy() == rowptr).all(), "device CSR offsets != oracle"
+    assert (g.out_adj.cpu().numpy() == adj).all(), "device CSR adjacency != oracle (stable order)"
+    assert (g.perm.cpu().numpy() == perm).all()
+    return g, V, hs, hd, rowptr, adj, perm
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_algorithms_match_oracle_and_golden(path, ctx, oracle):
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    z = np.load(path)
+    kind, scale, ef, seed = str(z["kind"]), int(z["scale"]), int(z["edge_factor"]), int(z["seed"])
+    g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, kind, scale, ef, seed)
+    source = int(z["source"])
+    full = "levels" in z.files
+
+    # weights: device generator == oracle generator, CSR order through the permutation
+    w_in_d = ctx.gen_weights(len(hs), seed)
+    w_in = O.gen_weights(len(hs), seed)
+    assert (w_in_d.cpu().numpy().view(np.int32) == w_in.view(np.int32)).all()
+    w_d = ctx.gather_u32(g.perm, w_in_d)
+    w = w_in[perm]
+
+    # ---- BFS: top-down (reference algorithm) and direction-optimising ----
+    ref_levels, ref_st = O.bfs_top_down(rowptr, adj, source)
+    for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+        levels, st = api.bfs(g, source, mode)
+        lv = levels.cpu().numpy()
+        assert (lv == ref_levels).all(), f"BFS mode {mode}: levels differ from the oracle"
+        assert O.fnv1a64(lv) == int(z["bfs_fnv"]), "BFS levels differ from the reference golden"
+        assert st["discovered"] == ref_st["discovered"] and st["frontier_total"] == ref_st["frontier_total"]
+        if mode == api.BFS_TOP_DOWN:
+            assert st["edges_examined"] == ref_st["edges_examined"] and st["levels"] == ref_st["levels"]
+    if full:
+        assert (lv == z["levels"]).all()
+
+    # ---- SSSP: both schedules reach the same bit-exact fixed point ----
+    ref_dist, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+        dist, st = api.sssp(g, w_d, source, mode)
+        dv = dist.cpu().numpy()
+        assert (dv.view(np.int32) == ref_dist.view(np.int32)).all(), f"SSSP mode {mode}: distances differ from the oracle"
+        assert O.fnv1a64(dv) == int(z["sssp_fnv"])
+    if full:
+        assert (dv.view(np.int32) == z["dist"].view(np.int32)).all()
+
+    # ---- PageRank ----
+    it = int(z["pr_iters"])
+    ranks, st = api.page_rank(g, it)
+    rk = ranks.cpu().numpy()
+    ref_rk = O.pagerank(rowptr, adj, it, 1)
+    assert relerr(rk, ref_rk) <= PR_RTOL
+    assert (rk.view(np.int32) == ref_rk.view(np.int32)).all(), "PageRank not bit-identical to the oracle's f32 evaluation order"
+    assert abs(st["ranks_sum"] - float(ref_rk.astype(np.float64).sum())) < 1e-9
+    tol = max(PR_RTOL, float(z["pr_ref_csr_vs_vcsr"]))
+    if full:
+        assert relerr(rk, z["pr_vgl_csr"]) <= tol
+    else:
+        assert relerr(rk[z["sample_idx"]], z["pr_vgl_csr_s"]) <= tol
+    # caller-supplied in-degrees give the same result
+    import torch
+    indeg = torch.from_numpy(O.indegree_noloops(rowptr, adj)).to(ctx.device)
+    ranks2, _ = api.page_rank(g, it, indeg_noloops=indeg)
+    assert (ranks2.cpu().numpy().view(np.int32) == rk.view(np.int32)).all()
+    g.close()
+
+    # ---- CC on the symmetrised graph ----
+    gs, V, hs2, hd2, rp2, adj2, _ = build_case(ctx, O, kind, scale, ef, seed, symmetric=True)
+    comp, st = api.connected_components(gs)
+    cv = comp.cpu().numpy()
+    ref_comp, _ = O.cc_sv(rp2, adj2)
+    assert (cv == ref_comp).all(), "CC labels differ from the oracle"
+    assert O.fnv1a64(cv) == int(z["cc_fnv"])
+    if full:
+        assert (cv == z["comp_csr"]).all()
+    gs.close()
+
+
+def test_directed_cc_and_unreachable(ctx, oracle):
+    """labels on a DIRECTED graph are min{u : u reaches v}; BFS/SSSP leave unreachable vertices at -1 / FLT_MAX."""
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, "rmat", 11, 2, 77)
+    comp, _ = api.connected_components(g)
+    assert (comp.cpu().numpy() == O.cc_sv(rowptr, adj)[0]).all()
+    source = O.pick_source(rowptr, 77)
+    levels, st = api.bfs(g, source, api.BFS_DIRECTION_OPT)
+    ref, _ = O.bfs_top_down(rowptr, adj, source)
+    assert (levels.cpu().numpy() == ref).all() and (ref == -1).sum() > 0
+    w = O.gen_weights(len(hs), 77)[perm]
+    import torch
+    dist, _ = api.sssp(g, torch.from_numpy(w).to(ctx.device), source)
+    dref, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
+    assert (dist.cpu().numpy().view(np.int32) == dref.view(np.int32)).all()
+    assert (dref == np.float32(3.4028234663852886e38)).sum() > 0
+    g.close()
+
+
+def test_tiny_and_ragged_graphs(ctx, oracle):
+    """hand-made inputs: isolated vertices, self loops, duplicates, V not a multiple of the tile / wave sizes, a hub row
+    spanning several edge tiles, empty rows at both ends."""
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    rng = np.random.default_rng(5)
+    V = 1000
+    hub = np.full(5000, 7, np.int32)                     # row 7 spans > 2 tiles
+    src = np.concatenate([hub, rng.integers(10, 900, 3000).astype(np.int32), np.array([7, 7, 950], np.int32)])
+    dst = np.concatenate([rng.integers(0, V, 5000).astype(np.int32), rng.integers(0, 990, 3000).astype(np.int32),
+                          np.array([7, 7, 950], np.int32)])
+    s_d, d_d = torch.from_numpy(src).to(ctx.device), torch.from_numpy(dst).to(ctx.device)
+    g = api.Graph.from_coo(ctx, V, s_d, d_d, want_perm=True)
+    rowptr, adj, perm = O.coo_to_csr(V, src, dst)
+    assert (g.out_adj.cpu().numpy() == adj).all() and (g.out_rowptr.cpu().numpy() == rowptr).all()
+    for source in (7, 10 + int(np.argmax(np.diff(rowptr)[10:900] > 0))):
+        ref, _ = O.bfs_top_down(rowptr, adj, source)
+        for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+            assert (api.bfs(g, source, mode)[0].cpu().numpy() == ref).all()
+    w = O.gen_weights(len(src), 1)[perm]
+    dref, _ = O.sssp_bellman_ford(rowptr, adj, w, 7)
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+        d, _ = api.sssp(g, torch.from_numpy(w).to(ctx.device), 7, mode)
+        assert (d.cpu().numpy().view(np.int32) == dref.view(np.int32)).all()
+    assert (api.connected_components(g)[0].cpu().numpy() == O.cc_sv(rowptr, adj)[0]).all()
+    rk, _ = api.page_rank(g, 4)
+    ref_rk = O.pagerank(rowptr, adj, 4, 1)
+    assert (rk.cpu().numpy().view(np.int32) == ref_rk.view(np.int32)).all()
+    # zero PageRank iterations = the initial vector (pr.hpp:39-44)
+    assert (api.page_rank(g, 0)[0].cpu().numpy() == np.float32(1.0 / V)).all()
+    g.close()
+
+
+def test_frontier_gnf_reduce(ctx, oracle):
+    """generic frontier API: set_all_active / clear / add_vertex / generate_new_frontier / reduce
+    (base_frontier.h, multicore/generate_new_frontier.hpp:113-164, multicore/reduce.hpp)."""
+    import torch
+    from vectorgraphlibrary_amd import api, lib
+    O = oracle
+    g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, "rmat", 13, 8, 9)
+    deg = np.diff(rowptr)
+    f = api.Frontier(g)
+    assert f.info() == (V, len(adj), api.ALL_ACTIVE)
+    vals = torch.arange(V, dtype=torch.int32, device=ctx.device)
+    assert f.reduce_sum(vals) == V * (V - 1) // 2
+    f.clear()
+    assert f.size() == 0
+    f.add_vertex(5)
+    assert f.info() == (1, int(deg[5]), api.SPARSE) and f.ids().tolist() == [5]
+    with pytest.raises(lib.VglHipError):
+        f.add_vertex(6)                                   # only into an empty frontier (modification.hpp:33-36)
+    rng = np.random.default_rng(3)
+    for p in (0.0, 0.001, 0.3, 0.9, 1.0):
+        flags = (rng.random(V) < p).astype(np.int32) * 3  # any non-zero value counts
+        if p == 1.0:
+            flags[:] = 1
+        fl = torch.from_numpy(flags).to(ctx.device)
+        f.generate_from_flags(fl)
+        size, neigh, kind = f.info()
+        want = np.flatnonzero(flags).astype(np.int32)
+        assert size == len(want) and neigh == int(deg[want].sum())
+        assert kind == (api.ALL_ACTIVE if size == V else api.SPARSE)
+        if kind == api.SPARSE:
+            assert (f.ids().numpy() == want).all()        # ascending ids
+        assert (f.flags().numpy() == (flags != 0)).all()
+        fv = torch.from_numpy(rng.random(V).astype(np.float32)).to(ctx.device)
+        assert abs(f.reduce_sum(fv) - float(fv.cpu().numpy().astype(np.float64)[want].sum())) < 1e-6
+        assert f.reduce_sum(vals) == int(want.astype(np.int64).sum())
+        f.generate_from_flags(fl, dense_threshold=0.7)    # VectCSR rule (generate_new_frontier.hpp:67-91)
+        if V > size > 0.7 * V:
+            assert f.info()[2] == api.DENSE
+            assert f.reduce_sum(vals) == int(want.astype(np.int64).sum())
+    levels = torch.from_numpy(rng.integers(-1, 4, V).astype(np.int32)).to(ctx.device)
+    f.generate_equal(levels, 2)
+    assert (f.ids().numpy() == np.flatnonzero(levels.cpu().numpy() == 2)).all()
+    a = torch.from_numpy(rng.integers(0, 3, V).astype(np.int32)).to(ctx.device)
+    b = torch.from_numpy(rng.integers(0, 3, V).astype(np.int32)).to(ctx.device)
+    assert api.count_not_equal(ctx, a, b) == int((a != b).sum())
+    f.close()
+    g.close()
+
+
+def test_sharded_super_steps_single_process(ctx, oracle):
+    """edge-cut shards driven from one process: the per-shard kernels + the bitmap / min exchange reproduce the
+    single-GPU results (the multi-process version of the same protocol is covered with gloo in test_distributed_cpu)."""
+    import torch
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd.distributed import HipShardOps
+    O = oracle
+    g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, "rmat", 12, 16, 21)
+    w = ctx.gather_u32(g.perm, ctx.gen_weights(len(hs), 21))
+    source = O.pick_source(rowptr, 21)
+    P = 3
+    bounds = ctx.partition_rows(g.out_rowptr, P)
+    assert bounds[0] == 0 and bounds[-1] == V and all(b % 64 == 0 for b in bounds[:-1]) and bounds == sorted(bounds)
+    edges = [int(rowptr[bounds[p + 1]] - rowptr[bounds[p]]) for p in range(P)]
+    assert max(edges) < 1.5 * len(adj) / P + 64 * int(np.diff(rowptr).max())
+    shards, ops = [], []
+    for p in range(P):
+        s = g.shard(bounds[p], bounds[p + 1])
+        lo, hi = g.out_edge_range(bounds[p], bounds[p + 1])
+        shards.append(s)
+        ops.append(HipShardOps(s, w[lo:hi].clone()))
+    words = (V + 63) // 64
+
+    # BFS: every shard expands its part of the frontier on its own replica, bitmaps are OR-ed
+    reps = [o.new_i32() for o in ops]
+    for o, r in zip(ops, reps):
+        o.bfs_init(r, source)
+    level = 1
+    while True:
+        everyone = ops[0].new_words(P)
+        for p, (o, r) in enumerate(zip(ops, reps)):
+            o.bfs_step(r, level)
+            o.levels_to_bitmap(r, level + 1, everyone[p * words:(p + 1) * words])
+        newly = [o.apply_bitmaps(P, everyone, r, level + 1) for o, r in zip(ops, reps)]
+        assert len(set(newly)) == 1
+        if newly[0] == 0:
+            break
+        level += 1
+    ref, _ = O.bfs_top_down(rowptr, adj, source)
+    for r in reps:
+        assert (r.cpu().numpy() == ref).all()
+
+    # SSSP: relax owned rows, elementwise min across replicas
+    reps = [o.new_f32() for o in ops]
+    for o, r in zip(ops, reps):
+        o.sssp_init(r, source)
+    while True:
+        ch = [o.sssp_relax(r) for o, r in zip(ops, reps)]
+        m = torch.stack(reps).min(dim=0).values
+        for r in reps:
+            r.copy_(m)
+        if not any(ch):
+            break
+    dref, _ = O.sssp_bellman_ford(rowptr, adj, O.gen_weights(len(hs), 21)[perm], source)
+    assert (reps[0].cpu().numpy().view(np.int32) == dref.view(np.int32)).all()
+
+    # CC (directed labels) and PageRank with owned-slice exchange
+    reps = [o.new_i32() for o in ops]
+    for o, r in zip(ops, reps):
+        o.cc_init(r)
+    while True:
+        ch = [o.cc_hook(r) for o, r in zip(ops, reps)]
+        m = torch.stack(reps).min(dim=0).values
+        for r in reps:
+            r.copy_(m)
+        if not any(ch):
+            break
+        for o, r in zip(ops, reps):
+            o.cc_jump(r)
+    assert (reps[0].cpu().numpy() == O.cc_sv(rowptr, adj)[0]).all()
+
+    indeg = ops[0].new_i32()
+    indeg.zero_()
+    for o in ops:
+        o.indeg_add(indeg)
+    assert (indeg.cpu().numpy() == O.indegree_noloops(rowptr, adj)).all()
+    ranks, rdeg, contrib = ops[0].new_f32(), ops[0].new_f32(), ops[0].new_f32()
+    ops[0].pr_setup(indeg, ranks, rdeg)
+    for _ in range(5):
+        new = [ranks.clone() for _ in range(P)]
+        for p, o in enumerate(ops):
+            o.pr_iteration(indeg, rdeg, new[p], contrib)
+        for p in range(P):
+            ranks[bounds[p]:bounds[p + 1]] = new[p][bounds[p]:bounds[p + 1]]
+    assert (ranks.cpu().numpy().view(np.int32) == O.pagerank(rowptr, adj, 5, 1).view(np.int32)).all()
+    for s in shards:
+        s.close()
+    g.close()
+
+
+@pytest.mark.parametrize("kind,scale", [("rmat", 20), ("ru", 20)])
+def test_large_scale_properties(kind, scale, ctx):
+    """size-independent invariants at a scale the CPU oracle is not asked to run in the GPU suite:
+    DO-BFS == top-down BFS, BFS level consistency over every edge, SSSP fixed point (no violated edge, every
+    finite distance is tight through some in-edge), CC labels closed under edges and idempotent, PageRank mass."""
+    import torch
+    from vectorgraphlibrary_amd import api
+    ef, seed = 16, 11
+    V = 1 << scale
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True)
+    deg = g.out_rowptr[1:] - g.out_rowptr[:-1]
+    source = int(torch.argmax((deg > 0).to(torch.int32)))
+    csr_src = torch.repeat_interleave(torch.arange(V, device=ctx.device), deg)
+    adj = g.out_adj.long()
+
+    lv_td, st_td = api.bfs(g, source, api.BFS_TOP_DOWN)
+    lv_do, st_do = api.bfs(g, source, api.BFS_DIRECTION_OPT)
+    assert torch.equal(lv_td, lv_do)
+    assert st_do["edges_examined"] <= st_td["edges_examined"]
+    ls, ld = lv_td[csr_src], lv_td[adj]
+    reached = ls > 0
+    assert bool((ld[reached] > 0).all()) and bool((ld[reached] <= ls[reached] + 1).all())
+    assert int(lv_td[source]) == 1 and int((lv_td == 1).sum()) == 1
+    # every reached non-source vertex has a parent one level up
+    best = torch.full((V,), 1 << 30, dtype=torch.int32, device=ctx.device)
+    best.scatter_reduce_(0, adj[reached], ls[reached], reduce="amin")
+    nz = (lv_td > 1)
+    assert bool((best[nz] == lv_td[nz] - 1).all())
+
+    w = ctx.gather_u32(g.perm, ctx.gen_weights(src.numel(), seed))
+    d1, s1 = api.sssp(g, w, source, api.SSSP_ACTIVE_TILES)
+    d2, s2 = api.sssp(g, w, source, api.SSSP_ALL_ACTIVE)
+    assert torch.equal(d1.view(torch.int32), d2.view(torch.int32))
+    assert s1["edges_relaxed"] <= s2["edges_relaxed"]
+    fin = d1[csr_src] < 3.0e38
+    cand = d1[csr_src][fin] + w[fin]
+    assert bool((d1[adj[fin]] <= cand).all())                       # no violated edge
+    tight = torch.full((V,), float("inf"), device=ctx.device)
+    tight.scatter_reduce_(0, adj[fin], cand, reduce="amin")
+    m = (d1 < 3.0e38)
+    m[source] = False
+    assert torch.equal(tight[m], d1[m])                             # every finite distance is realised by an in-edge
+    assert torch.equal(d1 < 3.0e38, lv_td > 0)                      # same reachable set as BFS
+
+    comp, _ = api.connected_components(g)
+    assert bool((comp[comp.long()] == comp).all()) and bool((comp[adj] <= comp[csr_src]).all())
+    assert bool((comp <= torch.arange(V, device=ctx.device)).all())
+
+    ranks, st = api.page_rank(g, 3)
+    assert bool((ranks > 0).all()) and abs(st["ranks_sum"] - float(ranks.double().sum())) < 1e-9
+    g.close()

@@ -1,0 +1,252 @@
+"""Host-side harness over the C ABI (include/vgl_hip.h): graph construction, frontier objects and the
+fused BFS / SSSP / PageRank / CC entry points, with torch tensors used only as device-memory handles
+(pointers and sizes cross the boundary; no torch types do).
+
+Names follow the reference: VGL_Graph -> Graph (outgoing + incoming CSR, vgl_graph.h:7-79),
+VGL_Frontier -> Frontier (base_frontier.h:5-62), algorithms/{bfs,sssp,pr,cc} -> bfs(), sssp(), page_rank(),
+connected_components().  The C++ drop-in class for arbitrary user lambdas is
+vectorgraphlibrary_amd/hip/graph_abstractions_hip.h.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _l
+
+RMAT_ABCD = (57, 19, 19, 5)            # vgl_runtime.hpp:36
+BFS_TOP_DOWN, BFS_DIRECTION_OPT = 0, 1
+SSSP_ALL_ACTIVE, SSSP_ACTIVE_TILES = 0, 1
+DENSE, SPARSE, ALL_ACTIVE = 0, 1, 2    # framework_types.h:156-160
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Context:
+    """One per GPU / process.  Work is ordered on torch's current stream of `device` so that it composes
+    with torch.distributed (RCCL) collectives issued from the same process."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise _l.VglHipError("no HIP device visible: vectorgraphlibrary_amd has no CPU fallback")
+        self.L = _l.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        _l.check(self.L.vgl_hip_ctx_create(device, C.c_void_p(stream), C.byref(h)))
+        self.h = h
+
+    def sync(self):
+        _l.check(self.L.vgl_hip_ctx_sync(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.vgl_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def empty(self, n, dtype):
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    # ---- timing hooks (bench.py roofline) ----
+    def timing(self, enable=True):
+        _l.check(self.L.vgl_hip_timing_enable(self.h, int(enable)))
+        _l.check(self.L.vgl_hip_timing_reset(self.h))
+
+    def timing_get(self, name):
+        n, ms = C.c_int64(), C.c_double()
+        _l.check(self.L.vgl_hip_timing_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # ---- synthetic inputs ----
+    def gen_rmat(self, scale, edge_factor, seed, relabel=True, first_edge=0, count=None):
+        E = (1 << scale) * edge_factor if count is None else count
+        src, dst = self.empty(E, torch.int32), self.empty(E, torch.int32)
+        a, b, c, d = RMAT_ABCD
+        _l.check(self.L.vgl_hip_gen_rmat(self.h, scale, first_edge, E, seed, a, b, c, d, int(relabel), _ptr(src), _ptr(dst)))
+        return src, dst
+
+    def gen_uniform(self, scale, edge_factor, seed, first_edge=0, count=None):
+        E = (1 << scale) * edge_factor if count is None else count
+        src, dst = self.empty(E, torch.int32), self.empty(E, torch.int32)
+        _l.check(self.L.vgl_hip_gen_uniform(self.h, scale, first_edge, E, seed, _ptr(src), _ptr(dst)))
+        return src, dst
+
+    def gen_weights(self, E, seed, first_edge=0):
+        w = self.empty(E, torch.float32)
+        _l.check(self.L.vgl_hip_gen_weights(self.h, first_edge, E, seed, _ptr(w)))
+        return w
+
+    def coo_to_csr(self, V, src, dst, row_begin=0, row_end=None, want_perm=False):
+        """stable COO -> CSR of the edges whose source lies in [row_begin,row_end)."""
+        row_end = V if row_end is None else row_end
+        E = src.numel()
+        rowptr = self.empty(row_end - row_begin + 1, torch.int64)
+        adj = self.empty(max(E, 1), torch.int32)
+        perm = self.empty(max(E, 1), torch.int64) if want_perm else None
+        kept = C.c_int64()
+        _l.check(self.L.vgl_hip_coo_to_csr(self.h, V, E, _ptr(src), _ptr(dst), row_begin, row_end, _ptr(rowptr), _ptr(adj),
+                                           _ptr(perm), C.byref(kept)))
+        k = kept.value
+        return rowptr, adj[:k], (perm[:k] if want_perm else None)
+
+    def gather_u32(self, perm, values):
+        out = torch.empty(perm.numel(), dtype=values.dtype, device=self.device)
+        _l.check(self.L.vgl_hip_gather_u32(self.h, perm.numel(), _ptr(perm), _ptr(values), _ptr(out)))
+        return out
+
+    def partition_rows(self, rowptr, parts):
+        V = rowptr.numel() - 1
+        bounds = (C.c_int32 * (parts + 1))()
+        _l.check(self.L.vgl_hip_partition_rows(self.h, V, _ptr(rowptr), parts, bounds))
+        return list(bounds)
+
+
+class Graph:
+    """Device CSR in both directions (or outgoing only), optionally restricted to the owned rows [row_begin,row_end)."""
+
+    def __init__(self, ctx, V, out_rowptr, out_adj, in_rowptr=None, in_adj=None, row_begin=0, row_end=None):
+        self.ctx, self.V = ctx, int(V)
+        self.row_begin, self.row_end = int(row_begin), int(V if row_end is None else row_end)
+        self.out_rowptr, self.out_adj, self.in_rowptr, self.in_adj = out_rowptr, out_adj, in_rowptr, in_adj
+        self.E = int(out_adj.numel())
+        h = C.c_void_p()
+        _l.check(ctx.L.vgl_hip_graph_create(ctx.h, self.V, self.row_begin, self.row_end, _ptr(out_rowptr), _ptr(out_adj), self.E,
+                                            _ptr(in_rowptr), _ptr(in_adj), int(in_adj.numel()) if in_adj is not None else 0,
+                                            C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_coo(cls, ctx, V, src, dst, with_incoming=True, want_perm=False):
+        """VGL_Graph::import (vgl_graph.hpp:57-68): outgoing CSR from (src,dst), incoming CSR from the OUT-CSR-ordered
+        transposed list (the container is sorted in place by the outgoing import before it is transposed)."""
+        rowptr, adj, perm = ctx.coo_to_csr(V, src, dst, want_perm=want_perm)
+        in_rowptr = in_adj = None
+        if with_incoming:
+            deg = rowptr[1:] - rowptr[:-1]
+            csr_src = torch.repeat_interleave(torch.arange(V, device=ctx.device, dtype=torch.int32), deg)
+            in_rowptr, in_adj, _ = ctx.coo_to_csr(V, adj, csr_src)
+            del csr_src
+        g = cls(ctx, V, rowptr, adj, in_rowptr, in_adj)
+        g.perm = perm
+        return g
+
+    def shard(self, row_begin, row_end):
+        """edge-cut shard owning rows [row_begin,row_end) of both directions (own, aligned copies of the slices)."""
+        def cut(rowptr, adj):
+            if rowptr is None:
+                return None, None
+            lo, hi = int(rowptr[row_begin]), int(rowptr[row_end])
+            return (rowptr[row_begin:row_end + 1] - lo).contiguous(), adj[lo:hi].clone()
+        orp, oadj = cut(self.out_rowptr, self.out_adj)
+        irp, iadj = cut(self.in_rowptr, self.in_adj)
+        return Graph(self.ctx, self.V, orp, oadj, irp, iadj, row_begin, row_end)
+
+    def out_edge_range(self, row_begin, row_end):
+        return int(self.out_rowptr[row_begin]), int(self.out_rowptr[row_end])
+
+    def close(self):
+        if self.h:
+            self.ctx.L.vgl_hip_graph_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class Frontier:
+    def __init__(self, graph):
+        self.g, self.ctx = graph, graph.ctx
+        h = C.c_void_p()
+        _l.check(self.ctx.L.vgl_hip_frontier_create(self.ctx.h, graph.h, C.byref(h)))
+        self.h = h
+
+    def set_all_active(self):
+        _l.check(self.ctx.L.vgl_hip_frontier_set_all_active(self.ctx.h, self.h))
+
+    def clear(self):
+        _l.check(self.ctx.L.vgl_hip_frontier_clear(self.ctx.h, self.h))
+
+    def add_vertex(self, v):
+        _l.check(self.ctx.L.vgl_hip_frontier_add_vertex(self.ctx.h, self.h, int(v)))
+
+    def info(self):
+        s, n, t = C.c_int32(), C.c_int64(), C.c_int()
+        _l.check(self.ctx.L.vgl_hip_frontier_info(self.ctx.h, self.h, C.byref(s), C.byref(n), C.byref(t)))
+        return s.value, n.value, t.value
+
+    def size(self):
+        return self.info()[0]
+
+    def _view(self, ptr, n):
+        if n == 0:
+            return torch.empty(0, dtype=torch.int32)
+        buf = torch.empty(n, dtype=torch.int32)
+        _l.check(self.ctx.L.vgl_hip_memcpy_d2h(self.ctx.h, C.c_void_p(buf.data_ptr()), C.c_void_p(ptr), n * 4))
+        return buf
+
+    def ids(self):
+        return self._view(self.ctx.L.vgl_hip_frontier_ids(self.h), self.size())
+
+    def flags(self):
+        return self._view(self.ctx.L.vgl_hip_frontier_flags(self.h), self.g.V)
+
+    def generate_from_flags(self, flags, dense_threshold=0.0):
+        _l.check(self.ctx.L.vgl_hip_gnf_from_flags(self.ctx.h, self.g.h, _ptr(flags), float(dense_threshold), self.h))
+
+    def generate_equal(self, values, value, dense_threshold=0.0):
+        _l.check(self.ctx.L.vgl_hip_gnf_equal_i32(self.ctx.h, self.g.h, _ptr(values), int(value), float(dense_threshold), self.h))
+
+    def reduce_sum(self, values):
+        if values.dtype == torch.int32:
+            r = C.c_int64()
+            _l.check(self.ctx.L.vgl_hip_reduce_sum_i32(self.ctx.h, self.h, _ptr(values), C.byref(r)))
+        else:
+            r = C.c_double()
+            _l.check(self.ctx.L.vgl_hip_reduce_sum_f32(self.ctx.h, self.h, _ptr(values), C.byref(r)))
+        return r.value
+
+    def close(self):
+        if self.h:
+            self.ctx.L.vgl_hip_frontier_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+def _stats(s):
+    return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def bfs(graph, source, mode=BFS_DIRECTION_OPT, levels=None):
+    ctx = graph.ctx
+    levels = ctx.empty(graph.V, torch.int32) if levels is None else levels
+    st = _l.BfsStats()
+    _l.check(ctx.L.vgl_hip_bfs_run(ctx.h, graph.h, int(source), mode, _ptr(levels), C.byref(st)))
+    return levels, _stats(st)
+
+
+def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None):
+    ctx = graph.ctx
+    dist = ctx.empty(graph.V, torch.float32) if dist is None else dist
+    st = _l.SsspStats()
+    _l.check(ctx.L.vgl_hip_sssp_run(ctx.h, graph.h, _ptr(weights), int(source), mode, _ptr(dist), C.byref(st)))
+    return dist, _stats(st)
+
+
+def page_rank(graph, iterations, indeg_noloops=None, ranks=None):
+    ctx = graph.ctx
+    ranks = ctx.empty(graph.V, torch.float32) if ranks is None else ranks
+    st = _l.PrStats()
+    _l.check(ctx.L.vgl_hip_pr_run(ctx.h, graph.h, _ptr(indeg_noloops), int(iterations), _ptr(ranks), C.byref(st)))
+    return ranks, _stats(st)
+
+
+def connected_components(graph, comp=None):
+    ctx = graph.ctx
+    comp = ctx.empty(graph.V, torch.int32) if comp is None else comp
+    st = _l.CcStats()
+    _l.check(ctx.L.vgl_hip_cc_run(ctx.h, graph.h, _ptr(comp), C.byref(st)))
+    return comp, _stats(st)
+
+
+def count_not_equal(ctx, a, b):
+    r = C.c_int64()
+    _l.check(ctx.L.vgl_hip_count_not_equal_u32(ctx.h, a.numel(), _ptr(a), _ptr(b), C.byref(r)))
+    return r.value

@@ -1,0 +1,186 @@
+// context.hip -- context, error reporting, device memory, kernel timing hooks.
+#include "vgl_hip_internal.h"
+#include <cstdio>
+#include <cstring>
+
+static thread_local std::string g_last_error;
+
+int vgl_set_error(const char *file, int line, const char *msg)
+{
+    char buf[512];
+    const char *base = strrchr(file, '/');
+    snprintf(buf, sizeof(buf), "vgl_hip: %s (%s:%d)", msg, base ? base + 1 : file, line);
+    g_last_error = buf;
+    return 1;
+}
+
+extern "C" {
+
+int vgl_hip_abi_version(void) { return VGL_HIP_ABI_VERSION; }
+const char *vgl_hip_last_error(void) { return g_last_error.c_str(); }
+
+int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out)
+{
+    if (!out) VGL_FAIL("ctx_create: null out pointer");
+    int ndev = 0;
+    VGL_HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) VGL_FAIL("no HIP device visible: the MI355X backend has no CPU fallback");
+    if (device < 0 || device >= ndev) VGL_FAIL("ctx_create: device index out of range");
+    VGL_HIP_TRY(hipSetDevice(device));
+    vgl_hip_ctx *c = new vgl_hip_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { VGL_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    VGL_HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(int64_t) * C_NSLOTS));
+    VGL_HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(int64_t) * C_NSLOTS, hipHostMallocDefault));
+    VGL_HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(int64_t) * C_NSLOTS, c->stream));
+    memset(c->h_counters, 0, sizeof(int64_t) * C_NSLOTS);
+    *out = c;
+    return 0;
+}
+
+int vgl_hip_ctx_destroy(vgl_hip_ctx *c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &kv : c->slots)
+        for (auto &p : kv.second.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    if (c->d_partials) hipFree(c->d_partials);
+    hipFree(c->d_counters);
+    hipHostFree(c->h_counters);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int vgl_hip_ctx_sync(vgl_hip_ctx *c)
+{
+    if (!c) VGL_FAIL("null context");
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void *vgl_hip_ctx_stream(vgl_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int vgl_hip_malloc(vgl_hip_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) VGL_FAIL("malloc: null argument");
+    VGL_HIP_TRY(hipSetDevice(c->device));
+    VGL_HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+int vgl_hip_free(vgl_hip_ctx *c, void *dptr)
+{
+    if (!c) VGL_FAIL("free: null context");
+    if (dptr) { VGL_HIP_TRY(hipStreamSynchronize(c->stream)); VGL_HIP_TRY(hipFree(dptr)); }
+    return 0;
+}
+int vgl_hip_memcpy_h2d(vgl_hip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) VGL_FAIL("memcpy: null context");
+    if (bytes == 0) return 0;
+    VGL_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int vgl_hip_memcpy_d2h(vgl_hip_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) VGL_FAIL("memcpy: null context");
+    if (bytes == 0) return 0;
+    VGL_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int vgl_hip_memset(vgl_hip_ctx *c, void *dst, int byte_value, size_t bytes)
+{
+    if (!c) VGL_FAIL("memset: null context");
+    if (bytes == 0) return 0;
+    VGL_HIP_TRY(hipMemsetAsync(dst, byte_value, bytes, c->stream));
+    return 0;
+}
+
+int vgl_hip_timing_enable(vgl_hip_ctx *c, int enable)
+{
+    if (!c) VGL_FAIL("null context");
+    c->timing = enable != 0;
+    return 0;
+}
+int vgl_hip_timing_reset(vgl_hip_ctx *c)
+{
+    if (!c) VGL_FAIL("null context");
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &kv : c->slots) {
+        for (auto &p : kv.second.pending) { c->event_pool.push_back(p.first); c->event_pool.push_back(p.second); }
+        kv.second.pending.clear();
+        kv.second.launches = 0;
+        kv.second.total_ms = 0.0;
+    }
+    return 0;
+}
+int vgl_hip_timing_get(vgl_hip_ctx *c, const char *name, int64_t *launches, double *total_ms)
+{
+    if (!c || !name) VGL_FAIL("null argument");
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    auto it = c->slots.find(name);
+    if (it == c->slots.end()) { if (launches) *launches = 0; if (total_ms) *total_ms = 0.0; return 0; }
+    vgl_timing_slot &s = it->second;
+    for (auto &p : s.pending) {
+        float ms = 0.f;
+        VGL_HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        s.total_ms += ms;
+        c->event_pool.push_back(p.first);
+        c->event_pool.push_back(p.second);
+    }
+    s.pending.clear();
+    if (launches) *launches = s.launches;
+    if (total_ms) *total_ms = s.total_ms;
+    return 0;
+}
+
+}  // extern "C"
+
+static hipEvent_t vgl_get_event(vgl_hip_ctx *c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+vgl_timed_launch::vgl_timed_launch(vgl_hip_ctx *c, const char *name) : ctx(c), slot(nullptr), a(nullptr), b(nullptr)
+{
+    if (!c->timing) return;
+    slot = &c->slots[name];
+    a = vgl_get_event(c);
+    b = vgl_get_event(c);
+    hipEventRecord(a, c->stream);
+}
+vgl_timed_launch::~vgl_timed_launch()
+{
+    if (!slot) return;
+    hipEventRecord(b, ctx->stream);
+    slot->pending.emplace_back(a, b);
+    slot->launches++;
+}
+
+int vgl_read_counters(vgl_hip_ctx *c)
+{
+    VGL_HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(int64_t) * C_NSLOTS, hipMemcpyDeviceToHost, c->stream));
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int vgl_zero_counters(vgl_hip_ctx *c, int first, int count)
+{
+    VGL_HIP_TRY(hipMemsetAsync(c->d_counters + first, 0, sizeof(int64_t) * count, c->stream));
+    return 0;
+}
+int vgl_ensure_partials(vgl_hip_ctx *c, size_t n)
+{
+    if (c->partials_cap >= n) return 0;
+    if (c->d_partials) { VGL_HIP_TRY(hipStreamSynchronize(c->stream)); VGL_HIP_TRY(hipFree(c->d_partials)); }
+    VGL_HIP_TRY(hipMalloc((void **)&c->d_partials, sizeof(double) * n));
+    c->partials_cap = n;
+    return 0;
+}

@@ -1,0 +1,284 @@
+// graph_frontier.hip -- graph handle (borrowed CSR + derived tile tables), frontier object,
+// generate_new_frontier entry points and the reduce primitive.
+#include "vgl_hip_internal.h"
+#include "vgl_gnf.h"
+
+// tile_row[t] = local row containing edge t*VGL_TILE: row r covers tiles [ceil(start/T), ceil(end/T))
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_rows(int32_t nrows, const int64_t *rowptr, int32_t *tile_row, int64_t ntiles)
+{
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK) {
+        const int64_t t0 = (rowptr[r] + VGL_TILE - 1) / VGL_TILE;
+        const int64_t t1 = (rowptr[r + 1] + VGL_TILE - 1) / VGL_TILE;
+        for (int64_t t = t0; t < t1; t++) tile_row[t] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) tile_row[ntiles] = nrows > 0 ? nrows - 1 : 0;
+}
+
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_iota_flags(int32_t n, int32_t *ids, int32_t *flags, int32_t flag)
+{
+    for (int32_t i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
+        if (ids) ids[i] = i;
+        flags[i] = flag;
+    }
+}
+__global__ void vgl_k_add_vertex(int32_t v, int32_t *ids, int32_t *flags) { ids[0] = v; flags[v] = 1; }
+
+// deterministic two-stage sums: per-workgroup partials (fixed shape) then one workgroup adds them in order
+template <class T, class ACC, int MODE>   // MODE 0: all, 1: flags, 2: ids
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_reduce_partial(int32_t n, const T *values, const int32_t *flags,
+                                                                  const int32_t *ids, double *partials)
+{
+    __shared__ ACC s[VGL_WAVES];
+    ACC acc = 0;
+    for (int32_t i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
+        if (MODE == 0) acc += (ACC)values[i];
+        else if (MODE == 1) { if (flags[i]) acc += (ACC)values[i]; }
+        else acc += (ACC)values[ids[i]];
+    }
+    acc = vgl_block_reduce_add(acc, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = (double)acc;
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_neq_partial(int32_t n, const uint32_t *a, const uint32_t *b, double *partials)
+{
+    __shared__ int64_t s[VGL_WAVES];
+    int64_t acc = 0;
+    for (int32_t i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) acc += (a[i] != b[i]);
+    acc = vgl_block_reduce_add(acc, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = (double)acc;
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_reduce_final(int nparts, const double *partials, double *out)
+{
+    __shared__ double s[VGL_WAVES];
+    double acc = 0;
+    for (int i = threadIdx.x; i < nparts; i += VGL_BLOCK) acc += partials[i];
+    acc = vgl_block_reduce_add(acc, s);
+    if (threadIdx.x == 0) *out = acc;
+}
+
+static int vgl_build_dir(vgl_hip_ctx *c, vgl_dir_csr &d, int32_t nrows)
+{
+    d.ntiles = vgl_ceil_div(d.edges, VGL_TILE);
+    VGL_HIP_TRY(hipMalloc((void **)&d.tile_row, sizeof(int32_t) * ((size_t)d.ntiles + 2)));
+    int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, vgl_ceil_div(nrows, VGL_BLOCK)));
+    hipLaunchKernelGGL(vgl_k_tile_rows, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, nrows, d.rowptr, d.tile_row, d.ntiles);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T>
+static int vgl_alloc(T **p, size_t n) { VGL_HIP_TRY(hipMalloc((void **)p, sizeof(T) * (n ? n : 1))); return 0; }
+
+static int vgl_reduce_common(vgl_hip_ctx *c, int nblocks, double *result)
+{
+    hipLaunchKernelGGL(vgl_k_reduce_final, dim3(1), dim3(VGL_BLOCK), 0, c->stream, nblocks, c->d_partials, c->d_partials + nblocks);
+    VGL_HIP_TRY(hipGetLastError());
+    VGL_HIP_TRY(hipMemcpyAsync(result, c->d_partials + nblocks, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" {
+
+int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t row_end,
+                         const int64_t *d_out_rowptr, const int32_t *d_out_adj, int64_t out_edges,
+                         const int64_t *d_in_rowptr, const int32_t *d_in_adj, int64_t in_edges, vgl_hip_graph **out)
+{
+    if (!c || !out) VGL_FAIL("graph_create: null argument");
+    if (V <= 0) VGL_FAIL("graph_create: vertices_count must be positive");
+    if (row_begin < 0 || row_end > V || row_begin >= row_end) VGL_FAIL("graph_create: bad owned row range");
+    if (row_begin % 64 != 0) VGL_FAIL("graph_create: row_begin must be a multiple of 64 (use vgl_hip_partition_rows)");
+    if (!d_out_rowptr || (!d_out_adj && out_edges > 0)) VGL_FAIL("graph_create: outgoing CSR is required");
+    if (out_edges < 0 || in_edges < 0) VGL_FAIL("graph_create: negative edge count");
+    VGL_HIP_TRY(hipSetDevice(c->device));
+    vgl_hip_graph *g = new vgl_hip_graph();
+    g->V = V; g->row_begin = row_begin; g->row_end = row_end; g->nrows = row_end - row_begin;
+    g->out.rowptr = d_out_rowptr; g->out.adj = d_out_adj; g->out.edges = out_edges;
+    VGL_TRY(vgl_build_dir(c, g->out, g->nrows));
+    if (d_in_rowptr) {
+        g->in.rowptr = d_in_rowptr; g->in.adj = d_in_adj; g->in.edges = in_edges;
+        VGL_TRY(vgl_build_dir(c, g->in, g->nrows));
+    }
+    const size_t words = (size_t)vgl_ceil_div(V, 64) + 1;
+    VGL_TRY(vgl_alloc(&g->bm_visited, words));
+    VGL_TRY(vgl_alloc(&g->bm_front, words));
+    VGL_TRY(vgl_alloc(&g->bm_next, words));
+    VGL_TRY(vgl_alloc(&g->ids, (size_t)g->nrows));
+    VGL_TRY(vgl_alloc(&g->offs, (size_t)g->nrows + 1));
+    g->nvtiles = vgl_ceil_div(g->nrows, VGL_TILE);
+    VGL_TRY(vgl_alloc(&g->vt_cnt, (size_t)g->nvtiles));
+    VGL_TRY(vgl_alloc(&g->vt_cnt_off, (size_t)g->nvtiles));
+    VGL_TRY(vgl_alloc(&g->vt_deg, (size_t)g->nvtiles));
+    VGL_TRY(vgl_alloc(&g->vt_deg_off, (size_t)g->nvtiles));
+    VGL_TRY(vgl_alloc(&g->tile_first, (size_t)g->out.ntiles + 2));
+    VGL_TRY(vgl_alloc(&g->heavy, (size_t)g->nrows));
+    VGL_TRY(vgl_alloc(&g->epoch, (size_t)V));
+    VGL_TRY(vgl_alloc(&g->fscratch, (size_t)V));
+    VGL_TRY(vgl_alloc(&g->fscratch2, (size_t)V));
+    VGL_TRY(vgl_alloc(&g->fscratch3, (size_t)V));
+    VGL_TRY(vgl_alloc(&g->iscratch, (size_t)V));
+    VGL_HIP_TRY(hipMemsetAsync(g->bm_visited, 0, words * 8, c->stream));
+    VGL_HIP_TRY(hipMemsetAsync(g->bm_front, 0, words * 8, c->stream));
+    VGL_HIP_TRY(hipMemsetAsync(g->bm_next, 0, words * 8, c->stream));
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = g;
+    return 0;
+}
+
+int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
+{
+    if (!g) return 0;
+    if (c) hipStreamSynchronize(c->stream);
+    void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->ids, g->offs, g->vt_cnt,
+                    g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->epoch, g->fscratch, g->fscratch2,
+                    g->fscratch3, g->iscratch};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete g;
+    return 0;
+}
+
+int vgl_hip_frontier_create(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier **out)
+{
+    if (!c || !g || !out) VGL_FAIL("frontier_create: null argument");
+    vgl_hip_frontier *f = new vgl_hip_frontier();
+    f->g = g;
+    VGL_TRY(vgl_alloc(&f->flags, (size_t)g->V));
+    VGL_TRY(vgl_alloc(&f->ids, (size_t)g->V));
+    *out = f;
+    return vgl_hip_frontier_set_all_active(c, f);   // VGL frontiers start all-active (base_frontier.h ctor)
+}
+int vgl_hip_frontier_destroy(vgl_hip_ctx *c, vgl_hip_frontier *f)
+{
+    if (!f) return 0;
+    if (c) hipStreamSynchronize(c->stream);
+    hipFree(f->flags); hipFree(f->ids);
+    delete f;
+    return 0;
+}
+int vgl_hip_frontier_set_all_active(vgl_hip_ctx *c, vgl_hip_frontier *f)
+{
+    if (!c || !f) VGL_FAIL("null argument");
+    const int32_t V = f->g->V;
+    hipLaunchKernelGGL(vgl_k_iota_flags, dim3((unsigned)std::min<int64_t>(4096, vgl_ceil_div(V, VGL_BLOCK))), dim3(VGL_BLOCK), 0,
+                       c->stream, V, f->ids, f->flags, 1);
+    VGL_HIP_TRY(hipGetLastError());
+    f->size = V; f->neighbours = f->g->out.edges; f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE;
+    return 0;
+}
+int vgl_hip_frontier_clear(vgl_hip_ctx *c, vgl_hip_frontier *f)
+{
+    if (!c || !f) VGL_FAIL("null argument");
+    VGL_HIP_TRY(hipMemsetAsync(f->flags, 0, sizeof(int32_t) * (size_t)f->g->V, c->stream));
+    f->size = 0; f->neighbours = 0; f->sparsity = VGL_HIP_FRONTIER_SPARSE;
+    return 0;
+}
+int vgl_hip_frontier_add_vertex(vgl_hip_ctx *c, vgl_hip_frontier *f, int32_t v)
+{
+    if (!c || !f) VGL_FAIL("null argument");
+    if (f->size > 0) VGL_FAIL("VGL error! can not add vertex to non-empty frontier");   // modification.hpp:33-36
+    if (v < 0 || v >= f->g->V) VGL_FAIL("frontier_add_vertex: vertex id out of range");
+    hipLaunchKernelGGL(vgl_k_add_vertex, dim3(1), dim3(1), 0, c->stream, v, f->ids, f->flags);
+    VGL_HIP_TRY(hipGetLastError());
+    f->size = 1; f->sparsity = VGL_HIP_FRONTIER_SPARSE;
+    int64_t rp[2] = {0, 0};
+    if (v >= f->g->row_begin && v < f->g->row_end)
+        VGL_TRY(vgl_hip_memcpy_d2h(c, rp, f->g->out.rowptr + (v - f->g->row_begin), sizeof(rp)));
+    f->neighbours = rp[1] - rp[0];
+    return 0;
+}
+int vgl_hip_frontier_info(vgl_hip_ctx *c, vgl_hip_frontier *f, int32_t *size, int64_t *neighbours, int *sparsity)
+{
+    if (!c || !f) VGL_FAIL("null argument");
+    if (size) *size = f->size;
+    if (neighbours) *neighbours = f->neighbours;
+    if (sparsity) *sparsity = f->sparsity;
+    return 0;
+}
+int32_t *vgl_hip_frontier_ids(vgl_hip_frontier *f) { return f ? f->ids : nullptr; }
+int32_t *vgl_hip_frontier_flags(vgl_hip_frontier *f) { return f ? f->flags : nullptr; }
+
+}  // extern "C"
+
+template <class Pred>
+static int vgl_gnf_frontier(vgl_hip_ctx *c, vgl_hip_graph *g, Pred pred, double dense_threshold, vgl_hip_frontier *f,
+                            int32_t *flags_out)
+{
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("generate_new_frontier: graph handle must own all rows");
+    // pass 1+2: flags, counts, totals
+    VGL_TRY(vgl_gnf_run(c, g, pred, f->ids, nullptr, nullptr, nullptr, nullptr, flags_out, false, true));
+    f->size = (int32_t)c->h_counters[C_FRONT];
+    f->neighbours = c->h_counters[C_NEIGH];
+    if (f->size == g->V) { f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE; }
+    else if (dense_threshold > 0.0 && (double)f->size / g->V > dense_threshold) { f->sparsity = VGL_HIP_FRONTIER_DENSE; }
+    else {
+        f->sparsity = VGL_HIP_FRONTIER_SPARSE;
+        vgl_timed_launch tl(c, "gnf");
+        hipLaunchKernelGGL(vgl_k_gnf_write<Pred>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows,
+                           g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, f->ids, (int64_t *)nullptr);
+    }
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int vgl_hip_gnf_from_flags(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *d_flags, double dense_threshold, vgl_hip_frontier *f)
+{
+    if (!c || !g || !f || !d_flags) VGL_FAIL("gnf_from_flags: null argument");
+    vgl_pred_nonzero_i32 pred{d_flags};
+    return vgl_gnf_frontier(c, g, pred, dense_threshold, f, f->flags);
+}
+int vgl_hip_gnf_equal_i32(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *d_values, int32_t value, double dense_threshold,
+                          vgl_hip_frontier *f)
+{
+    if (!c || !g || !f || !d_values) VGL_FAIL("gnf_equal_i32: null argument");
+    vgl_pred_equal_i32 pred{d_values, value};
+    return vgl_gnf_frontier(c, g, pred, dense_threshold, f, f->flags);
+}
+
+int vgl_hip_reduce_sum_i32(vgl_hip_ctx *c, vgl_hip_frontier *f, const int32_t *d_values, int64_t *result)
+{
+    if (!c || !f || !d_values || !result) VGL_FAIL("reduce: null argument");
+    const int32_t n = (f->sparsity == VGL_HIP_FRONTIER_SPARSE) ? f->size : f->g->V;
+    if (n == 0) { *result = 0; return 0; }
+    const int nb = (int)std::min<int64_t>(1024, vgl_ceil_div(n, VGL_BLOCK));
+    VGL_TRY(vgl_ensure_partials(c, (size_t)nb + 1));
+    if (f->sparsity == VGL_HIP_FRONTIER_ALL_ACTIVE)
+        hipLaunchKernelGGL((vgl_k_reduce_partial<int32_t, int64_t, 0>), dim3(nb), dim3(VGL_BLOCK), 0, c->stream, n, d_values, f->flags, f->ids, c->d_partials);
+    else if (f->sparsity == VGL_HIP_FRONTIER_DENSE)
+        hipLaunchKernelGGL((vgl_k_reduce_partial<int32_t, int64_t, 1>), dim3(nb), dim3(VGL_BLOCK), 0, c->stream, n, d_values, f->flags, f->ids, c->d_partials);
+    else
+        hipLaunchKernelGGL((vgl_k_reduce_partial<int32_t, int64_t, 2>), dim3(nb), dim3(VGL_BLOCK), 0, c->stream, n, d_values, f->flags, f->ids, c->d_partials);
+    double r = 0;
+    VGL_TRY(vgl_reduce_common(c, nb, &r));
+    *result = (int64_t)r;     // exact: every partial is an integer below 2^53
+    return 0;
+}
+int vgl_hip_reduce_sum_f32(vgl_hip_ctx *c, vgl_hip_frontier *f, const float *d_values, double *result)
+{
+    if (!c || !f || !d_values || !result) VGL_FAIL("reduce: null argument");
+    const int32_t n = (f->sparsity == VGL_HIP_FRONTIER_SPARSE) ? f->size : f->g->V;
+    if (n == 0) { *result = 0; return 0; }
+    const int nb = (int)std::min<int64_t>(1024, vgl_ceil_div(n, VGL_BLOCK));
+    VGL_TRY(vgl_ensure_partials(c, (size_t)nb + 1));
+    if (f->sparsity == VGL_HIP_FRONTIER_ALL_ACTIVE)
+        hipLaunchKernelGGL((vgl_k_reduce_partial<float, double, 0>), dim3(nb), dim3(VGL_BLOCK), 0, c->stream, n, d_values, f->flags, f->ids, c->d_partials);
+    else if (f->sparsity == VGL_HIP_FRONTIER_DENSE)
+        hipLaunchKernelGGL((vgl_k_reduce_partial<float, double, 1>), dim3(nb), dim3(VGL_BLOCK), 0, c->stream, n, d_values, f->flags, f->ids, c->d_partials);
+    else
+        hipLaunchKernelGGL((vgl_k_reduce_partial<float, double, 2>), dim3(nb), dim3(VGL_BLOCK), 0, c->stream, n, d_values, f->flags, f->ids, c->d_partials);
+    return vgl_reduce_common(c, nb, result);
+}
+int vgl_hip_count_not_equal_u32(vgl_hip_ctx *c, int32_t n, const void *d_a, const void *d_b, int64_t *result)
+{
+    if (!c || !d_a || !d_b || !result) VGL_FAIL("count_not_equal: null argument");
+    if (n <= 0) { *result = 0; return 0; }
+    const int nb = (int)std::min<int64_t>(1024, vgl_ceil_div(n, VGL_BLOCK));
+    VGL_TRY(vgl_ensure_partials(c, (size_t)nb + 1));
+    hipLaunchKernelGGL(vgl_k_neq_partial, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, n, (const uint32_t *)d_a, (const uint32_t *)d_b, c->d_partials);
+    double r = 0;
+    VGL_TRY(vgl_reduce_common(c, nb, &r));
+    *result = (int64_t)r;
+    return 0;
+}
+
+}  // extern "C"

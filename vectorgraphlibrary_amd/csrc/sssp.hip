@@ -1,0 +1,167 @@
+// sssp.hip -- Bellman-Ford push relaxation (SSSP::vgl_dijkstra_all_active_push, algorithms/sssp/shortest_paths.hpp:85-163)
+// as an edge-balanced HIP kernel.
+//
+// One launch = one super-step over the owned out-edges.  Workgroup = one static tile of 2048 consecutive CSR edges
+// (thread = 8 consecutive edges: two 16-byte loads of adjacency and of weights, fully coalesced), rows recovered with
+// the LDS marker + max-scan map.  Per edge: dist[src] (re-read only when the row changes), gather dist[dst] (4 B random,
+// served by L2 / Infinity Cache for a 64 MiB array), f32 add + compare, integer atomic-min on the f32 bits when it
+// improves (all distances are non-negative, so the int order equals the float order).  The fixed point
+// d[v] = min_u (d[u] (+) w(u,v)) is unique, so any relaxation order gives bit-identical distances.
+//
+// VGL_HIP_SSSP_ACTIVE_TILES additionally keeps epoch[v] = last super-step in which d[v] decreased and skips a whole
+// tile (no adjacency / weight traffic) when none of its rows changed in the current or previous super-step.
+// Algorithmic bytes per streamed edge: 4 (adj) + 4 (weight) + 4 (dist[dst]) = 12; per vertex and super-step 28.
+#include "vgl_hip_internal.h"
+#include <cfloat>
+
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_init(int32_t V, int32_t source, float *dist, int32_t *epoch)
+{
+    for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK) {
+        dist[v] = (v == source) ? 0.0f : FLT_MAX;     // inf_val = FLT_MAX - MAX_WEIGHT == FLT_MAX in f32 (shortest_paths.hpp:102)
+        if (epoch) epoch[v] = (v == source) ? 0 : -4;
+    }
+}
+
+template <bool ACTIVE_FILTER>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax(const int64_t *rowptr, const int32_t *adj, const float *w,
+                                                              const int32_t *tile_row, int64_t E, int32_t row_base,
+                                                              float *dist, int32_t *epoch, int32_t iter, int64_t *counters)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, E - e0);
+    const int r_first = tile_row[blockIdx.x];
+    const int r_last = tile_row[blockIdx.x + 1];
+    if (ACTIVE_FILTER) {
+        int any = 0;
+        for (int r = r_first + threadIdx.x; r <= r_last; r += VGL_BLOCK) any |= (epoch[row_base + r] >= iter - 1);
+        if (!__syncthreads_or(any)) return;              // nothing in this tile can relax: skip its 16 KB of edge data
+    }
+    vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
+
+    const int i0 = threadIdx.x * VGL_EPT;
+    int changed = 0;
+    if (i0 < n) {
+        int32_t dsts[VGL_EPT];
+        float ws[VGL_EPT];
+        if (i0 + VGL_EPT <= n) {
+            const int4 a0 = *reinterpret_cast<const int4 *>(adj + e0 + i0);
+            const int4 a1 = *reinterpret_cast<const int4 *>(adj + e0 + i0 + 4);
+            const float4 w0 = *reinterpret_cast<const float4 *>(w + e0 + i0);
+            const float4 w1 = *reinterpret_cast<const float4 *>(w + e0 + i0 + 4);
+            dsts[0] = a0.x; dsts[1] = a0.y; dsts[2] = a0.z; dsts[3] = a0.w; dsts[4] = a1.x; dsts[5] = a1.y; dsts[6] = a1.z; dsts[7] = a1.w;
+            ws[0] = w0.x; ws[1] = w0.y; ws[2] = w0.z; ws[3] = w0.w; ws[4] = w1.x; ws[5] = w1.y; ws[6] = w1.z; ws[7] = w1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) {
+                const bool ok = i0 + j < n;
+                dsts[j] = ok ? adj[e0 + i0 + j] : 0;
+                ws[j] = ok ? w[e0 + i0 + j] : 0.0f;
+            }
+        }
+        int rows[VGL_EPT];
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) rows[j] = s_map[i0 + j];
+        // gather phase: issue all dist[dst] loads before any dependent work
+        float olds[VGL_EPT];
+        float dsrc[VGL_EPT];
+        int prev_row = -1;
+        float d = 0.0f;
+        bool live = false;
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            if (rows[j] != prev_row) {
+                prev_row = rows[j];
+                const int32_t u = row_base + r_first + rows[j];
+                d = dist[u];
+                live = d < FLT_MAX;
+                if (ACTIVE_FILTER) live = live && (epoch[u] >= iter - 1);
+            }
+            const bool ok = live && (i0 + j < n);
+            dsrc[j] = ok ? d : FLT_MAX;
+            olds[j] = ok ? dist[dsts[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            if (dsrc[j] < FLT_MAX) {
+                const float nd = __fadd_rn(dsrc[j], ws[j]);          // src_weight + weight (shortest_paths.hpp:126-130)
+                if (olds[j] > nd) {
+                    const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nd));
+                    if (before > __float_as_int(nd)) {
+                        changed = 1;
+                        if (ACTIVE_FILTER) epoch[dsts[j]] = iter;
+                    }
+                }
+            }
+        }
+    }
+    const int any_changed = __syncthreads_or(changed);
+    if (threadIdx.x == 0) {
+        if (any_changed) counters[C_CHANGED] = 1;
+        atomicAdd((unsigned long long *)&counters[C_EDGES], (unsigned long long)n);
+    }
+}
+
+static inline unsigned vgl_grid1(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, vgl_ceil_div(n, VGL_BLOCK))); }
+
+static int vgl_sssp_launch(vgl_hip_ctx *c, vgl_hip_graph *g, const float *w, float *dist, bool filter, int32_t iter)
+{
+    if (g->out.ntiles == 0) return 0;
+    vgl_timed_launch tl(c, "sssp_relax");
+    if (filter)
+        hipLaunchKernelGGL(vgl_k_sssp_relax<true>, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
+                           g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters);
+    else
+        hipLaunchKernelGGL(vgl_k_sssp_relax<false>, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
+                           g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int vgl_hip_sssp_init(vgl_hip_ctx *c, int32_t V, int32_t source, float *d_dist)
+{
+    if (!c || !d_dist) VGL_FAIL("sssp_init: null argument");
+    if (source < 0 || source >= V) VGL_FAIL("sssp_init: source vertex out of range");
+    hipLaunchKernelGGL(vgl_k_sssp_init, dim3(vgl_grid1(V)), dim3(VGL_BLOCK), 0, c->stream, V, source, d_dist, (int32_t *)nullptr);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int vgl_hip_sssp_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode, float *d_dist,
+                     vgl_hip_sssp_stats *stats)
+{
+    if (!c || !g || !d_weights || !d_dist) VGL_FAIL("sssp_run: null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("sssp_run: graph handle must own all rows (use vgl_hip_sssp_relax_owned for shards)");
+    if (source < 0 || source >= g->V) VGL_FAIL("sssp_run: source vertex out of range");
+    if (mode != VGL_HIP_SSSP_ALL_ACTIVE && mode != VGL_HIP_SSSP_ACTIVE_TILES) VGL_FAIL("sssp_run: unknown mode");
+    const bool filter = mode == VGL_HIP_SSSP_ACTIVE_TILES;
+    hipLaunchKernelGGL(vgl_k_sssp_init, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, g->epoch);
+    VGL_TRY(vgl_zero_counters(c, C_EDGES, 1));
+    vgl_hip_sssp_stats st = {0, 0, 0};
+    for (int32_t iter = 1;; iter++) {
+        VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
+        VGL_TRY(vgl_sssp_launch(c, g, d_weights, d_dist, filter, iter));
+        VGL_TRY(vgl_read_counters(c));
+        st.iterations = iter;
+        if (!c->h_counters[C_CHANGED]) break;      // do { ... } while(changes)  (shortest_paths.hpp:112-154)
+    }
+    st.edges_relaxed = c->h_counters[C_EDGES];
+    st.algorithmic_bytes = 12 * st.edges_relaxed + 28 * (int64_t)g->V * st.iterations;
+    if (stats) *stats = st;
+    return 0;
+}
+
+int vgl_hip_sssp_relax_owned(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, float *d_dist, int *changed)
+{
+    if (!c || !g || !d_weights || !d_dist) VGL_FAIL("sssp_relax_owned: null argument");
+    VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
+    VGL_TRY(vgl_sssp_launch(c, g, d_weights, d_dist, false, 1));
+    VGL_TRY(vgl_read_counters(c));
+    if (changed) *changed = (int)c->h_counters[C_CHANGED];
+    return 0;
+}
+
+}  // extern "C"

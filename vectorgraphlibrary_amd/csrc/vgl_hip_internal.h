@@ -1,0 +1,210 @@
+// vgl_hip_internal.h -- shared host/device internals of libvgl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <map>
+#include <vector>
+#include "../../include/vgl_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// geometry: 256-thread workgroups (4 wavefronts of 64), edge tiles of 2048 entries (8 per thread)
+// ---------------------------------------------------------------------------------------------
+constexpr int VGL_BLOCK = 256;
+constexpr int VGL_EPT = 8;
+constexpr int VGL_TILE = VGL_BLOCK * VGL_EPT;      // 2048 edges (or vertices) per workgroup tile
+constexpr int VGL_WAVES = VGL_BLOCK / 64;
+
+int vgl_set_error(const char *file, int line, const char *msg);
+#define VGL_FAIL(msg) return vgl_set_error(__FILE__, __LINE__, (msg))
+#define VGL_HIP_TRY(expr)                                                          \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) return vgl_set_error(__FILE__, __LINE__, hipGetErrorString(_e)); \
+    } while (0)
+#define VGL_TRY(expr)            \
+    do {                         \
+        int _s = (expr);         \
+        if (_s != 0) return _s;  \
+    } while (0)
+
+// device counters (int64 slots in ctx->d_counters, mirrored into pinned host memory on demand)
+enum {
+    C_FRONT = 0, C_NEIGH = 1, C_BU_FOUND = 2, C_BU_EDGES = 3, C_HEAVY = 4, C_CHANGED = 5,
+    C_EDGES = 6, C_TMP0 = 7, C_TMP1 = 8, C_JUMP = 9, C_NSLOTS = 32
+};
+
+struct vgl_timing_slot {
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+};
+
+struct vgl_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t *d_counters = nullptr;   // C_NSLOTS
+    int64_t *h_counters = nullptr;   // pinned mirror
+    double *d_partials = nullptr;    // reduction partials (f64), capacity partials_cap
+    size_t partials_cap = 0;
+    bool timing = false;
+    std::map<std::string, vgl_timing_slot> slots;
+    std::vector<hipEvent_t> event_pool;
+};
+
+struct vgl_dir_csr {                 // one direction of the graph (borrowed) + derived tile table (owned)
+    const int64_t *rowptr = nullptr; // nrows+1, rebased to 0
+    const int32_t *adj = nullptr;    // global vertex ids
+    int64_t edges = 0;
+    int32_t *tile_row = nullptr;     // ntiles+1: local row that contains edge t*VGL_TILE
+    int64_t ntiles = 0;
+};
+
+struct vgl_hip_graph {
+    int32_t V = 0, row_begin = 0, row_end = 0, nrows = 0;
+    vgl_dir_csr out, in;
+    // scratch shared by the fused algorithms (allocated at creation, sized by V / nrows / edges)
+    uint64_t *bm_visited = nullptr, *bm_front = nullptr, *bm_next = nullptr; // ceil(V/64)+1 words each
+    int32_t *ids = nullptr;          // nrows
+    int64_t *offs = nullptr;         // nrows+1
+    int32_t *vt_cnt = nullptr, *vt_cnt_off = nullptr;   // per vertex tile
+    int64_t *vt_deg = nullptr, *vt_deg_off = nullptr;
+    int64_t nvtiles = 0;
+    int32_t *tile_first = nullptr;   // out.ntiles + 2
+    int32_t *heavy = nullptr;        // nrows
+    int32_t *epoch = nullptr;        // V (SSSP active filter)
+    float *fscratch = nullptr;       // V (PR contrib)
+    float *fscratch2 = nullptr;      // V (PR rdeg)
+    float *fscratch3 = nullptr;      // V (PR new ranks)
+    int32_t *iscratch = nullptr;     // V (PR indeg when not supplied)
+};
+
+struct vgl_hip_frontier {
+    vgl_hip_graph *g = nullptr;
+    int32_t *flags = nullptr;        // V
+    int32_t *ids = nullptr;          // V
+    int32_t size = 0;
+    int64_t neighbours = 0;
+    int sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE;
+};
+
+// timing helpers (no-ops unless ctx->timing)
+struct vgl_timed_launch {
+    vgl_hip_ctx *ctx; vgl_timing_slot *slot; hipEvent_t a, b;
+    vgl_timed_launch(vgl_hip_ctx *c, const char *name);
+    ~vgl_timed_launch();
+};
+
+int vgl_read_counters(vgl_hip_ctx *ctx);   // D2H all slots into h_counters, synchronises
+int vgl_zero_counters(vgl_hip_ctx *ctx, int first, int count);
+int vgl_ensure_partials(vgl_hip_ctx *ctx, size_t n);
+
+static inline int64_t vgl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// device helpers (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int vgl_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ int vgl_wave() { return threadIdx.x >> 6; }
+
+template <class T>
+__device__ __forceinline__ T vgl_wave_incl_add(T v)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T n = __shfl_up(v, o);
+        if (vgl_lane() >= o) v += n;
+    }
+    return v;
+}
+__device__ __forceinline__ int vgl_wave_incl_max(int v)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(v, o);
+        if (vgl_lane() >= o) v = max(v, n);
+    }
+    return v;
+}
+template <class T>
+__device__ __forceinline__ T vgl_wave_reduce_add(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exclusive block scan (add); smem must hold VGL_WAVES elements of T; returns exclusive prefix, *total = block sum
+template <class T>
+__device__ __forceinline__ T vgl_block_excl_add(T v, T *smem, T *total)
+{
+    T inc = vgl_wave_incl_add(v);
+    __syncthreads();                       // protect smem reuse across calls
+    if (vgl_lane() == 63) smem[vgl_wave()] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < VGL_WAVES; w++) {
+        T s = smem[w];
+        if (w < vgl_wave()) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+// exclusive block scan (max) for non-negative ints, identity 0
+__device__ __forceinline__ int vgl_block_excl_max(int v, int *smem)
+{
+    int inc = vgl_wave_incl_max(v);
+    __syncthreads();
+    if (vgl_lane() == 63) smem[vgl_wave()] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < VGL_WAVES; w++)
+        if (w < vgl_wave()) base = max(base, smem[w]);
+    int up = __shfl_up(inc, 1);
+    if (vgl_lane() == 0) up = 0;
+    return max(base, up);
+}
+template <class T>
+__device__ __forceinline__ T vgl_block_reduce_add(T v, T *smem)
+{
+    v = vgl_wave_reduce_add(v);
+    __syncthreads();
+    if (vgl_lane() == 0) smem[vgl_wave()] = v;
+    __syncthreads();
+    T tot = 0;
+#pragma unroll
+    for (int w = 0; w < VGL_WAVES; w++) tot += smem[w];
+    return tot;
+}
+
+// Row map of an edge tile.  Positions [0, n) of the tile belong to consecutive "rows" (CSR rows or frontier
+// positions) r_first..r_last whose start offsets are starts[r] (int64, monotone).  On return s_map[i] holds
+// (row of slot i) - r_first.  Empty rows are skipped naturally (the last row starting at a slot owns it).
+// s_map: VGL_TILE ints of LDS; s_w: VGL_WAVES ints.  All threads of the workgroup must call.
+__device__ __forceinline__ void vgl_tile_row_map(int *s_map, int *s_w, const int64_t *starts, int64_t e0,
+                                                 int r_first, int r_last)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) s_map[tid + j * VGL_BLOCK] = 0;
+    __syncthreads();
+    for (int r = r_first + 1 + tid; r <= r_last; r += VGL_BLOCK) {
+        const int64_t q = starts[r] - e0;          // > 0 because r_first contains e0
+        if (q < VGL_TILE) atomicMax(&s_map[(int)q], r - r_first);
+    }
+    __syncthreads();
+    int m[VGL_EPT];
+    int run = 0;
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) { run = max(run, s_map[tid * VGL_EPT + j]); m[j] = run; }
+    const int pre = vgl_block_excl_max(run, s_w);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) s_map[tid * VGL_EPT + j] = max(m[j], pre);
+    __syncthreads();
+}
+#endif  // __HIPCC__

@@ -1,0 +1,186 @@
+"""Edge-cut multi-GPU super-step drivers: one process per GPU, vertex arrays replicated, every rank owns the
+out-edges (and in-edges) of a contiguous vertex range with ~E/P edges (VectorCSRGraph::get_mpi_thresholds,
+vect_csr/get_api.hpp:66-94), one exchange per super-step (common/mpi_exchange.hpp:110-150,222-271 in the reference,
+an RCCL collective over xGMI here; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
+
+The per-shard compute is delegated to an `ops` object.  `HipShardOps` (the product) calls libvgl_hip.so;
+tests/ inject a numpy double to exercise the exchange protocol with gloo on CPU (no GPU code runs there).
+
+Exchange payloads:
+  BFS  : bitmap of the vertices discovered in this super-step (V/8 bytes per rank, all-gather + OR) instead of the
+         reference's whole-array exchange
+  SSSP : allreduce(min) of the f32 distance array    (EXCHANGE_ALL with min_op, shortest_paths.hpp:136-141)
+  CC   : allreduce(min) of the int32 label array
+  PR   : owned slices of the new ranks               (EXCHANGE_PRIVATE_DATA, pr.hpp:127), as a sum with zeros elsewhere
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import lib as _l
+from .api import _ptr
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+class HipShardOps:
+    """per-shard super-step kernels through the C ABI (graph = api.Graph restricted to the owned rows)."""
+
+    def __init__(self, graph, weights=None):
+        self.g, self.ctx, self.L = graph, graph.ctx, graph.ctx.L
+        self.V = graph.V
+        self.device = graph.ctx.device
+        self.weights = weights
+
+    def new_i32(self):
+        return torch.empty(self.V, dtype=torch.int32, device=self.device)
+
+    def new_f32(self):
+        return torch.empty(self.V, dtype=torch.float32, device=self.device)
+
+    def new_words(self, parts):
+        return torch.empty(parts * ((self.V + 63) // 64), dtype=torch.int64, device=self.device)
+
+    def scalar(self, values):
+        return torch.tensor(values, dtype=torch.int64, device=self.device)
+
+    def bfs_init(self, levels, source):
+        _l.check(self.L.vgl_hip_bfs_init(self.ctx.h, self.V, int(source), _ptr(levels)))
+
+    def bfs_step(self, levels, level):
+        f, m = C.c_int64(), C.c_int64()
+        _l.check(self.L.vgl_hip_bfs_step_top_down(self.ctx.h, self.g.h, _ptr(levels), int(level), C.byref(f), C.byref(m)))
+        return f.value, m.value
+
+    def levels_to_bitmap(self, levels, level, bits):
+        _l.check(self.L.vgl_hip_levels_to_bitmap(self.ctx.h, self.V, _ptr(levels), int(level), _ptr(bits)))
+
+    def apply_bitmaps(self, parts, bits_all, levels, level):
+        n = C.c_int64()
+        _l.check(self.L.vgl_hip_bfs_apply_bitmaps(self.ctx.h, self.V, parts, _ptr(bits_all), _ptr(levels), int(level), C.byref(n)))
+        return n.value
+
+    def sssp_init(self, d, source):
+        _l.check(self.L.vgl_hip_sssp_init(self.ctx.h, self.V, int(source), _ptr(d)))
+
+    def sssp_relax(self, d):
+        ch = C.c_int()
+        _l.check(self.L.vgl_hip_sssp_relax_owned(self.ctx.h, self.g.h, _ptr(self.weights), _ptr(d), C.byref(ch)))
+        return ch.value
+
+    def cc_init(self, comp):
+        _l.check(self.L.vgl_hip_cc_init(self.ctx.h, self.V, _ptr(comp)))
+
+    def cc_hook(self, comp):
+        ch = C.c_int()
+        _l.check(self.L.vgl_hip_cc_hook_owned(self.ctx.h, self.g.h, _ptr(comp), C.byref(ch)))
+        return ch.value
+
+    def cc_jump(self, comp):
+        _l.check(self.L.vgl_hip_cc_jump(self.ctx.h, self.V, _ptr(comp)))
+
+    def indeg_add(self, indeg):
+        _l.check(self.L.vgl_hip_indegree_noloops_add(self.ctx.h, self.g.h, _ptr(indeg)))
+
+    def pr_setup(self, indeg, ranks, rdeg):
+        _l.check(self.L.vgl_hip_pr_setup(self.ctx.h, self.V, _ptr(indeg), _ptr(ranks), _ptr(rdeg)))
+
+    def pr_iteration(self, indeg, rdeg, ranks, contrib):
+        _l.check(self.L.vgl_hip_pr_iteration_owned(self.ctx.h, self.g.h, _ptr(indeg), _ptr(rdeg), _ptr(ranks), _ptr(contrib)))
+
+    def sync(self):
+        self.ctx.sync()
+
+
+def _allreduce(t, op, group):
+    if _world(group)[0] > 1:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def bfs_sharded(ops, source, group=None):
+    """top-down BFS over edge-cut shards; returns the replicated levels array and the number of levels."""
+    P, rank = _world(group)
+    levels = ops.new_i32()
+    ops.bfs_init(levels, source)
+    words = (ops.V + 63) // 64
+    mine = ops.new_words(1)
+    everyone = ops.new_words(P) if P > 1 else mine
+    level, nlevels = 1, 0
+    while True:
+        ops.bfs_step(levels, level)                       # owned frontier vertices expand; levels[dst] = level+1
+        nlevels += 1
+        ops.levels_to_bitmap(levels, level + 1, mine)     # what this rank discovered
+        if P > 1:
+            ops.sync()
+            dist.all_gather_into_tensor(everyone, mine, group=group)
+        newly = ops.apply_bitmaps(P, everyone, levels, level + 1)
+        if newly == 0:
+            break
+        level += 1
+    assert everyone.numel() == P * words
+    return levels, nlevels
+
+
+def sssp_sharded(ops, source, group=None):
+    P, _ = _world(group)
+    d = ops.new_f32()
+    ops.sssp_init(d, source)
+    iters = 0
+    while True:
+        changed = ops.sssp_relax(d)
+        iters += 1
+        if P > 1:
+            ops.sync()
+            dist.all_reduce(d, op=dist.ReduceOp.MIN, group=group)
+            flag = ops.scalar([changed])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            changed = int(flag.item())
+        if not changed:
+            break
+    return d, iters
+
+
+def cc_sharded(ops, group=None):
+    P, _ = _world(group)
+    comp = ops.new_i32()
+    ops.cc_init(comp)
+    passes = 0
+    while True:
+        changed = ops.cc_hook(comp)
+        passes += 1
+        if P > 1:
+            ops.sync()
+            dist.all_reduce(comp, op=dist.ReduceOp.MIN, group=group)
+            flag = ops.scalar([changed])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            changed = int(flag.item())
+        if not changed:
+            break
+        ops.cc_jump(comp)
+    return comp, passes
+
+
+def page_rank_sharded(ops, iterations, row_begin, row_end, group=None):
+    P, _ = _world(group)
+    indeg = ops.new_i32()
+    indeg.zero_()
+    ops.indeg_add(indeg)
+    if P > 1:
+        ops.sync()
+        dist.all_reduce(indeg, op=dist.ReduceOp.SUM, group=group)
+    ranks, rdeg, contrib = ops.new_f32(), ops.new_f32(), ops.new_f32()
+    ops.pr_setup(indeg, ranks, rdeg)
+    for _ in range(iterations):
+        ops.pr_iteration(indeg, rdeg, ranks, contrib)     # writes the owned rows of `ranks`
+        if P > 1:
+            ops.sync()
+            ranks[:row_begin] = 0
+            ranks[row_end:] = 0
+            dist.all_reduce(ranks, op=dist.ReduceOp.SUM, group=group)   # x + 0 + ... + 0 is exact
+    ops.sync()
+    return ranks
