@@ -33,7 +33,7 @@ typedef struct vgl_hip_frontier vgl_hip_frontier;
  *      and the throw "literal" convention, apps/bfs/bfs.cpp:53-61) ---- */
 int vgl_hip_abi_version(void);
 const char *vgl_hip_last_error(void);
-/* stream: a hipStream_t created by the caller (e.g. torch's current stream) or NULL for a private one */
+/* stream: a hipStream_t created by the caller (e.g. torch's current stream); NULL = the device's default stream */
 int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out);
 int vgl_hip_ctx_destroy(vgl_hip_ctx *ctx);
 int vgl_hip_ctx_sync(vgl_hip_ctx *ctx);

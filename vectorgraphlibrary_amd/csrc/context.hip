@@ -29,8 +29,9 @@ int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out)
     VGL_HIP_TRY(hipSetDevice(device));
     vgl_hip_ctx *c = new vgl_hip_ctx();
     c->device = device;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else { VGL_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    // NULL = the device's default (null) stream, which is also what torch uses unless told otherwise
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
     VGL_HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(int64_t) * C_NSLOTS));
     VGL_HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(int64_t) * C_NSLOTS, hipHostMallocDefault));
     VGL_HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(int64_t) * C_NSLOTS, c->stream));
