@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- TEPS of the VGL hot path on MI355X (BASELINE.json metric).
+
+One "step" = one BFS traversal of the synthetic graph from a fresh random non-isolated source
+(apps/bfs/bfs.cpp:36-40; TEPS = E_graph / time, performance_stats.hpp:272-275).
+N=1   : BASELINE configs[1] "BFS direction-optimising on RMAT scale-24, 1xMI355X" (graph resident in HBM).
+N>1   : the same graph, edge-cut into N shards (one process per GPU, bitmap exchange over RCCL) -> strong scaling.
+Prints ONE JSON line on rank 0 with the driver contract keys plus `roofline` (dominant kernel, algorithmic bytes per
+launch / HIP-event duration measured in the timed region) and `cpu_baseline` (the oracle's OpenMP port of the
+reference top-down BFS on the same graph, timed on the host cores; N=1 only).  Extra keys carry the SSSP numbers.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def pick_sources(rowptr_dev, n, seed):
+    """deterministic random non-isolated sources (VGL_Graph::select_random_nz_vertex)."""
+    import torch
+    deg = rowptr_dev[1:] - rowptr_dev[:-1]
+    nz = torch.nonzero(deg > 0).flatten()
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    pick = torch.randint(0, nz.numel(), (n,), generator=g)
+    return [int(nz[i]) for i in pick]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=int, default=24)
+    ap.add_argument("--edge-factor", type=int, default=32)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sssp", action="store_true")
+    ap.add_argument("--cpu-sources", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import distributed as vd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = api.Context(local_rank if world > 1 else 0)
+
+    scale, ef, seed = args.scale, args.edge_factor, args.seed
+    V, E = 1 << scale, (1 << scale) * ef
+    t_build = time.time()
+    src, dst = ctx.gen_rmat(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True, want_perm=not args.no_sssp)
+    del src, dst
+    ctx.sync()
+    t_build = time.time() - t_build
+    sources = pick_sources(g.out_rowptr, args.steps + args.warmup, seed)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    extra = {}
+    roofline = None
+    cpu_baseline = None
+    if world == 1:
+        for s in sources[:args.warmup]:
+            api.bfs(g, s, api.BFS_DIRECTION_OPT)
+        ctx.timing(True)
+        barrier()
+        t0 = time.perf_counter()
+        stats = []
+        for s in sources[args.warmup:]:
+            stats.append(api.bfs(g, s, api.BFS_DIRECTION_OPT)[1])
+        barrier()
+        dt = time.perf_counter() - t0
+        # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----
+        kern = {}
+        for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "gnf"):
+            n, ms = ctx.timing_get(name)
+            kern[name] = {"launches": n, "total_ms": round(ms, 4)}
+        ctx.timing(False)
+        bu_edges = sum(s["bu_edges"] for s in stats)
+        bu_found = sum(s["bu_found"] for s in stats)
+        bu_steps = sum(s["bu_steps"] for s in stats)
+        td_edges = sum(s["td_edges"] for s in stats)
+        td_front = sum(s["td_frontier"] for s in stats)
+        td_steps = sum(s["td_steps"] for s in stats)
+        levels = sum(s["levels"] for s in stats)
+        # algorithmic bytes per kernel: 8 B per examined adjacency entry (4 B id + 4 B status probe),
+        # 20 B per top-down frontier vertex (id + row offsets), 4 B per discovered vertex, V/8 per bottom-up bitmap scan,
+        # 4 B per vertex per GNF pass
+        bytes_k = {
+            "bfs_bottom_up": 8 * bu_edges + 4 * bu_found + bu_steps * (V // 8),
+            "bfs_top_down": 8 * td_edges + 20 * td_front,
+            "gnf": 4 * V * kern["gnf"]["launches"],
+        }
+        dom = max(("bfs_bottom_up", "bfs_top_down", "gnf"), key=lambda k: kern[k]["total_ms"])
+        if kern[dom]["launches"] > 0 and kern[dom]["total_ms"] > 0:
+            per_launch_bytes = bytes_k[dom] / kern[dom]["launches"]
+            per_launch_ms = kern[dom]["total_ms"] / kern[dom]["launches"]
+            achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(per_launch_ms, 5),
+                        "launches": kern[dom]["launches"]}
+        total_alg = sum(s["algorithmic_bytes"] for s in stats)
+        extra["bfs"] = {"kernels": kern, "levels_per_bfs": levels / len(stats), "td_steps": td_steps, "bu_steps": bu_steps,
+                        "edges_examined_per_bfs": (bu_edges + td_edges) / len(stats),
+                        "whole_bfs_algorithmic_GBps": round(total_alg / dt / 1e9, 2),
+                        "whole_bfs_frac_of_hbm_peak": round(total_alg / dt / 1e9 / HBM_PEAK_GBS, 5)}
+        # reference algorithm (pure top-down, bfs.hpp:6-51) for comparison
+        t1 = time.perf_counter()
+        td_stats = [api.bfs(g, s, api.BFS_TOP_DOWN)[1] for s in sources[args.warmup:args.warmup + 4]]
+        torch.cuda.synchronize()
+        dt_td = (time.perf_counter() - t1) / len(td_stats)
+        extra["bfs_top_down_reference_algorithm"] = {
+            "teps": round(E / dt_td, 1), "ms": round(dt_td * 1e3, 3),
+            "algorithmic_GBps": round(sum(s["algorithmic_bytes"] for s in td_stats) / len(td_stats) / dt_td / 1e9, 2)}
+
+        # ---- SSSP (BASELINE configs[2]) ----
+        if not args.no_sssp:
+            w = ctx.gather_u32(g.perm, ctx.gen_weights(E, seed))
+            res = {}
+            for mode, name in ((api.SSSP_ACTIVE_TILES, "active_tiles"), (api.SSSP_ALL_ACTIVE, "all_active")):
+                api.sssp(g, w, sources[0], mode)
+                ctx.timing(True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sst = [api.sssp(g, w, s, mode)[1] for s in sources[args.warmup:args.warmup + 3]]
+                torch.cuda.synchronize()
+                dts = (time.perf_counter() - t1) / len(sst)
+                n, ms = ctx.timing_get("sssp_relax")
+                ctx.timing(False)
+                edges = sum(s["edges_relaxed"] for s in sst)
+                res[name] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "iterations": sst[0]["iterations"],
+                             "edges_relaxed_per_run": edges // len(sst),
+                             "relax_kernel": {"launches": n, "total_ms": round(ms, 3),
+                                              "algorithmic_GBps": round(12 * edges / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
+                                              "frac_of_hbm_peak": round(12 * edges / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None}}
+            extra["sssp"] = res
+            del w
+
+        # ---- CPU baseline: the oracle's OpenMP port of the reference top-down BFS, same graph, host cores ----
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            rp = g.out_rowptr.cpu().numpy()
+            adj = g.out_adj.cpu().numpy()
+            O.bfs_top_down(rp, adj, sources[0], parallel=True)           # warm-up / page-in
+            tc = time.perf_counter()
+            n_cpu = 0
+            for s in sources[args.warmup:args.warmup + args.cpu_sources]:
+                O.bfs_top_down(rp, adj, s, parallel=True)
+                n_cpu += 1
+                if time.perf_counter() - tc > 30:
+                    break
+            dtc = time.perf_counter() - tc
+            cpu_baseline = {"value": round(n_cpu * E / dtc, 1), "unit": "edges/s", "cores": O.max_threads(), "kind": "port",
+                            "sample": f"{n_cpu} top-down BFS traversals (oracle/vgl_oracle.c, OpenMP) of the same RMAT-{scale} graph"}
+            del rp, adj
+        workload = f"BFS direction-optimising on RMAT scale-{scale} (edge factor {ef}), 1xMI355X"
+        scaling = "weak"
+    else:
+        # edge-cut shards of the SAME graph: strong scaling.  Top-down super-steps with bitmap all-gather.
+        bounds = ctx.partition_rows(g.out_rowptr, world)
+        shard = g.shard(bounds[rank], bounds[rank + 1])
+        ops = vd.HipShardOps(shard)
+        for s in sources[:args.warmup]:
+            vd.bfs_sharded(ops, s)
+        barrier()
+        t0 = time.perf_counter()
+        for s in sources[args.warmup:]:
+            vd.bfs_sharded(ops, s)
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        workload = f"BFS (top-down super-steps, bitmap exchange) on RMAT scale-{scale} (edge factor {ef}), edge-cut over {world} GPUs"
+        scaling = "strong"
+
+    if rank == 0:
+        out = {
+            "metric": "TEPS (edges/s) BFS on RMAT-%d" % scale, "value": round(args.steps * E / dt, 1), "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": workload, "vertices": V, "edges": E, "seed": seed, "parallelism": f"edge-cut x{world}",
+                       "graph_build_s": round(t_build, 2)},
+        }
+        if roofline:
+            out["roofline"] = roofline
+        if cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline
+        out.update(extra)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,8 @@ typedef struct {
     int64_t frontier_total;    /* sum of |F_l| */
     int64_t discovered;        /* vertices reached, incl. source */
     int64_t algorithmic_bytes; /* 8*m_ex + 20*n_front + 4*n_disc + 4*V (+ V/8 per bottom-up level) */
+    int64_t td_edges, td_frontier;   /* per-kernel shares for the roofline line: top-down launches */
+    int64_t bu_edges, bu_found;      /* bottom-up launches: adjacency entries probed, vertices discovered */
 } vgl_hip_bfs_stats;
 #define VGL_HIP_BFS_TOP_DOWN 0           /* BFS::fast_vgl_top_down, bfs.hpp:6-51 */
 #define VGL_HIP_BFS_DIRECTION_OPT 1      /* + bottom-up steps; switch rule change_state.hpp:100-141 (ALPHA 15, BETA 18) */

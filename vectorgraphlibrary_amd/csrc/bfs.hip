@@ -219,7 +219,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     const int64_t words = vgl_ceil_div(V, 64);
     VGL_TRY(vgl_hip_bfs_init(c, V, source, d_levels));
 
-    vgl_hip_bfs_stats st = {0, 0, 0, 0, 0, 0, 0};
+    vgl_hip_bfs_stats st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int32_t cur = 1;
     bool bottom_up = false;          // state used to PROCESS level `cur`
     bool have_bitmaps = false;       // bm_front / bm_visited describe level `cur`
@@ -262,7 +262,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                                    g->nrows, g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
             }
             VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1));
-            st.td_steps++; st.edges_examined += M;
+            st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
         } else {
             if (!have_bitmaps) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
             VGL_TRY(vgl_zero_counters(c, C_BU_FOUND, 3));        // C_BU_FOUND, C_BU_EDGES, C_HEAVY
@@ -282,6 +282,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             VGL_HIP_TRY(hipGetLastError());
             VGL_TRY(vgl_read_counters(c));
             st.bu_steps++; st.edges_examined += c->h_counters[C_BU_EDGES];
+            st.bu_edges += c->h_counters[C_BU_EDGES]; st.bu_found += c->h_counters[C_BU_FOUND];
             F = c->h_counters[C_BU_FOUND]; M = 0;      // next frontier; bitmaps now describe level cur+1
             have_bitmaps = true;
         }

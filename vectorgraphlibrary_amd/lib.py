@@ -18,7 +18,8 @@ class VglHipError(RuntimeError):
 class BfsStats(C.Structure):
     _fields_ = [("levels", C.c_int32), ("td_steps", C.c_int32), ("bu_steps", C.c_int32),
                 ("edges_examined", C.c_int64), ("frontier_total", C.c_int64), ("discovered", C.c_int64),
-                ("algorithmic_bytes", C.c_int64)]
+                ("algorithmic_bytes", C.c_int64), ("td_edges", C.c_int64), ("td_frontier", C.c_int64),
+                ("bu_edges", C.c_int64), ("bu_found", C.c_int64)]
 
 
 class SsspStats(C.Structure):
