@@ -41,90 +41,129 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
                                                              int32_t next_level)
 {
     __shared__ int s_map[VGL_TILE];
+    __shared__ int64_t s_base[VGL_TILE];
     __shared__ int s_w[VGL_WAVES];
     const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
     const int n = (int)min((int64_t)VGL_TILE, M - e0);
     const int p_first = tile_first[blockIdx.x];
     const int p_last = (e0 + VGL_TILE < M) ? tile_first[blockIdx.x + 1] : F - 1;
-    vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);
+    // per frontier position of this tile: (first adjacency index of the vertex) - (its edge offset in the frontier), staged
+    // in LDS so that the per-edge path is LDS lookups + one adjacency load (falls back to global reads when a tile spans
+    // more than 2048 frontier positions, i.e. thousands of zero-degree frontier vertices)
+    const int np = p_last - p_first + 1;
+    const bool staged = np <= VGL_TILE;
+    if (staged)
+        for (int k = threadIdx.x; k < np; k += VGL_BLOCK) {
+            const int p = p_first + k;
+            s_base[k] = rowptr[ids[p] - row_base] - offs[p];
+        }
+    vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);      // ends with a barrier: s_base is visible too
+    int32_t dsts[VGL_EPT];
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) {
         const int i = threadIdx.x + j * VGL_BLOCK;          // strided slots => coalesced adjacency reads
+        dsts[j] = -1;
         if (i < n) {
-            const int p = p_first + s_map[i];
-            const int32_t v = ids[p];
-            const int64_t e = rowptr[v - row_base] + (e0 + i - offs[p]);
-            const int32_t dst = adj[e];
-            if (!((visited[dst >> 6] >> (dst & 63)) & 1ULL)) {
-                if (levels[dst] == -1) levels[dst] = next_level;
-            }
+            const int k = s_map[i];
+            const int64_t base = staged ? s_base[k] : (rowptr[ids[p_first + k] - row_base] - offs[p_first + k]);
+            dsts[j] = adj[base + e0 + i];
         }
     }
+    bool unvis[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++)
+        unvis[j] = dsts[j] >= 0 && !((visited[dsts[j] >> 6] >> (dsts[j] & 63)) & 1ULL);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++)
+        if (unvis[j] && levels[dsts[j]] == -1) levels[dsts[j]] = next_level;
 }
 
-// bottom-up, pass 1: one thread per owned vertex; unvisited vertices probe their first incoming neighbours against
-// the frontier bitmap.  Writes whole words of the next-frontier bitmap (wave = 64 consecutive vertices).
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, const int64_t *in_rowptr,
-                                                            const int32_t *in_adj, const uint64_t *visited,
+// Bottom-up step.  No global atomics: a single same-address device atomic costs ~12 ns and serialises (65 536 blocks
+// adding to one counter took 1.5 ms per launch in the first version); instead a fixed grid of VGL_BU_BLOCKS persistent
+// workgroups each owns a contiguous vertex range, a private segment of the deferred-vertex list and a private slot of
+// partial counters, which vgl_k_bu_fold sums in a fixed order afterwards.
+constexpr int VGL_BU_BLOCKS = 2048;
+
+// pass 1: one thread per owned vertex.  A vertex is a candidate when it is unvisited AND has incoming edges (in_nz
+// bitmap, built once per graph: ~45 % of RMAT vertices have none and would otherwise re-read 16 B of row offsets in every
+// bottom-up level).  The first VGL_BU_PROBES incoming neighbours are loaded together and their frontier bits tested
+// together (two dependent memory round trips per vertex).  Writes whole words of the next-frontier bitmap.
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
+                                                            const int32_t *in_adj, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
-                                                            int32_t next_level, int32_t *heavy, int64_t *counters)
+                                                            int32_t next_level, int32_t *heavy, int32_t *heavy_cnt, int64_t *partials)
 {
     __shared__ int64_t s64[VGL_WAVES];
+    __shared__ int s_nheavy;
+    if (threadIdx.x == 0) s_nheavy = 0;
+    __syncthreads();
     int64_t found_cnt = 0, probes = 0;
-    const int32_t nround = (nrows + 63) & ~63;
-    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nround; r += gridDim.x * VGL_BLOCK) {
+    const int32_t r_begin = blockIdx.x * chunk;                      // chunk is a multiple of VGL_BLOCK
+    const int32_t r_end = min(r_begin + chunk, (nrows + 63) & ~63);
+    int32_t *my_heavy = heavy + r_begin;                             // at most `chunk` deferrals per workgroup
+    for (int32_t r = r_begin + threadIdx.x; r < r_end; r += VGL_BLOCK) {
         const int32_t v = row_base + r;
+        const uint64_t cand_word = ~visited[v >> 6] & in_nz[v >> 6];       // wave-uniform
         bool found = false, defer = false;
-        if (r < nrows && !((visited[v >> 6] >> (v & 63)) & 1ULL)) {
-            const int64_t b = in_rowptr[r], e = in_rowptr[r + 1];
-            const int n = (int)min((int64_t)VGL_BU_PROBES, e - b);
-            int i = 0;
-            for (; i < n; i++) {
-                const int32_t u = in_adj[b + i];
-                if ((front[u >> 6] >> (u & 63)) & 1ULL) { found = true; i++; break; }
+        if (cand_word != 0ULL) {
+            if (r < nrows && ((cand_word >> (v & 63)) & 1ULL)) {
+                const int64_t b = in_rowptr[r], e = in_rowptr[r + 1];
+                const int n = (int)min((int64_t)VGL_BU_PROBES, e - b);
+                int32_t u[VGL_BU_PROBES];
+#pragma unroll
+                for (int j = 0; j < VGL_BU_PROBES; j++) u[j] = (j < n) ? in_adj[b + j] : -1;
+                uint32_t hit = 0;
+#pragma unroll
+                for (int j = 0; j < VGL_BU_PROBES; j++)
+                    if (u[j] >= 0) hit |= (uint32_t)((front[u[j] >> 6] >> (u[j] & 63)) & 1ULL) << j;
+                found = hit != 0;
+                probes += found ? __ffs(hit) : n;        // adjacency entries a sequential scan would have examined
+                defer = !found && (e - b) > VGL_BU_PROBES;
+                if (found) levels[v] = next_level;
             }
-            probes += i;
-            defer = !found && (e - b) > VGL_BU_PROBES;
-            if (found) levels[v] = next_level;
         }
         const unsigned long long fm = __ballot(found);
         if (vgl_lane() == 0) next[v >> 6] = fm;
         found_cnt += found;
         const unsigned long long dm = __ballot(defer);
-        if (dm) {                                   // wave-aggregated append to the heavy list
+        if (dm) {                                   // wave-aggregated append to this workgroup's segment (LDS counter)
             int base = 0;
-            if (vgl_lane() == 0) base = (int)atomicAdd((unsigned long long *)&counters[C_HEAVY], (unsigned long long)__popcll(dm));
+            if (vgl_lane() == 0) base = atomicAdd(&s_nheavy, (int)__popcll(dm));
             base = __shfl(base, 0);
-            if (defer) heavy[base + __popcll(dm & ((1ULL << vgl_lane()) - 1ULL))] = r;
+            if (defer) my_heavy[base + __popcll(dm & ((1ULL << vgl_lane()) - 1ULL))] = r;
         }
     }
     found_cnt = vgl_block_reduce_add(found_cnt, s64);
     probes = vgl_block_reduce_add(probes, s64);
     if (threadIdx.x == 0) {
-        if (found_cnt) atomicAdd((unsigned long long *)&counters[C_BU_FOUND], (unsigned long long)found_cnt);
-        if (probes) atomicAdd((unsigned long long *)&counters[C_BU_EDGES], (unsigned long long)probes);
+        partials[blockIdx.x * 4 + 0] = found_cnt;
+        partials[blockIdx.x * 4 + 1] = probes;
+        heavy_cnt[blockIdx.x] = s_nheavy;
     }
 }
 
-// bottom-up, pass 2: one wavefront per deferred vertex, 64 incoming neighbours per step, early exit on the first hit
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, const int64_t *in_rowptr, const int32_t *in_adj,
-                                                            const uint64_t *front, uint64_t *next, int32_t *levels,
-                                                            int32_t next_level, const int32_t *heavy, int64_t *counters)
+// pass 2: the deferred vertices of segment blockIdx.x, one wavefront per vertex, 64 incoming neighbours per step, early
+// exit on the first hit.  next-frontier bits are OR-ed in (different vertices of one word may be found by different waves).
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
+                                                            const int32_t *in_adj, const uint64_t *front, uint64_t *next,
+                                                            int32_t *levels, int32_t next_level, const int32_t *heavy,
+                                                            const int32_t *heavy_cnt, int64_t *partials)
 {
-    const int64_t nheavy = counters[C_HEAVY];
-    const int wave_global = blockIdx.x * VGL_WAVES + vgl_wave();
-    const int nwaves = gridDim.x * VGL_WAVES;
+    __shared__ int64_t s64[VGL_WAVES];
+    const int32_t nheavy = heavy_cnt[blockIdx.x];
+    const int32_t *my_heavy = heavy + (int64_t)blockIdx.x * chunk;
     int64_t found_cnt = 0, probes = 0;
-    for (int64_t h = wave_global; h < nheavy; h += nwaves) {
-        const int32_t r = heavy[h];
+    for (int32_t h = vgl_wave(); h < nheavy; h += VGL_WAVES) {
+        const int32_t r = my_heavy[h];
         const int64_t b = in_rowptr[r] + VGL_BU_PROBES, e = in_rowptr[r + 1];
         bool hit_any = false;
         for (int64_t p = b; p < e && !hit_any; p += 64) {
             const int64_t q = p + vgl_lane();
             bool hit = false;
             if (q < e) { const int32_t u = in_adj[q]; hit = (front[u >> 6] >> (u & 63)) & 1ULL; }
-            hit_any = __ballot(hit) != 0ULL;
-            probes += min((int64_t)64, e - p);
+            const unsigned long long hm = __ballot(hit);
+            hit_any = hm != 0ULL;
+            if (vgl_lane() == 0) probes += hit_any ? (int64_t)(__ffsll((long long)hm)) : min((int64_t)64, e - p);
         }
         if (hit_any && vgl_lane() == 0) {
             const int32_t v = row_base + r;
@@ -133,10 +172,26 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, co
             found_cnt++;
         }
     }
-    if (vgl_lane() == 0) {
-        if (found_cnt) atomicAdd((unsigned long long *)&counters[C_BU_FOUND], (unsigned long long)found_cnt);
-        if (probes) atomicAdd((unsigned long long *)&counters[C_BU_EDGES], (unsigned long long)probes);
+    found_cnt = vgl_block_reduce_add(found_cnt, s64);
+    probes = vgl_block_reduce_add(probes, s64);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 4 + 2] = found_cnt;
+        partials[blockIdx.x * 4 + 3] = probes;
     }
+}
+
+// counters[C_BU_FOUND] / counters[C_BU_EDGES] = sums of the per-workgroup partials, in a fixed order
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_fold(const int64_t *partials, int64_t *counters)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    int64_t f = 0, p = 0;
+    for (int b = threadIdx.x; b < VGL_BU_BLOCKS; b += VGL_BLOCK) {
+        f += partials[b * 4 + 0] + partials[b * 4 + 2];
+        p += partials[b * 4 + 1] + partials[b * 4 + 3];
+    }
+    f = vgl_block_reduce_add(f, s64);
+    p = vgl_block_reduce_add(p, s64);
+    if (threadIdx.x == 0) { counters[C_BU_FOUND] = f; counters[C_BU_EDGES] = p; }
 }
 
 // visited |= next; front = next   (one word per thread)
@@ -229,7 +284,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         if (!bottom_up) {
             // frontier of level cur from the levels array: counts + bitmaps, then ids + edge offsets
             vgl_pred_equal_i32 pred{d_levels, cur};
-            VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, d_levels,
+            VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited,
                                 nullptr, false, true));
             F = c->h_counters[C_FRONT]; M = c->h_counters[C_NEIGH];
             have_bitmaps = true;
@@ -246,7 +301,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                     bottom_up = false;
                     // need ids/offs of level cur: regenerate from levels
                     vgl_pred_equal_i32 pred{d_levels, cur};
-                    VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, d_levels,
+                    VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited,
                                         nullptr, false, true));
                     F = c->h_counters[C_FRONT]; M = c->h_counters[C_NEIGH];
                     have_bitmaps = true;
@@ -265,22 +320,23 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
         } else {
             if (!have_bitmaps) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
-            VGL_TRY(vgl_zero_counters(c, C_BU_FOUND, 3));        // C_BU_FOUND, C_BU_EDGES, C_HEAVY
+            const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
             {
                 vgl_timed_launch tl(c, "bfs_bottom_up");
-                hipLaunchKernelGGL(vgl_k_bu_probe, dim3(vgl_grid(g->nrows, 1 << 20)), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin,
-                                   g->in.rowptr, g->in.adj, g->bm_visited, g->bm_front, g->bm_next, d_levels, cur + 1, g->heavy,
-                                   c->d_counters);
+                hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
+                                   g->in.rowptr, g->in.adj, g->bm_visited, g->bm_in_nz, g->bm_front, g->bm_next, d_levels, cur + 1,
+                                   g->heavy, g->heavy_cnt, g->bu_partials);
             }
             {
                 vgl_timed_launch tl(c, "bfs_bottom_up_heavy");
-                hipLaunchKernelGGL(vgl_k_bu_heavy, dim3(2048), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, g->in.rowptr, g->in.adj,
-                                   g->bm_front, g->bm_next, d_levels, cur + 1, g->heavy, c->d_counters);
+                hipLaunchKernelGGL(vgl_k_bu_heavy, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,
+                                   g->in.adj, g->bm_front, g->bm_next, d_levels, cur + 1, g->heavy, g->heavy_cnt, g->bu_partials);
             }
+            hipLaunchKernelGGL(vgl_k_bu_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->bu_partials, c->d_counters);
             hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
                                g->bm_front, g->bm_next);
             VGL_HIP_TRY(hipGetLastError());
-            VGL_TRY(vgl_read_counters(c));
+            VGL_TRY(vgl_read_counters(c, false));
             st.bu_steps++; st.edges_examined += c->h_counters[C_BU_EDGES];
             st.bu_edges += c->h_counters[C_BU_EDGES]; st.bu_found += c->h_counters[C_BU_FOUND];
             F = c->h_counters[C_BU_FOUND]; M = 0;      // next frontier; bitmaps now describe level cur+1
@@ -303,7 +359,7 @@ int vgl_hip_bfs_step_top_down(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_level
     hipLaunchKernelGGL(vgl_k_levels_to_bitmap<true>, dim3(vgl_grid(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, d_levels, -1,
                        g->bm_visited);
     vgl_pred_equal_i32 pred{d_levels, level};
-    VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, nullptr, nullptr, nullptr, nullptr, true, true));
+    VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, nullptr, nullptr, nullptr, true, true));
     const int64_t F = c->h_counters[C_FRONT], M = c->h_counters[C_NEIGH];
     if (local_frontier) *local_frontier = F;
     if (local_edges) *local_edges = M;
@@ -325,7 +381,7 @@ int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *c, int32_t V, int parts, const uint64
     if (!c || !d_bits_all || !d_levels) VGL_FAIL("bfs_apply_bitmaps: null argument");
     if (parts < 1) VGL_FAIL("bfs_apply_bitmaps: parts must be >= 1");
     VGL_TRY(vgl_zero_counters(c, C_TMP0, 1));
-    hipLaunchKernelGGL(vgl_k_apply_bitmaps, dim3(vgl_grid(V)), dim3(VGL_BLOCK), 0, c->stream, V, parts, vgl_ceil_div(V, 64), d_bits_all,
+    hipLaunchKernelGGL(vgl_k_apply_bitmaps, dim3(vgl_grid(V, 1024)), dim3(VGL_BLOCK), 0, c->stream, V, parts, vgl_ceil_div(V, 64), d_bits_all,
                        d_levels, level, c->d_counters);
     VGL_HIP_TRY(hipGetLastError());
     VGL_TRY(vgl_read_counters(c));

@@ -35,6 +35,8 @@ int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out)
     VGL_HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(int64_t) * C_NSLOTS));
     VGL_HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(int64_t) * C_NSLOTS, hipHostMallocDefault));
     VGL_HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(int64_t) * C_NSLOTS, c->stream));
+    VGL_HIP_TRY(hipMalloc((void **)&c->d_shards, sizeof(int64_t) * VGL_NSHARD));
+    VGL_HIP_TRY(hipMemsetAsync(c->d_shards, 0, sizeof(int64_t) * VGL_NSHARD, c->stream));
     memset(c->h_counters, 0, sizeof(int64_t) * C_NSLOTS);
     *out = c;
     return 0;
@@ -50,6 +52,7 @@ int vgl_hip_ctx_destroy(vgl_hip_ctx *c)
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->d_partials) hipFree(c->d_partials);
     hipFree(c->d_counters);
+    hipFree(c->d_shards);
     hipHostFree(c->h_counters);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -166,8 +169,19 @@ vgl_timed_launch::~vgl_timed_launch()
     slot->launches++;
 }
 
-int vgl_read_counters(vgl_hip_ctx *c)
+// counters[C_EDGES] += sum of the shards; shards are cleared
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_fold_shards(int64_t *shards, int64_t *counters)
 {
+    __shared__ int64_t s64[VGL_WAVES];
+    int64_t acc = 0;
+    for (int i = threadIdx.x; i < VGL_NSHARD; i += VGL_BLOCK) { acc += shards[i]; shards[i] = 0; }
+    acc = vgl_block_reduce_add(acc, s64);
+    if (threadIdx.x == 0) counters[C_EDGES] += acc;
+}
+
+int vgl_read_counters(vgl_hip_ctx *c, bool fold_shards)
+{
+    if (fold_shards) hipLaunchKernelGGL(vgl_k_fold_shards, dim3(1), dim3(VGL_BLOCK), 0, c->stream, c->d_shards, c->d_counters);
     VGL_HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(int64_t) * C_NSLOTS, hipMemcpyDeviceToHost, c->stream));
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;

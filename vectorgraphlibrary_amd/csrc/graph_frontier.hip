@@ -14,6 +14,17 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_rows(int32_t nrows, cons
     if (blockIdx.x == 0 && threadIdx.x == 0) tile_row[ntiles] = nrows > 0 ? nrows - 1 : 0;
 }
 
+// bit (row_base + r) = row r is non-empty; whole words are written (row_base is a multiple of 64)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_nonempty_rows(int32_t nrows, int32_t row_base, const int64_t *rowptr, uint64_t *bits)
+{
+    const int32_t nround = (nrows + 63) & ~63;
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nround; r += gridDim.x * VGL_BLOCK) {
+        const bool on = r < nrows && rowptr[r + 1] > rowptr[r];
+        const unsigned long long m = __ballot(on);
+        if ((threadIdx.x & 63) == 0) bits[(row_base + r) >> 6] = m;
+    }
+}
+
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_iota_flags(int32_t n, int32_t *ids, int32_t *flags, int32_t flag)
 {
     for (int32_t i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
@@ -102,6 +113,7 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_TRY(vgl_alloc(&g->bm_visited, words));
     VGL_TRY(vgl_alloc(&g->bm_front, words));
     VGL_TRY(vgl_alloc(&g->bm_next, words));
+    VGL_TRY(vgl_alloc(&g->bm_in_nz, words));
     VGL_TRY(vgl_alloc(&g->ids, (size_t)g->nrows));
     VGL_TRY(vgl_alloc(&g->offs, (size_t)g->nrows + 1));
     g->nvtiles = vgl_ceil_div(g->nrows, VGL_TILE);
@@ -110,7 +122,9 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_TRY(vgl_alloc(&g->vt_deg, (size_t)g->nvtiles));
     VGL_TRY(vgl_alloc(&g->vt_deg_off, (size_t)g->nvtiles));
     VGL_TRY(vgl_alloc(&g->tile_first, (size_t)g->out.ntiles + 2));
-    VGL_TRY(vgl_alloc(&g->heavy, (size_t)g->nrows));
+    VGL_TRY(vgl_alloc(&g->heavy, (size_t)g->nrows + 2048 * VGL_BLOCK));
+    VGL_TRY(vgl_alloc(&g->heavy_cnt, (size_t)2048));
+    VGL_TRY(vgl_alloc(&g->bu_partials, (size_t)2048 * 4));
     VGL_TRY(vgl_alloc(&g->epoch, (size_t)V));
     VGL_TRY(vgl_alloc(&g->fscratch, (size_t)V));
     VGL_TRY(vgl_alloc(&g->fscratch2, (size_t)V));
@@ -119,6 +133,12 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_HIP_TRY(hipMemsetAsync(g->bm_visited, 0, words * 8, c->stream));
     VGL_HIP_TRY(hipMemsetAsync(g->bm_front, 0, words * 8, c->stream));
     VGL_HIP_TRY(hipMemsetAsync(g->bm_next, 0, words * 8, c->stream));
+    VGL_HIP_TRY(hipMemsetAsync(g->bm_in_nz, 0, words * 8, c->stream));
+    if (g->in.rowptr) {
+        int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, vgl_ceil_div(g->nrows, VGL_BLOCK)));
+        hipLaunchKernelGGL(vgl_k_nonempty_rows, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, g->in.rowptr, g->bm_in_nz);
+        VGL_HIP_TRY(hipGetLastError());
+    }
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
     *out = g;
     return 0;
@@ -128,8 +148,8 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
 {
     if (!g) return 0;
     if (c) hipStreamSynchronize(c->stream);
-    void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->ids, g->offs, g->vt_cnt,
-                    g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->epoch, g->fscratch, g->fscratch2,
+    void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->ids, g->offs, g->vt_cnt,
+                    g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->bu_partials, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch};
     for (void *p : ptrs) if (p) hipFree(p);
     delete g;
@@ -204,7 +224,7 @@ static int vgl_gnf_frontier(vgl_hip_ctx *c, vgl_hip_graph *g, Pred pred, double 
 {
     if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("generate_new_frontier: graph handle must own all rows");
     // pass 1+2: flags, counts, totals
-    VGL_TRY(vgl_gnf_run(c, g, pred, f->ids, nullptr, nullptr, nullptr, nullptr, flags_out, false, true));
+    VGL_TRY(vgl_gnf_run(c, g, pred, f->ids, nullptr, nullptr, nullptr, flags_out, false, true));
     f->size = (int32_t)c->h_counters[C_FRONT];
     f->neighbours = c->h_counters[C_NEIGH];
     if (f->size == g->V) { f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE; }

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_init(int32_t V, int32_t 
 template <bool ACTIVE_FILTER>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax(const int64_t *rowptr, const int32_t *adj, const float *w,
                                                               const int32_t *tile_row, int64_t E, int32_t row_base,
-                                                              float *dist, int32_t *epoch, int32_t iter, int64_t *counters)
+                                                              float *dist, int32_t *epoch, int32_t iter, int64_t *counters, int64_t *shards)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int s_w[VGL_WAVES];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax(const int64_t *row
     const int any_changed = __syncthreads_or(changed);
     if (threadIdx.x == 0) {
         if (any_changed) counters[C_CHANGED] = 1;
-        atomicAdd((unsigned long long *)&counters[C_EDGES], (unsigned long long)n);
+        atomicAdd((unsigned long long *)&shards[blockIdx.x & (VGL_NSHARD - 1)], (unsigned long long)n);   // edges streamed (stats)
     }
 }
 
@@ -111,10 +111,10 @@ static int vgl_sssp_launch(vgl_hip_ctx *c, vgl_hip_graph *g, const float *w, flo
     vgl_timed_launch tl(c, "sssp_relax");
     if (filter)
         hipLaunchKernelGGL(vgl_k_sssp_relax<true>, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
-                           g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters);
+                           g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters, c->d_shards);
     else
         hipLaunchKernelGGL(vgl_k_sssp_relax<false>, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
-                           g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters);
+                           g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters, c->d_shards);
     VGL_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -33,6 +33,9 @@ enum {
     C_FRONT = 0, C_NEIGH = 1, C_BU_FOUND = 2, C_BU_EDGES = 3, C_HEAVY = 4, C_CHANGED = 5,
     C_EDGES = 6, C_TMP0 = 7, C_TMP1 = 8, C_JUMP = 9, C_NSLOTS = 32
 };
+// sharded accumulators: kernels launched with very many workgroups add into shard (blockIdx & (VGL_NSHARD-1)) so that no
+// single address receives more than a few hundred device atomics; vgl_read_counters folds them into the counter slots.
+constexpr int VGL_NSHARD = 1024;
 
 struct vgl_timing_slot {
     int64_t launches = 0;
@@ -45,6 +48,7 @@ struct vgl_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int64_t *d_counters = nullptr;   // C_NSLOTS
+    int64_t *d_shards = nullptr;     // VGL_NSHARD accumulators folded into d_counters[C_EDGES]
     int64_t *h_counters = nullptr;   // pinned mirror
     double *d_partials = nullptr;    // reduction partials (f64), capacity partials_cap
     size_t partials_cap = 0;
@@ -66,13 +70,16 @@ struct vgl_hip_graph {
     vgl_dir_csr out, in;
     // scratch shared by the fused algorithms (allocated at creation, sized by V / nrows / edges)
     uint64_t *bm_visited = nullptr, *bm_front = nullptr, *bm_next = nullptr; // ceil(V/64)+1 words each
+    uint64_t *bm_in_nz = nullptr;    // bit v = owned vertex v has incoming edges (bottom-up candidates)
     int32_t *ids = nullptr;          // nrows
     int64_t *offs = nullptr;         // nrows+1
     int32_t *vt_cnt = nullptr, *vt_cnt_off = nullptr;   // per vertex tile
     int64_t *vt_deg = nullptr, *vt_deg_off = nullptr;
     int64_t nvtiles = 0;
     int32_t *tile_first = nullptr;   // out.ntiles + 2
-    int32_t *heavy = nullptr;        // nrows
+    int32_t *heavy = nullptr;        // nrows + slack: per-workgroup segments of deferred bottom-up vertices
+    int32_t *heavy_cnt = nullptr;    // one count per bottom-up workgroup
+    int64_t *bu_partials = nullptr;  // 4 partial counters per bottom-up workgroup
     int32_t *epoch = nullptr;        // V (SSSP active filter)
     float *fscratch = nullptr;       // V (PR contrib)
     float *fscratch2 = nullptr;      // V (PR rdeg)
@@ -96,7 +103,7 @@ struct vgl_timed_launch {
     ~vgl_timed_launch();
 };
 
-int vgl_read_counters(vgl_hip_ctx *ctx);   // D2H all slots into h_counters, synchronises
+int vgl_read_counters(vgl_hip_ctx *ctx, bool fold_shards = true);   // D2H all slots into h_counters, synchronises
 int vgl_zero_counters(vgl_hip_ctx *ctx, int first, int count);
 int vgl_ensure_partials(vgl_hip_ctx *ctx, size_t n);
 
