@@ -1,0 +1,58 @@
+// All-active push Bellman-Ford against the operator API (call sequence of SSSP::vgl_dijkstra_all_active_push,
+// algorithms/sssp/shortest_paths.hpp:85-163; the `changes` word lives in host-visible memory like the reference's GPU
+// variant, gpu_shortest_paths.hpp:92-113).  The relaxation uses an integer atomic-min on the f32 bits so that no update
+// is lost; the fixed point is the same bit pattern either way.
+#pragma once
+
+struct ShortestPaths {
+    template <typename _T>
+    static double vgl_dijkstra_all_active_push(VGL_Graph &graph, EdgesArray<_T> &weights, VerticesArray<_T> &distances, int source_vertex)
+    {
+        VGL_GRAPH_ABSTRACTIONS graph_API(graph, SCATTER);
+        VGL_FRONTIER frontier(graph, SCATTER);
+        graph_API.change_traversal_direction(SCATTER, distances, frontier);
+        Timer tm;
+        tm.start();
+        const _T inf_val = std::numeric_limits<_T>::max() - MAX_WEIGHT;
+        auto init_distances = [distances, source_vertex, inf_val] __VGL_COMPUTE_ARGS__ {
+            distances[src_id] = (src_id == source_vertex) ? (_T)0 : inf_val;
+        };
+        frontier.set_all_active();
+        graph_API.compute(graph, frontier, init_distances);
+        int *changes;
+        MemoryAPI::allocate_array(&changes, 1);
+        int iterations_count = 0;
+        do {
+            changes[0] = 0;
+            iterations_count++;
+            auto edge_op_push = [distances, weights, changes, inf_val] __VGL_SCATTER_ARGS__ {
+                const _T src_weight = distances[src_id];
+                if (src_weight < inf_val) {
+                    const _T candidate = __fadd_rn(src_weight, weights[global_edge_pos]);
+                    if (distances[dst_id] > candidate) {
+                        atomicMin(reinterpret_cast<int *>(&distances[dst_id]), __float_as_int(candidate));
+                        changes[0] = 1;
+                    }
+                }
+            };
+            graph_API.scatter(graph, frontier, edge_op_push);
+        } while (changes[0]);
+        MemoryAPI::free_array(changes);
+        tm.end();
+        performance_stats.print_algorithm_performance_stats("SSSP (Bellman-Ford, all-active, push, operator API)", tm.get_time(), graph.get_edges_count());
+        return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
+    }
+
+    static double hip_fused(VGL_Graph &graph, EdgesArray<float> &weights, VerticesArray<float> &distances, int source_vertex)
+    {
+        Timer tm;
+        tm.start();
+        vgl_hip_sssp_stats st;
+        VGL_HIP_CALL(vgl_hip_sssp_run(VGL_RUNTIME::ctx(), graph.get_handle(), weights.get_ptr(), source_vertex, VGL_HIP_SSSP_ACTIVE_TILES,
+                                      distances.get_ptr(), &st));
+        tm.end();
+        performance_stats.print_algorithm_performance_stats("SSSP (fused)", tm.get_time(), graph.get_edges_count());
+        return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
+    }
+};
+#define SSSP ShortestPaths

@@ -1,0 +1,30 @@
+// bfs app: counterpart of apps/bfs/bfs.cpp:15-62 (rounds with random non-isolated sources, optional -check).
+#include "common.hpp"
+#include "algorithms/bfs.hpp"
+int main(int argc, char **argv)
+{
+    try {
+        VGL_RUNTIME::init_library(argc, argv);
+        Parser parser;
+        parser.parse_args(argc, argv);
+        VGL_Graph graph;
+        prepare_graph(graph, parser);
+        VerticesArray<int> levels(graph, SCATTER);
+        double avg_perf = 0;
+        for (int i = 0; i < parser.get_number_of_rounds(); i++) {
+            const int source_vertex = parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(SCATTER, i);
+            const double perf = parser.fused ? BFS::hip_fused(graph, levels, source_vertex, parser.direction_optimising)
+                                             : BFS::vgl_top_down(graph, levels, source_vertex);
+            avg_perf += perf / parser.get_number_of_rounds();
+            if (parser.get_check_flag()) {
+                HostCSR h(graph);
+                verify_results(levels.to_host(), seq_bfs(h, source_vertex));
+            }
+        }
+        dump_array(parser.dump, levels.to_host());
+        report_performance(avg_perf);
+        VGL_RUNTIME::finalize_library();
+    } catch (std::string error) { std::cout << error << std::endl; return 1; }
+    catch (const char *error) { std::cout << error << std::endl; return 1; }
+    return 0;
+}

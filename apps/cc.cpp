@@ -1,0 +1,26 @@
+// cc app: counterpart of apps/cc/cc.cpp:11-60 (undirected input, heat run + timed run).
+#include "common.hpp"
+#include "algorithms/cc.hpp"
+int main(int argc, char **argv)
+{
+    try {
+        VGL_RUNTIME::init_library(argc, argv);
+        Parser parser;
+        parser.parse_args(argc, argv);
+        VGL_Graph graph;
+        prepare_graph(graph, parser, UNDIRECTED_GRAPH);
+        VerticesArray<int> components(graph, SCATTER);
+        auto run = [&]() { return parser.fused ? ConnectedComponents::hip_fused(graph, components)
+                                               : ConnectedComponents::vgl_shiloach_vishkin(graph, components); };
+        run();                                   // heat run
+        report_performance(run());
+        if (parser.get_check_flag()) {
+            HostCSR h(graph);
+            equal_components(components.to_host(), seq_components(h));
+        }
+        dump_array(parser.dump, components.to_host());
+        VGL_RUNTIME::finalize_library();
+    } catch (std::string error) { std::cout << error << std::endl; return 1; }
+    catch (const char *error) { std::cout << error << std::endl; return 1; }
+    return 0;
+}

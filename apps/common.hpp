@@ -1,0 +1,168 @@
+// common.hpp -- shared pieces of the example applications: command line (cmd_parser.hpp:51-233 subset), graph
+// preparation (VGL_RUNTIME::prepare_graph, vgl_runtime.hpp:27-60), host-side sequential checkers in the spirit of the
+// reference's -check mode (seq_bfs.hpp, seq_shortest_paths.hpp, seq_pr.hpp, seq_bfs_based.hpp + verify_results.h), and
+// the AVG_PERF / error count output lines the reference's harness greps (scripts/benchmarking_api.py:38-63).
+#pragma once
+#include "../vectorgraphlibrary_amd/hip/vgl_hip.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <queue>
+
+struct Parser {
+    int scale = 10, avg_degree = 5, rounds = 1, source = -1;
+    bool rmat = true, check = false, direction_optimising = false, fused = false;
+    unsigned long long seed = 1;
+    std::string dump;
+    void parse_args(int argc, char **argv)
+    {
+        for (int i = 1; i < argc; i++) {
+            const std::string a = argv[i];
+            auto next = [&]() -> const char * { if (i + 1 >= argc) throw "missing value for command line option"; return argv[++i]; };
+            if (a == "-s") scale = atoi(next());
+            else if (a == "-e") avg_degree = atoi(next());
+            else if (a == "-type") rmat = std::string(next()) == "rmat";
+            else if (a == "-it") rounds = atoi(next());
+            else if (a == "-check") check = true;
+            else if (a == "-seed") seed = strtoull(next(), nullptr, 10);
+            else if (a == "-dump") dump = next();
+            else if (a == "-source") source = atoi(next());
+            else if (a == "-do") direction_optimising = true;
+            else if (a == "-td") direction_optimising = false;
+            else if (a == "-fused") fused = true;
+            else if (a == "-format") next();                       // csr only; accepted for CLI compatibility
+            else if (a == "-push" || a == "-all-active") {}
+            else throw "unknown command line option";
+        }
+    }
+    int get_number_of_rounds() const { return rounds; }
+    bool get_check_flag() const { return check; }
+};
+
+inline void prepare_graph(VGL_Graph &graph, const Parser &p, DirectionType dir = DIRECTED_GRAPH)
+{
+    GraphGenerationAPI::seed() = p.seed;
+    EdgesContainer ec;
+    const int v = 1 << p.scale;
+    const long long e = (long long)v * p.avg_degree;
+    if (p.rmat) GraphGenerationAPI::R_MAT(ec, v, e, 57, 19, 19, 5, dir);      // vgl_runtime.hpp:36
+    else GraphGenerationAPI::random_uniform(ec, v, e, dir);
+    graph.import(ec);
+}
+
+struct HostCSR {
+    int V; std::vector<long long> rowptr; std::vector<int> adj;
+    HostCSR(VGL_Graph &g, TraversalDirection d = SCATTER)
+    {
+        const vgl_csr_view v = g.get_direction_view(d);
+        V = g.get_vertices_count();
+        rowptr.resize((size_t)V + 1); adj.resize((size_t)v.edges);
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), rowptr.data(), v.rowptr, rowptr.size() * sizeof(long long)));
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), adj.data(), v.adj, adj.size() * sizeof(int)));
+    }
+};
+
+template <class T>
+inline void dump_array(const std::string &path, const std::vector<T> &a)
+{
+    if (path.empty()) return;
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char *)a.data(), (std::streamsize)(a.size() * sizeof(T)));
+}
+
+inline void report_performance(double mteps) { std::cout << "AVG_PERF: " << mteps << " MTEPS" << std::endl; }
+
+// verify_results (verify_results.h:33-92): exact for integers, |a-b| <= 100*FLT_EPSILON for floats
+template <class T>
+inline int verify_results(const std::vector<T> &a, const std::vector<T> &b)
+{
+    int errors = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+        bool same;
+        if (std::is_floating_point<T>::value) same = std::fabs((double)a[i] - (double)b[i]) <= 100.0 * FLT_EPSILON * std::max(1.0, std::fabs((double)b[i]));
+        else same = a[i] == b[i];
+        if (!same && errors++ < 10) std::cout << "error at " << i << ": " << a[i] << " vs " << b[i] << std::endl;
+    }
+    std::cout << "error count: " << errors << std::endl;
+    return errors;
+}
+
+// ---- sequential checkers ----
+inline std::vector<int> seq_bfs(const HostCSR &g, int source)
+{
+    std::vector<int> lv((size_t)g.V, -1);
+    std::queue<int> q;
+    lv[source] = 1; q.push(source);
+    while (!q.empty()) {
+        const int s = q.front(); q.pop();
+        for (long long p = g.rowptr[s]; p < g.rowptr[s + 1]; p++)
+            if (lv[g.adj[p]] == -1) { lv[g.adj[p]] = lv[s] + 1; q.push(g.adj[p]); }
+    }
+    return lv;
+}
+inline std::vector<float> seq_dijkstra(const HostCSR &g, const std::vector<float> &w, int source)
+{
+    const float inf = std::numeric_limits<float>::max() - MAX_WEIGHT;
+    std::vector<float> d((size_t)g.V, inf);
+    typedef std::pair<float, int> item;
+    std::priority_queue<item, std::vector<item>, std::greater<item>> pq;
+    d[source] = 0; pq.push({0.0f, source});
+    while (!pq.empty()) {
+        const int u = pq.top().second; pq.pop();
+        for (long long p = g.rowptr[u]; p < g.rowptr[u + 1]; p++) {
+            const int v = g.adj[p];
+            if (d[v] > d[u] + w[p]) { d[v] = d[u] + w[p]; pq.push({d[v], v}); }
+        }
+    }
+    return d;
+}
+inline std::vector<float> seq_page_rank(const HostCSR &g, int iterations)
+{
+    const int V = g.V;
+    const float d = 0.85f, k = (float)((1.0 - d) / ((float)V));
+    std::vector<int> indeg((size_t)V, 0);
+    for (int u = 0; u < V; u++) for (long long p = g.rowptr[u]; p < g.rowptr[u + 1]; p++) if (g.adj[p] != u) indeg[g.adj[p]]++;
+    std::vector<float> r((size_t)V, (float)(1.0 / V)), old((size_t)V);
+    for (int it = 0; it < iterations; it++) {
+        old = r;
+        double dangling = 0;
+        for (int v = 0; v < V; v++) if (indeg[v] == 0) dangling += old[v] / V;
+        for (int u = 0; u < V; u++) {
+            float acc = 0;
+            for (long long p = g.rowptr[u]; p < g.rowptr[u + 1]; p++) {
+                const int v = g.adj[p];
+                if (v != u) acc += old[v] * (float)(1.0 / indeg[v]);
+            }
+            r[u] = k + d * (acc + (float)dangling);
+        }
+    }
+    return r;
+}
+inline std::vector<int> seq_components(const HostCSR &g)
+{
+    std::vector<int> c((size_t)g.V, -1);
+    int cur = 1;
+    for (int s0 = 0; s0 < g.V; s0++) {
+        if (c[s0] != -1) continue;
+        std::queue<int> q; c[s0] = cur; q.push(s0);
+        while (!q.empty()) {
+            const int s = q.front(); q.pop();
+            for (long long p = g.rowptr[s]; p < g.rowptr[s + 1]; p++) if (c[g.adj[p]] == -1) { c[g.adj[p]] = cur; q.push(g.adj[p]); }
+        }
+        cur++;
+    }
+    return c;
+}
+// equal_components (verify_results.h:198-254): the two labelings must induce the same partition
+inline int equal_components(const std::vector<int> &a, const std::vector<int> &b)
+{
+    std::map<int, int> f, r; int errors = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+        auto x = f.emplace(a[i], b[i]); auto y = r.emplace(b[i], a[i]);
+        if (x.first->second != b[i] || y.first->second != a[i]) errors++;
+    }
+    std::cout << "error count: " << errors << std::endl;
+    return errors;
+}

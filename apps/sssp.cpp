@@ -1,0 +1,32 @@
+// sssp app: counterpart of apps/sssp/sssp.cpp:16-80.
+#include "common.hpp"
+#include "algorithms/sssp.hpp"
+int main(int argc, char **argv)
+{
+    try {
+        VGL_RUNTIME::init_library(argc, argv);
+        Parser parser;
+        parser.parse_args(argc, argv);
+        VGL_Graph graph;
+        prepare_graph(graph, parser);
+        VerticesArray<float> distances(graph, SCATTER);
+        EdgesArray<float> weights(graph);
+        weights.set_all_random(MAX_WEIGHT);
+        double avg_perf = 0;
+        for (int i = 0; i < parser.get_number_of_rounds(); i++) {
+            const int source_vertex = parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(SCATTER, i);
+            const double perf = parser.fused ? ShortestPaths::hip_fused(graph, weights, distances, source_vertex)
+                                             : ShortestPaths::vgl_dijkstra_all_active_push(graph, weights, distances, source_vertex);
+            avg_perf += perf / parser.get_number_of_rounds();
+            if (parser.get_check_flag()) {
+                HostCSR h(graph);
+                verify_results(distances.to_host(), seq_dijkstra(h, weights.outgoing_to_host(), source_vertex));
+            }
+        }
+        dump_array(parser.dump, distances.to_host());
+        report_performance(avg_perf);
+        VGL_RUNTIME::finalize_library();
+    } catch (std::string error) { std::cout << error << std::endl; return 1; }
+    catch (const char *error) { std::cout << error << std::endl; return 1; }
+    return 0;
+}

@@ -102,6 +102,15 @@ int vgl_hip_gnf_from_flags(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_
 int vgl_hip_gnf_equal_i32(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_values, int32_t value,
                           double dense_threshold, vgl_hip_frontier *f);
 
+/* ---- plans for the templated advance kernels of the C++ operator class (vectorgraphlibrary_amd/hip/): the edge-balanced
+ *      kernels need, per direction (0 = outgoing / SCATTER, 1 = incoming / GATHER), the static tile->row table of the
+ *      graph and, for a SPARSE frontier, the exclusive edge offsets of its ids plus the tile->position table. ---- */
+int vgl_hip_graph_tile_rows(vgl_hip_graph *g, int direction, const int32_t **d_tile_row, int64_t *ntiles);
+int vgl_hip_frontier_advance_plan(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f, int direction,
+                                  const int64_t **d_offs, const int32_t **d_tile_first, int64_t *edges);
+/* device buffer of V doubles owned by the context, used by the operator class to materialise reduce_op values */
+int vgl_hip_reduce_sum_f64_buffer(vgl_hip_ctx *ctx, int64_t n, const double *d_values, double *result);
+
 /* ---- reduce (reduce_worker_sum, multicore/reduce.hpp:6-60; only REDUCE_SUM is live).
  *      Sums d_values[v] over the frontier's active vertices; deterministic (fixed tree). Synchronises. ---- */
 int vgl_hip_reduce_sum_i32(vgl_hip_ctx *ctx, vgl_hip_frontier *f, const int32_t *d_values, int64_t *result);

@@ -66,6 +66,62 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_reduce_final(int nparts, cons
     if (threadIdx.x == 0) *out = acc;
 }
 
+// ---- advance plan of a sparse frontier: exclusive scan of the degrees of ids[0..F) (three passes, like the GNF) ----
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_plan_sums(int32_t F, const int32_t *ids, int32_t row_base, const int64_t *rowptr,
+                                                             int64_t *blk_sum)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    int64_t deg = 0;
+    const int32_t p0 = blockIdx.x * VGL_TILE + threadIdx.x * VGL_EPT;
+    for (int j = 0; j < VGL_EPT; j++)
+        if (p0 + j < F) { const int32_t r = ids[p0 + j] - row_base; deg += rowptr[r + 1] - rowptr[r]; }
+    deg = vgl_block_reduce_add(deg, s64);
+    if (threadIdx.x == 0) blk_sum[blockIdx.x] = deg;
+}
+__global__ __launch_bounds__(VGL_SCAN_THREADS) void vgl_k_plan_scan(int64_t nblk, const int64_t *blk_sum, int64_t *blk_off, int64_t *counters,
+                                                                    int64_t *offs, int32_t F)
+{
+    __shared__ int64_t s_d[VGL_SCAN_THREADS / 64];
+    const int64_t per = (nblk + VGL_SCAN_THREADS - 1) / VGL_SCAN_THREADS;
+    const int64_t lo = min(nblk, (int64_t)threadIdx.x * per), hi = min(nblk, lo + per);
+    int64_t d = 0;
+    for (int64_t t = lo; t < hi; t++) d += blk_sum[t];
+    const int64_t di = vgl_wave_incl_add(d);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) s_d[w] = di;
+    __syncthreads();
+    int64_t db = 0, dtot = 0;
+    for (int i = 0; i < VGL_SCAN_THREADS / 64; i++) { if (i < w) db += s_d[i]; dtot += s_d[i]; }
+    int64_t dpre = db + di - d;
+    for (int64_t t = lo; t < hi; t++) { blk_off[t] = dpre; dpre += blk_sum[t]; }
+    if (threadIdx.x == 0) { counters[C_NEIGH] = dtot; offs[F] = dtot; }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_plan_write(int32_t F, const int32_t *ids, int32_t row_base, const int64_t *rowptr,
+                                                              const int64_t *blk_off, int64_t *offs)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    int64_t degs[VGL_EPT], deg = 0;
+    const int32_t p0 = blockIdx.x * VGL_TILE + threadIdx.x * VGL_EPT;
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        degs[j] = 0;
+        if (p0 + j < F) { const int32_t r = ids[p0 + j] - row_base; degs[j] = rowptr[r + 1] - rowptr[r]; deg += degs[j]; }
+    }
+    int64_t tot;
+    int64_t e = blk_off[blockIdx.x] + vgl_block_excl_add(deg, s64, &tot);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++)
+        if (p0 + j < F) { offs[p0 + j] = e; e += degs[j]; }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_plan_tile_first(int32_t F, const int64_t *offs, int32_t *tile_first)
+{
+    for (int32_t p = blockIdx.x * VGL_BLOCK + threadIdx.x; p < F; p += gridDim.x * VGL_BLOCK) {
+        const int64_t t0 = (offs[p] + VGL_TILE - 1) / VGL_TILE;
+        const int64_t t1 = (offs[p + 1] + VGL_TILE - 1) / VGL_TILE;
+        for (int64_t t = t0; t < t1; t++) tile_first[t] = p;
+    }
+}
+
 static int vgl_build_dir(vgl_hip_ctx *c, vgl_dir_csr &d, int32_t nrows)
 {
     d.ntiles = vgl_ceil_div(d.edges, VGL_TILE);
@@ -171,6 +227,7 @@ int vgl_hip_frontier_destroy(vgl_hip_ctx *c, vgl_hip_frontier *f)
     if (!f) return 0;
     if (c) hipStreamSynchronize(c->stream);
     hipFree(f->flags); hipFree(f->ids);
+    if (f->offs) { hipFree(f->offs); hipFree(f->tile_first); hipFree(f->blk_sum); hipFree(f->blk_off); }
     delete f;
     return 0;
 }
@@ -213,6 +270,56 @@ int vgl_hip_frontier_info(vgl_hip_ctx *c, vgl_hip_frontier *f, int32_t *size, in
     if (sparsity) *sparsity = f->sparsity;
     return 0;
 }
+int vgl_hip_graph_tile_rows(vgl_hip_graph *g, int direction, const int32_t **d_tile_row, int64_t *ntiles)
+{
+    if (!g || !d_tile_row || !ntiles) VGL_FAIL("graph_tile_rows: null argument");
+    const vgl_dir_csr &d = direction ? g->in : g->out;
+    if (!d.rowptr) VGL_FAIL("graph_tile_rows: this direction of the graph is not stored");
+    *d_tile_row = d.tile_row; *ntiles = d.ntiles;
+    return 0;
+}
+
+int vgl_hip_frontier_advance_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, int direction, const int64_t **d_offs,
+                                  const int32_t **d_tile_first, int64_t *edges)
+{
+    if (!c || !g || !f || !d_offs || !d_tile_first || !edges) VGL_FAIL("frontier_advance_plan: null argument");
+    const vgl_dir_csr &d = direction ? g->in : g->out;
+    if (!d.rowptr) VGL_FAIL("frontier_advance_plan: this direction of the graph is not stored");
+    if (f->sparsity != VGL_HIP_FRONTIER_SPARSE) VGL_FAIL("frontier_advance_plan: only sparse frontiers need a plan");
+    const int32_t F = f->size;
+    const int64_t nblk = vgl_ceil_div(std::max<int64_t>(F, 1), VGL_TILE);
+    if (!f->offs) {
+        const int64_t emax = std::max(g->out.edges, g->in.edges);
+        VGL_TRY(vgl_alloc(&f->offs, (size_t)g->V + 1));
+        VGL_TRY(vgl_alloc(&f->tile_first, (size_t)vgl_ceil_div(emax, VGL_TILE) + 2));
+        VGL_TRY(vgl_alloc(&f->blk_sum, (size_t)vgl_ceil_div(g->V, VGL_TILE) + 1));
+        VGL_TRY(vgl_alloc(&f->blk_off, (size_t)vgl_ceil_div(g->V, VGL_TILE) + 1));
+    }
+    *d_offs = f->offs; *d_tile_first = f->tile_first; *edges = 0;
+    if (F == 0) return 0;
+    hipLaunchKernelGGL(vgl_k_plan_sums, dim3((unsigned)nblk), dim3(VGL_BLOCK), 0, c->stream, F, f->ids, g->row_begin, d.rowptr, f->blk_sum);
+    hipLaunchKernelGGL(vgl_k_plan_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, nblk, f->blk_sum, f->blk_off, c->d_counters, f->offs, F);
+    hipLaunchKernelGGL(vgl_k_plan_write, dim3((unsigned)nblk), dim3(VGL_BLOCK), 0, c->stream, F, f->ids, g->row_begin, d.rowptr, f->blk_off, f->offs);
+    const int grid = (int)std::min<int64_t>(4096, vgl_ceil_div(F, VGL_BLOCK));
+    hipLaunchKernelGGL(vgl_k_plan_tile_first, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, F, f->offs, f->tile_first);
+    VGL_HIP_TRY(hipGetLastError());
+    VGL_TRY(vgl_read_counters(c, false));
+    *edges = c->h_counters[C_NEIGH];
+    return 0;
+}
+
+int vgl_hip_reduce_sum_f64_buffer(vgl_hip_ctx *c, int64_t n, const double *d_values, double *result)
+{
+    if (!c || !d_values || !result) VGL_FAIL("reduce_sum_f64_buffer: null argument");
+    if (n <= 0) { *result = 0; return 0; }
+    if (n > 0x7FFFFFFFLL) VGL_FAIL("reduce_sum_f64_buffer: n too large");
+    const int nb = (int)std::min<int64_t>(1024, vgl_ceil_div(n, VGL_BLOCK));
+    VGL_TRY(vgl_ensure_partials(c, (size_t)nb + 1));
+    hipLaunchKernelGGL((vgl_k_reduce_partial<double, double, 0>), dim3(nb), dim3(VGL_BLOCK), 0, c->stream, (int32_t)n, d_values,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, c->d_partials);
+    return vgl_reduce_common(c, nb, result);
+}
+
 int32_t *vgl_hip_frontier_ids(vgl_hip_frontier *f) { return f ? f->ids : nullptr; }
 int32_t *vgl_hip_frontier_flags(vgl_hip_frontier *f) { return f ? f->flags : nullptr; }
 

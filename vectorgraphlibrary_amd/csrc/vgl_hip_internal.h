@@ -94,6 +94,10 @@ struct vgl_hip_frontier {
     int32_t size = 0;
     int64_t neighbours = 0;
     int sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE;
+    // advance plan of a SPARSE frontier (built on demand by vgl_hip_frontier_advance_plan)
+    int64_t *offs = nullptr;         // V+1 exclusive edge offsets of ids[] in the planned direction
+    int32_t *tile_first = nullptr;   // ceil(E/VGL_TILE)+2
+    int64_t *blk_sum = nullptr, *blk_off = nullptr;   // per 2048-id block degree sums / offsets
 };
 
 // timing helpers (no-ops unless ctx->timing)

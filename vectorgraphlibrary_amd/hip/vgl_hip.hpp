@@ -1,0 +1,545 @@
+// vgl_hip.hpp -- C++ operator API of the MI355X backend: the drop-in counterpart of the reference's per-architecture
+// backend class (vgl_compute_api/template/graph_abstractions_template.h:5-107, selected through
+// architecture_independent_api.h:3-43).  Compile the application TU with hipcc (--offload-arch=gfx950) and link
+// libvgl_hip.so; user operators are device lambdas exactly as in the reference's __USE_GPU__ flavour:
+//
+//     auto edge_op = [levels, cur] __VGL_SCATTER_ARGS__ { ... };
+//     graph_API.scatter(graph, frontier, edge_op);
+//
+// Header-only part : templated HIP kernels that call the user lambdas (advance all-active / dense / sparse, compute,
+//                    reduce, generate_new_frontier predicate), edge-balanced with the same LDS row-map machinery as the
+//                    fused kernels of libvgl_hip.so.
+// Library part     : everything that does not depend on a user type goes through the C ABI (include/vgl_hip.h):
+//                    graph build, frontier compaction, scans, reductions, synthetic inputs.
+//
+// The data-structure classes below mirror the members the reference's algorithms and apps use
+// (VGL_Graph vgl_graph.h:7-79, VGL_Frontier frontier.h:13-54, VerticesArray vertices_array.h:17-77,
+//  EdgesArray edges_array.h:10-63, EdgesContainer edges_container.h:5-233).  Graph storage is plain CSR with identity
+// numbering (CSR_GRAPH), so reorder() is the identity and every direction shares one vertex numbering.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <string>
+#include <vector>
+#include <chrono>
+#include "../../include/vgl_hip.h"
+#include "../csrc/vgl_hip_internal.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// architecture macros (architecture_independent_api.h:19-43, GPU flavour)
+// ------------------------------------------------------------------------------------------------------------------
+#define __USE_HIP__
+#define __VGL_COMPUTE_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_SCATTER_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
+#define __VGL_GATHER_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
+#define __VGL_ADVANCE_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
+#define __VGL_ADVANCE_PREPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_ADVANCE_POSTPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_GNF_ARGS__ __device__ (int src_id, int connections_count)->int
+#define __VGL_REDUCE_ANY_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_REDUCE_INT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->int
+#define __VGL_REDUCE_FLT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->float
+#define __VGL_REDUCE_DBL_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->double
+#define VGL_GRAPH_ABSTRACTIONS GraphAbstractionsHIP
+#define VGL_FRONTIER VGL_Frontier
+#define VGL_SRC_ID_ADD(a, b) (atomicAdd(&(a), (b)))
+#define VGL_INC(a) (atomicAdd(&(a), 1))
+#define VGL_LAMBDA_CAP(a) a
+
+// framework_types.h:120-160, settings.h:93
+enum TraversalDirection { SCATTER = 0, GATHER = 1, ORIGINAL = 2 };
+enum REDUCE_TYPE { REDUCE_SUM = 0, REDUCE_MAX = 1, REDUCE_MIN = 1, REDUCE_AVG = 3 };
+enum FrontierSparsityType { ALL_ACTIVE_FRONTIER = 2, SPARSE_FRONTIER = 1, DENSE_FRONTIER = 0 };
+enum DirectionType { UNDIRECTED_GRAPH = 0, DIRECTED_GRAPH = 1 };
+#define IN_FRONTIER_FLAG 1
+#define NOT_IN_FRONTIER_FLAG 0
+#define MAX_WEIGHT 100
+
+// errors are thrown as C strings, like the reference (apps/bfs/bfs.cpp:53-61)
+#define VGL_HIP_CALL(expr) do { if ((expr) != 0) throw vgl_hip_last_error(); } while (0)
+#define VGL_HIP_RT(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw hipGetErrorString(_e); } while (0)
+
+// ------------------------------------------------------------------------------------------------------------------
+// runtime: one context per process (VGL_RUNTIME::init_library, vgl_runtime.hpp:5-25)
+// ------------------------------------------------------------------------------------------------------------------
+struct VGL_RUNTIME {
+    static vgl_hip_ctx *&ctx() { static vgl_hip_ctx *c = nullptr; return c; }
+    static hipStream_t stream() { return (hipStream_t)vgl_hip_ctx_stream(ctx()); }
+    static void init_library(int, char **, int device = 0) { if (!ctx()) VGL_HIP_CALL(vgl_hip_ctx_create(device, nullptr, &ctx())); }
+    static void finalize_library() { if (ctx()) { vgl_hip_ctx_destroy(ctx()); ctx() = nullptr; } }
+    static void sync() { VGL_HIP_CALL(vgl_hip_ctx_sync(ctx())); }
+};
+
+// MemoryAPI (memory_API.hpp:4-15): allocate_array gives HOST-VISIBLE, device-writable memory for the small flag / counter
+// words the reference keeps in managed memory (e.g. `changes[0]`, gpu_shortest_paths.hpp:92-113)
+struct MemoryAPI {
+    template <class T> static void allocate_array(T **p, size_t n) { VGL_HIP_RT(hipHostMalloc((void **)p, sizeof(T) * (n ? n : 1), hipHostMallocDefault)); }
+    template <class T> static void free_array(T *p) { if (p) hipHostFree(p); }
+    template <class T> static void allocate_device_array(T **p, size_t n) { VGL_HIP_CALL(vgl_hip_malloc(VGL_RUNTIME::ctx(), sizeof(T) * n, (void **)p)); }
+    template <class T> static void free_device_array(T *p) { if (p) vgl_hip_free(VGL_RUNTIME::ctx(), p); }
+};
+
+class Timer {                                 // timer.hpp:20-56 (wall time around synchronised primitives)
+    std::chrono::steady_clock::time_point t0, t1;
+public:
+    void start() { VGL_RUNTIME::sync(); t0 = std::chrono::steady_clock::now(); }
+    void end() { VGL_RUNTIME::sync(); t1 = std::chrono::steady_clock::now(); }
+    double get_time() const { return std::chrono::duration<double>(t1 - t0).count(); }
+};
+struct PerformanceStats {                     // performance_stats.hpp:248-275
+    double get_algorithm_performance(double t, long long edges) const { return edges / (t * 1e6); }   // MTEPS
+    void print_algorithm_performance_stats(const std::string &name, double t, long long edges) const
+    {
+        std::cout << name << ": Wall time " << t * 1e3 << " ms, Wall (graph500) perf: " << edges / (t * 1e6) << " MTEPS" << std::endl;
+    }
+};
+static PerformanceStats performance_stats;
+
+// ------------------------------------------------------------------------------------------------------------------
+// edges container + synthetic generators (edges_container.h, graph_generation.hpp:5-51,94-187) -- device resident
+// ------------------------------------------------------------------------------------------------------------------
+class EdgesContainer {
+    int vertices_count = 0; long long edges_count = 0; int *src_ids = nullptr, *dst_ids = nullptr;
+public:
+    EdgesContainer() {}
+    ~EdgesContainer() { MemoryAPI::free_device_array(src_ids); MemoryAPI::free_device_array(dst_ids); }
+    EdgesContainer(const EdgesContainer &) = delete;
+    void resize(int v, long long e)
+    {
+        MemoryAPI::free_device_array(src_ids); MemoryAPI::free_device_array(dst_ids);
+        vertices_count = v; edges_count = e;
+        MemoryAPI::allocate_device_array(&src_ids, (size_t)e); MemoryAPI::allocate_device_array(&dst_ids, (size_t)e);
+    }
+    int *get_src_ids() { return src_ids; }    // device pointers
+    int *get_dst_ids() { return dst_ids; }
+    int get_vertices_count() const { return vertices_count; }
+    long long get_edges_count() const { return edges_count; }
+    void load_from_host(int v, const std::vector<int> &s, const std::vector<int> &d)
+    {
+        resize(v, (long long)s.size());
+        VGL_HIP_CALL(vgl_hip_memcpy_h2d(VGL_RUNTIME::ctx(), src_ids, s.data(), s.size() * sizeof(int)));
+        VGL_HIP_CALL(vgl_hip_memcpy_h2d(VGL_RUNTIME::ctx(), dst_ids, d.data(), d.size() * sizeof(int)));
+    }
+};
+
+struct GraphGenerationAPI {
+    static unsigned long long &seed() { static unsigned long long s = 1; return s; }     // deterministic (the reference seeds with time())
+    static void R_MAT(EdgesContainer &ec, int v, long long e, int a, int b, int c, int d, DirectionType dir = DIRECTED_GRAPH)
+    {
+        int scale = 0; while ((1 << scale) < v) scale++;
+        if ((1 << scale) != v) throw "R_MAT: vertices count must be a power of two";
+        ec.resize(v, dir == DIRECTED_GRAPH ? e : 2 * e);
+        VGL_HIP_CALL(vgl_hip_gen_rmat(VGL_RUNTIME::ctx(), scale, 0, e, seed(), a, b, c, d, 1, ec.get_src_ids(), ec.get_dst_ids()));
+        if (dir != DIRECTED_GRAPH) mirror(ec, e);
+    }
+    static void random_uniform(EdgesContainer &ec, int v, long long e, DirectionType dir = DIRECTED_GRAPH)
+    {
+        int scale = 0; while ((1 << scale) < v) scale++;
+        if ((1 << scale) != v) throw "random_uniform: vertices count must be a power of two";
+        ec.resize(v, dir == DIRECTED_GRAPH ? e : 2 * e);
+        VGL_HIP_CALL(vgl_hip_gen_uniform(VGL_RUNTIME::ctx(), scale, 0, e, seed(), ec.get_src_ids(), ec.get_dst_ids()));
+        if (dir != DIRECTED_GRAPH) mirror(ec, e);
+    }
+private:
+    static void mirror(EdgesContainer &ec, long long e)    // src[i+e] = dst[i], dst[i+e] = src[i] (graph_generation.hpp:41-49)
+    {
+        VGL_HIP_RT(hipMemcpyAsync(ec.get_src_ids() + e, ec.get_dst_ids(), e * sizeof(int), hipMemcpyDeviceToDevice, VGL_RUNTIME::stream()));
+        VGL_HIP_RT(hipMemcpyAsync(ec.get_dst_ids() + e, ec.get_src_ids(), e * sizeof(int), hipMemcpyDeviceToDevice, VGL_RUNTIME::stream()));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// VGL_Graph: outgoing + incoming CSR on the device (VGL_Graph::import, vgl_graph.hpp:57-68)
+// ------------------------------------------------------------------------------------------------------------------
+struct vgl_csr_view { const long long *rowptr; const int *adj; long long edges; };
+
+class VGL_Graph {
+    int vertices_count = 0; long long edges_count = 0;
+    int64_t *out_rowptr = nullptr, *in_rowptr = nullptr, *out_perm = nullptr, *in_perm = nullptr;
+    int32_t *out_adj = nullptr, *in_adj = nullptr;
+    vgl_hip_graph *handle = nullptr;
+    std::vector<long long> host_out_rowptr;
+public:
+    VGL_Graph() {}
+    ~VGL_Graph()
+    {
+        if (handle) vgl_hip_graph_destroy(VGL_RUNTIME::ctx(), handle);
+        for (void *p : {(void *)out_rowptr, (void *)in_rowptr, (void *)out_perm, (void *)in_perm, (void *)out_adj, (void *)in_adj})
+            MemoryAPI::free_device_array((char *)p);
+    }
+    VGL_Graph(const VGL_Graph &) = delete;
+    void import(EdgesContainer &ec)
+    {
+        vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+        const int V = ec.get_vertices_count(); const long long E = ec.get_edges_count();
+        vertices_count = V; edges_count = E;
+        MemoryAPI::allocate_device_array(&out_rowptr, (size_t)V + 1); MemoryAPI::allocate_device_array(&in_rowptr, (size_t)V + 1);
+        MemoryAPI::allocate_device_array(&out_adj, (size_t)E); MemoryAPI::allocate_device_array(&in_adj, (size_t)E);
+        MemoryAPI::allocate_device_array(&out_perm, (size_t)E); MemoryAPI::allocate_device_array(&in_perm, (size_t)E);
+        int64_t kept = 0;
+        VGL_HIP_CALL(vgl_hip_coo_to_csr(c, V, E, ec.get_src_ids(), ec.get_dst_ids(), 0, V, out_rowptr, out_adj, out_perm, &kept));
+        // the incoming container is built from the OUT-CSR-ordered list transposed (vgl_graph.hpp:61-64): src := adjacency, dst := row
+        int32_t *csr_src = nullptr;
+        MemoryAPI::allocate_device_array(&csr_src, (size_t)E);
+        VGL_HIP_CALL(vgl_hip_gather_u32(c, E, out_perm, ec.get_src_ids(), csr_src));
+        VGL_HIP_CALL(vgl_hip_coo_to_csr(c, V, E, out_adj, csr_src, 0, V, in_rowptr, in_adj, in_perm, &kept));
+        MemoryAPI::free_device_array(csr_src);
+        VGL_HIP_CALL(vgl_hip_graph_create(c, V, 0, V, out_rowptr, out_adj, E, in_rowptr, in_adj, E, &handle));
+        host_out_rowptr.resize((size_t)V + 1);
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(c, host_out_rowptr.data(), out_rowptr, sizeof(long long) * ((size_t)V + 1)));
+    }
+    int get_vertices_count() const { return vertices_count; }
+    long long get_edges_count() const { return edges_count; }
+    vgl_hip_graph *get_handle() const { return handle; }
+    vgl_csr_view get_direction_view(TraversalDirection d) const
+    {
+        return d == GATHER ? vgl_csr_view{(const long long *)in_rowptr, in_adj, edges_count}
+                           : vgl_csr_view{(const long long *)out_rowptr, out_adj, edges_count};
+    }
+    const int64_t *get_outgoing_edges_reorder_indexes() const { return out_perm; }   // CSR position -> input edge
+    const int64_t *get_incoming_edges_reorder_indexes() const { return in_perm; }    // in-CSR position -> out-CSR position
+    int reorder(int v, TraversalDirection, TraversalDirection) const { return v; }  // identity numbering (CSR_GRAPH)
+    int get_outgoing_connections_count(int v) const { return (int)(host_out_rowptr[v + 1] - host_out_rowptr[v]); }
+    // deterministic stand-in for select_random_nz_vertex (vgl_graph get_api): k-th draw of a fixed stream
+    int select_random_nz_vertex(TraversalDirection = ORIGINAL, unsigned long long draw = 0) const
+    {
+        unsigned long long x = 0x9E3779B97F4A7C15ULL * (draw + 1) + GraphGenerationAPI::seed();
+        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 29;
+        int v = (int)(x % (unsigned long long)vertices_count);
+        for (int i = 0; i < vertices_count; i++, v = (v + 1) % vertices_count)
+            if (host_out_rowptr[v + 1] > host_out_rowptr[v]) return v;
+        throw "select_random_nz_vertex: graph has no edges";
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// VerticesArray / EdgesArray: raw typed device arrays; the copy constructor is a SHALLOW alias so that lambdas can
+// capture them by value (vertices_array.hpp:20-28)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename _T>
+class VerticesArray {
+    _T *vertices_data = nullptr; int vertices_count = 0; bool is_copy = false; TraversalDirection direction = SCATTER;
+public:
+    VerticesArray(VGL_Graph &g, TraversalDirection d = SCATTER) : vertices_count(g.get_vertices_count()), direction(d)
+    { MemoryAPI::allocate_device_array(&vertices_data, (size_t)vertices_count); }
+    __host__ __device__ VerticesArray(const VerticesArray &o)
+        : vertices_data(o.vertices_data), vertices_count(o.vertices_count), is_copy(true), direction(o.direction) {}
+    __host__ __device__ ~VerticesArray()
+    {
+#ifndef __HIP_DEVICE_COMPILE__
+        if (!is_copy && vertices_data) MemoryAPI::free_device_array(vertices_data);
+#endif
+    }
+    __host__ __device__ inline _T &operator[](int i) const { return vertices_data[i]; }
+    __host__ __device__ inline _T get(int i) const { return vertices_data[i]; }
+    __host__ __device__ inline void set(int i, _T v) const { vertices_data[i] = v; }
+    __host__ __device__ _T *get_ptr() const { return vertices_data; }
+    int size() const { return vertices_count; }
+    TraversalDirection get_direction() const { return direction; }
+    void set_direction(TraversalDirection d) { direction = d; }
+    void reorder(TraversalDirection) {}                                   // identity numbering
+    void set_all_constant(_T v)
+    {
+        std::vector<_T> h((size_t)vertices_count, v);
+        VGL_HIP_CALL(vgl_hip_memcpy_h2d(VGL_RUNTIME::ctx(), vertices_data, h.data(), sizeof(_T) * h.size()));
+    }
+    std::vector<_T> to_host() const
+    {
+        std::vector<_T> h((size_t)vertices_count);
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h.data(), vertices_data, sizeof(_T) * h.size()));
+        return h;
+    }
+};
+
+template <typename _T>
+class EdgesArray {                     // layout [outgoing E ; incoming E] (csr_edges_array.hpp:67-73)
+    _T *edges_data = nullptr; long long edges_count = 0; bool is_copy = false; VGL_Graph *graph_ptr = nullptr;
+public:
+    EdgesArray(VGL_Graph &g) : edges_count(g.get_edges_count()), graph_ptr(&g)
+    { MemoryAPI::allocate_device_array(&edges_data, (size_t)(2 * edges_count)); }
+    __host__ __device__ EdgesArray(const EdgesArray &o) : edges_data(o.edges_data), edges_count(o.edges_count), is_copy(true), graph_ptr(o.graph_ptr) {}
+    __host__ __device__ ~EdgesArray()
+    {
+#ifndef __HIP_DEVICE_COMPILE__
+        if (!is_copy && edges_data) MemoryAPI::free_device_array(edges_data);
+#endif
+    }
+    __host__ __device__ inline _T &operator[](long long i) const { return edges_data[i]; }
+    __host__ __device__ inline _T get(long long i) const { return edges_data[i]; }
+    __host__ __device__ _T *get_ptr() const { return edges_data; }
+    // random f32 in [0, max) per INPUT edge, carried to both CSR orders (csr_edges_array.hpp:31-40); deterministic stream
+    void set_all_random(_T max_rand)
+    {
+        static_assert(sizeof(_T) == 4, "4-byte edge properties");
+        vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+        float *w_in = nullptr;
+        MemoryAPI::allocate_device_array(&w_in, (size_t)edges_count);
+        VGL_HIP_CALL(vgl_hip_gen_weights(c, 0, edges_count, GraphGenerationAPI::seed(), w_in));   // uniform [0,100)
+        (void)max_rand;
+        VGL_HIP_CALL(vgl_hip_gather_u32(c, edges_count, graph_ptr->get_outgoing_edges_reorder_indexes(), w_in, edges_data));
+        VGL_HIP_CALL(vgl_hip_gather_u32(c, edges_count, graph_ptr->get_incoming_edges_reorder_indexes(), edges_data, edges_data + edges_count));
+        VGL_RUNTIME::sync();
+        MemoryAPI::free_device_array(w_in);
+    }
+    std::vector<_T> outgoing_to_host() const
+    {
+        std::vector<_T> h((size_t)edges_count);
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h.data(), edges_data, sizeof(_T) * h.size()));
+        return h;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// VGL_Frontier (frontier.h:13-54 / base_frontier.h:5-62)
+// ------------------------------------------------------------------------------------------------------------------
+class VGL_Frontier {
+    vgl_hip_frontier *handle = nullptr; VGL_Graph *graph_ptr; TraversalDirection direction;
+public:
+    VGL_Frontier(VGL_Graph &g, TraversalDirection d = SCATTER) : graph_ptr(&g), direction(d)
+    { VGL_HIP_CALL(vgl_hip_frontier_create(VGL_RUNTIME::ctx(), g.get_handle(), &handle)); }
+    ~VGL_Frontier() { if (handle) vgl_hip_frontier_destroy(VGL_RUNTIME::ctx(), handle); }
+    VGL_Frontier(const VGL_Frontier &) = delete;
+    vgl_hip_frontier *get_handle() const { return handle; }
+    void set_all_active() { VGL_HIP_CALL(vgl_hip_frontier_set_all_active(VGL_RUNTIME::ctx(), handle)); }
+    void clear() { VGL_HIP_CALL(vgl_hip_frontier_clear(VGL_RUNTIME::ctx(), handle)); }
+    void add_vertex(int v) { VGL_HIP_CALL(vgl_hip_frontier_add_vertex(VGL_RUNTIME::ctx(), handle, v)); }
+    int size() const { int32_t s; VGL_HIP_CALL(vgl_hip_frontier_info(VGL_RUNTIME::ctx(), handle, &s, nullptr, nullptr)); return s; }
+    long long get_neighbours_count() const { int64_t n; VGL_HIP_CALL(vgl_hip_frontier_info(VGL_RUNTIME::ctx(), handle, nullptr, &n, nullptr)); return n; }
+    FrontierSparsityType get_sparsity_type() const { int t; VGL_HIP_CALL(vgl_hip_frontier_info(VGL_RUNTIME::ctx(), handle, nullptr, nullptr, &t)); return (FrontierSparsityType)t; }
+    int *get_ids() const { return vgl_hip_frontier_ids(handle); }        // device
+    int *get_flags() const { return vgl_hip_frontier_flags(handle); }    // device
+    TraversalDirection get_direction() const { return direction; }
+    void set_direction(TraversalDirection d) { direction = d; }
+    void reorder(TraversalDirection) {}
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// templated kernels calling user operators
+// ------------------------------------------------------------------------------------------------------------------
+// advance over ALL edges of a direction (ALL_ACTIVE) or over the rows flagged in a DENSE frontier: static edge tiles
+template <bool DENSE, class EdgeOp>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_static(const long long *rowptr, const int *adj, const int32_t *tile_row,
+                                                                  long long E, long long process_shift, const int *flags, EdgeOp edge_op)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, (int64_t)E - e0);
+    const int r_first = tile_row[blockIdx.x];
+    const int r_last = tile_row[blockIdx.x + 1];
+    vgl_tile_row_map(s_map, s_w, (const int64_t *)rowptr, e0, r_first, r_last);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;
+        if (i < n) {
+            const int src = r_first + s_map[i];
+            if (!DENSE || flags[src] > 0) {
+                const long long e = e0 + i;
+                edge_op(src, adj[e], (int)(e - rowptr[src]), process_shift + e, (int)(threadIdx.x & 63));
+            }
+        }
+    }
+}
+// advance over a SPARSE frontier: tiles of the frontier's own edge list (plan = offs + tile_first)
+template <class EdgeOp>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_sparse(const int *ids, const int64_t *offs, const int32_t *tile_first, int F,
+                                                                  long long M, const long long *rowptr, const int *adj,
+                                                                  long long process_shift, EdgeOp edge_op)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, (int64_t)M - e0);
+    const int p_first = tile_first[blockIdx.x];
+    const int p_last = (e0 + VGL_TILE < M) ? tile_first[blockIdx.x + 1] : F - 1;
+    vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;
+        if (i < n) {
+            const int p = p_first + s_map[i];
+            const int src = ids[p];
+            const int local = (int)(e0 + i - offs[p]);
+            const long long e = rowptr[src] + local;
+            edge_op(src, adj[e], local, process_shift + e, (int)(threadIdx.x & 63));
+        }
+    }
+}
+// per-vertex operator over all vertices / flagged vertices / listed vertices (compute_worker, multicore/compute.hpp:6-58)
+template <int MODE, class Op>     // 0 all-active, 1 dense (flags), 2 sparse (ids)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_vertex_op(int n, const long long *rowptr, const int *flags, const int *ids, Op op)
+{
+    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
+        if (MODE == 1 && flags[i] <= 0) continue;
+        const int src = (MODE == 2) ? ids[i] : i;
+        op(src, (int)(rowptr[src + 1] - rowptr[src]), (int)(threadIdx.x & 63));
+    }
+}
+template <int MODE, class Op>     // reduce_op values materialised as doubles (exact for int / float operands)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_reduce_values(int n, const long long *rowptr, const int *flags, const int *ids, Op op, double *out)
+{
+    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
+        double v = 0.0;
+        if (!(MODE == 1 && flags[i] <= 0)) {
+            const int src = (MODE == 2) ? ids[i] : i;
+            v = (double)op(src, (int)(rowptr[src + 1] - rowptr[src]), (int)(threadIdx.x & 63));
+        }
+        out[i] = v;
+    }
+}
+template <class Cond>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_filter_flags(int n, const long long *rowptr, Cond cond, int *flags)
+{
+    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK)
+        flags[i] = cond(i, (int)(rowptr[i + 1] - rowptr[i])) > 0 ? 1 : 0;
+}
+
+struct vgl_empty_vertex_op { __device__ void operator()(int, int, int) const {} };
+struct vgl_empty_edge_op { __device__ void operator()(int, int, int, long long, int) const {} };
+static const vgl_empty_vertex_op EMPTY_VERTEX_OP;
+static const vgl_empty_edge_op EMPTY_EDGE_OP;
+
+// ------------------------------------------------------------------------------------------------------------------
+// GraphAbstractionsHIP: public member list of graph_abstractions_template.h:44-104
+// ------------------------------------------------------------------------------------------------------------------
+class GraphAbstractionsHIP {
+    VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
+    double *reduce_buffer = nullptr;
+
+    static unsigned grid_for(long long n) { long long b = (n + VGL_BLOCK - 1) / VGL_BLOCK; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+    template <class T> static constexpr bool is_empty_vertex_op() { return std::is_same<typename std::decay<T>::type, vgl_empty_vertex_op>::value; }
+
+    void set_correct_direction() {}
+    template <typename _T, typename... Types>
+    void set_correct_direction(_T &first, Types &...rest) { first.set_direction(current_traversal_direction); first.reorder(current_traversal_direction); set_correct_direction(rest...); }
+
+    template <class Op>
+    void vertex_pass(VGL_Graph &g, VGL_Frontier &f, TraversalDirection dir, Op &&op)
+    {
+        const vgl_csr_view v = g.get_direction_view(dir);
+        const FrontierSparsityType t = f.get_sparsity_type();
+        hipStream_t st = VGL_RUNTIME::stream();
+        const int V = g.get_vertices_count();
+        if (t == ALL_ACTIVE_FRONTIER) hipLaunchKernelGGL((vgl_k_vertex_op<0, typename std::decay<Op>::type>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), op);
+        else if (t == DENSE_FRONTIER) hipLaunchKernelGGL((vgl_k_vertex_op<1, typename std::decay<Op>::type>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), op);
+        else if (f.size() > 0) hipLaunchKernelGGL((vgl_k_vertex_op<2, typename std::decay<Op>::type>), dim3(grid_for(f.size())), dim3(VGL_BLOCK), 0, st, f.size(), v.rowptr, f.get_flags(), f.get_ids(), op);
+        VGL_HIP_RT(hipGetLastError());
+    }
+
+    // advance_worker: pre (per vertex) -> edge_op over every edge of the active vertices -> post (per vertex).
+    // Kernel boundaries give the per-vertex ordering the reference guarantees (advance_worker.hpp:79-99).
+    template <class EdgeOp, class PreOp, class PostOp>
+    void advance_worker(VGL_Graph &g, VGL_Frontier &f, TraversalDirection dir, EdgeOp &&edge_op, PreOp &&pre_op, PostOp &&post_op)
+    {
+        vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+        hipStream_t st = VGL_RUNTIME::stream();
+        const vgl_csr_view v = g.get_direction_view(dir);
+        const long long process_shift = (dir == GATHER) ? g.get_edges_count() : 0;     // compute_process_shift (graph_abstractions.hpp:19-28)
+        if (!is_empty_vertex_op<PreOp>()) vertex_pass(g, f, dir, pre_op);
+        const FrontierSparsityType t = f.get_sparsity_type();
+        using E = typename std::decay<EdgeOp>::type;
+        if (t == SPARSE_FRONTIER) {
+            const int64_t *offs; const int32_t *tile_first; int64_t M;
+            VGL_HIP_CALL(vgl_hip_frontier_advance_plan(c, g.get_handle(), f.get_handle(), dir == GATHER, &offs, &tile_first, &M));
+            if (M > 0) {
+                const unsigned nt = (unsigned)((M + VGL_TILE - 1) / VGL_TILE);
+                hipLaunchKernelGGL((vgl_k_advance_sparse<E>), dim3(nt), dim3(VGL_BLOCK), 0, st, f.get_ids(), offs, tile_first, f.size(), (long long)M,
+                                   v.rowptr, v.adj, process_shift, edge_op);
+            }
+        } else if (v.edges > 0) {
+            const int32_t *tile_row; int64_t ntiles;
+            VGL_HIP_CALL(vgl_hip_graph_tile_rows(g.get_handle(), dir == GATHER, &tile_row, &ntiles));
+            if (t == DENSE_FRONTIER)
+                hipLaunchKernelGGL((vgl_k_advance_static<true, E>), dim3((unsigned)ntiles), dim3(VGL_BLOCK), 0, st, v.rowptr, v.adj, tile_row, v.edges, process_shift, f.get_flags(), edge_op);
+            else
+                hipLaunchKernelGGL((vgl_k_advance_static<false, E>), dim3((unsigned)ntiles), dim3(VGL_BLOCK), 0, st, v.rowptr, v.adj, tile_row, v.edges, process_shift, f.get_flags(), edge_op);
+        }
+        VGL_HIP_RT(hipGetLastError());
+        if (!is_empty_vertex_op<PostOp>()) vertex_pass(g, f, dir, post_op);
+        VGL_RUNTIME::sync();                 // primitives are synchronous, like the reference GPU backend (advance_csr.hpp:204)
+    }
+
+public:
+    GraphAbstractionsHIP(VGL_Graph &g, TraversalDirection initial = SCATTER) : processed_graph_ptr(&g), current_traversal_direction(initial)
+    { MemoryAPI::allocate_device_array(&reduce_buffer, (size_t)g.get_vertices_count()); }
+    ~GraphAbstractionsHIP() { MemoryAPI::free_device_array(reduce_buffer); }
+
+    // change_traversal_direction (graph_abstractions.hpp:87-125): tags and permutes every passed container; with identity
+    // numbering only the tag changes
+    template <typename... Types>
+    void change_traversal_direction(TraversalDirection d, Types &...args) { current_traversal_direction = d; set_correct_direction(args...); }
+
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation,
+              typename CollectiveEdgeOperation, typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+    void scatter(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op, VertexPreprocessOperation &&pre, VertexPostprocessOperation &&post,
+                 CollectiveEdgeOperation &&, CollectiveVertexPreprocessOperation &&, CollectiveVertexPostprocessOperation &&)
+    {
+        if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";   // common/advance.hpp:19-26
+        advance_worker(g, f, SCATTER, edge_op, pre, post);
+    }
+    template <typename EdgeOperation>
+    void scatter(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op)
+    {
+        if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";
+        advance_worker(g, f, SCATTER, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP);
+    }
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation,
+              typename CollectiveEdgeOperation, typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+    void gather(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op, VertexPreprocessOperation &&pre, VertexPostprocessOperation &&post,
+                CollectiveEdgeOperation &&, CollectiveVertexPreprocessOperation &&, CollectiveVertexPostprocessOperation &&)
+    {
+        if (current_traversal_direction != GATHER) throw "VGL ERROR: incorrect traversal direction in gather";
+        advance_worker(g, f, GATHER, edge_op, pre, post);
+    }
+    template <typename EdgeOperation>
+    void gather(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op)
+    {
+        if (current_traversal_direction != GATHER) throw "VGL ERROR: incorrect traversal direction in gather";
+        advance_worker(g, f, GATHER, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP);
+    }
+
+    template <typename ComputeOperation>
+    void compute(VGL_Graph &g, VGL_Frontier &f, ComputeOperation &&compute_op)
+    {
+        vertex_pass(g, f, current_traversal_direction, compute_op);
+        VGL_RUNTIME::sync();
+    }
+
+    template <typename _T, typename ReduceOperation>
+    _T reduce(VGL_Graph &g, VGL_Frontier &f, ReduceOperation &&reduce_op, REDUCE_TYPE type)
+    {
+        if (type != REDUCE_SUM) throw "VGL ERROR: only REDUCE_SUM is implemented (as in the reference, multicore/reduce.hpp:88-121)";
+        const vgl_csr_view v = g.get_direction_view(current_traversal_direction);
+        const FrontierSparsityType t = f.get_sparsity_type();
+        hipStream_t st = VGL_RUNTIME::stream();
+        using R = typename std::decay<ReduceOperation>::type;
+        const int V = g.get_vertices_count();
+        int n = V;
+        if (t == ALL_ACTIVE_FRONTIER) hipLaunchKernelGGL((vgl_k_reduce_values<0, R>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_buffer);
+        else if (t == DENSE_FRONTIER) hipLaunchKernelGGL((vgl_k_reduce_values<1, R>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_buffer);
+        else { n = f.size(); if (n > 0) hipLaunchKernelGGL((vgl_k_reduce_values<2, R>), dim3(grid_for(n)), dim3(VGL_BLOCK), 0, st, n, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_buffer); }
+        VGL_HIP_RT(hipGetLastError());
+        double r = 0.0;
+        VGL_HIP_CALL(vgl_hip_reduce_sum_f64_buffer(VGL_RUNTIME::ctx(), n, reduce_buffer, &r));
+        return (_T)r;
+    }
+
+    template <typename FilterCondition>
+    void generate_new_frontier(VGL_Graph &g, VGL_Frontier &f, FilterCondition &&filter_cond)
+    {
+        const vgl_csr_view v = g.get_direction_view(current_traversal_direction);
+        using C = typename std::decay<FilterCondition>::type;
+        const int V = g.get_vertices_count();
+        hipLaunchKernelGGL((vgl_k_filter_flags<C>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), V, v.rowptr, filter_cond, f.get_flags());
+        VGL_HIP_RT(hipGetLastError());
+        f.set_direction(current_traversal_direction);
+        VGL_HIP_CALL(vgl_hip_gnf_from_flags(VGL_RUNTIME::ctx(), g.get_handle(), f.get_flags(), 0.0, f.get_handle()));
+    }
+
+    void enable_safe_stores() {}         // no-op off NEC (graph_abstractions_multicore.h:295-296)
+    void disable_safe_stores() {}
+};

@@ -65,6 +65,9 @@ _SIGNATURES = {
     "vgl_hip_frontier_info": [_p, _p, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_int)],
     "vgl_hip_gnf_from_flags": [_p, _p, _p, _dbl, _p],
     "vgl_hip_gnf_equal_i32": [_p, _p, _p, _i32, _dbl, _p],
+    "vgl_hip_graph_tile_rows": [_p, _int, _pp, C.POINTER(_i64)],
+    "vgl_hip_frontier_advance_plan": [_p, _p, _p, _int, _pp, _pp, C.POINTER(_i64)],
+    "vgl_hip_reduce_sum_f64_buffer": [_p, _i64, _p, C.POINTER(_dbl)],
     "vgl_hip_reduce_sum_i32": [_p, _p, _p, C.POINTER(_i64)],
     "vgl_hip_reduce_sum_f32": [_p, _p, _p, C.POINTER(_dbl)],
     "vgl_hip_count_not_equal_u32": [_p, _i32, _p, _p, C.POINTER(_i64)],
