@@ -1,0 +1,163 @@
+"""CPU test (gloo, world_size 2) of the multi-GPU super-step drivers in vectorgraphlibrary_amd/distributed.py: the
+edge-cut partition, the per-step exchange (bitmap all-gather / min all-reduce / owned-slice sum) and the termination
+logic.  The per-shard kernels are replaced by a numpy test double defined HERE (no GPU code can run in this container);
+the HIP kernels behind the same `ops` interface are covered by tests/test_gpu_parity.py::test_sharded_super_steps_single_process."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+FLT_MAX = np.float32(3.4028234663852886e38)
+
+
+class NumpyShardOps:
+    """numpy stand-in for HipShardOps over the rows [lo,hi) of a host CSR (test double, not product code)."""
+
+    def __init__(self, V, rowptr, adj, w, lo, hi):
+        self.V, self.rowptr, self.adj, self.w, self.lo, self.hi = V, rowptr, adj, w, lo, hi
+        self.src = np.repeat(np.arange(V, dtype=np.int64), np.diff(rowptr))
+        e0, e1 = rowptr[lo], rowptr[hi]
+        self.es, self.ed = self.src[e0:e1], adj[e0:e1].astype(np.int64)
+        self.ew = w[e0:e1] if w is not None else None
+
+    def new_i32(self): return torch.empty(self.V, dtype=torch.int32)
+    def new_f32(self): return torch.empty(self.V, dtype=torch.float32)
+    def new_words(self, parts): return torch.empty(parts * ((self.V + 63) // 64), dtype=torch.int64)
+    def scalar(self, v): return torch.tensor(v, dtype=torch.int64)
+    def sync(self): pass
+
+    def bfs_init(self, levels, source):
+        levels.fill_(-1); levels[source] = 1
+
+    def bfs_step(self, levels, level):
+        lv = levels.numpy()
+        m = lv[self.es] == level
+        tgt = self.ed[m]
+        tgt = tgt[lv[tgt] == -1]
+        lv[tgt] = level + 1
+        return int(((lv[self.lo:self.hi]) == level).sum()), int(m.sum())
+
+    def levels_to_bitmap(self, levels, level, bits):
+        b = np.zeros(((self.V + 63) // 64) * 64, np.uint8)
+        b[:self.V] = levels.numpy() == level
+        bits.numpy().view(np.uint8)[:] = np.packbits(b, bitorder="little")
+
+    def apply_bitmaps(self, parts, bits_all, levels, level):
+        words = (self.V + 63) // 64
+        w = bits_all.numpy().reshape(parts, words)
+        merged = np.bitwise_or.reduce(w, axis=0)
+        on = np.unpackbits(merged.view(np.uint8), bitorder="little")[:self.V].astype(bool)
+        lv = levels.numpy()
+        lv[on & (lv == -1)] = level
+        return int((lv == level).sum())
+
+    def sssp_init(self, d, source):
+        d.fill_(float(FLT_MAX)); d[source] = 0
+
+    def sssp_relax(self, d):
+        dv = d.numpy()
+        live = dv[self.es] < FLT_MAX
+        cand = (dv[self.es][live] + self.ew[live]).astype(np.float32)
+        before = dv.copy()
+        np.minimum.at(dv, self.ed[live], cand)
+        return int((before != dv).any())
+
+    def cc_init(self, comp): comp.copy_(torch.arange(self.V, dtype=torch.int32))
+
+    def cc_hook(self, comp):
+        c = comp.numpy()
+        before = c.copy()
+        np.minimum.at(c, self.ed, c[self.es])
+        return int((before != c).any())
+
+    def cc_jump(self, comp):
+        c = comp.numpy()
+        while True:
+            n = c[c]
+            if (n == c).all():
+                break
+            c[:] = n
+
+    def indeg_add(self, indeg):
+        m = self.es != self.ed
+        np.add.at(indeg.numpy(), self.ed[m], 1)
+
+    def pr_setup(self, indeg, ranks, rdeg):
+        ranks.fill_(float(np.float32(1.0 / self.V)))
+        dg = indeg.numpy()
+        rdeg.numpy()[:] = np.where(dg == 0, np.float32(0), (1.0 / np.maximum(dg, 1)).astype(np.float32))
+
+    def pr_iteration(self, indeg, rdeg, ranks, contrib):
+        V = self.V
+        old = ranks.numpy().copy()
+        c = (old * rdeg.numpy()).astype(np.float32)
+        dang = np.float32((old[indeg.numpy() == 0] / np.float32(V)).astype(np.float64).sum())
+        d, k = np.float32(0.85), np.float32((1.0 - float(np.float32(0.85))) / float(np.float32(V)))
+        out = ranks.numpy()
+        for u in range(self.lo, self.hi):                 # f32 adjacency-order sums, like the kernel
+            acc = np.float32(0)
+            for p in range(self.rowptr[u], self.rowptr[u + 1]):
+                v = self.adj[p]
+                if v != u:
+                    acc = np.float32(acc + c[v])
+            out[u] = np.float32(k + np.float32(d * np.float32(acc + dang)))
+
+
+def _worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from vectorgraphlibrary_amd import distributed as vd
+    scale, ef, seed = 9, 8, 13
+    V = 1 << scale
+    src, dst = O.gen_rmat(scale, ef, seed)
+    rowptr, adj, perm = O.coo_to_csr(V, src, dst)
+    w = O.gen_weights(len(src), seed)[perm]
+    # edge-balanced cut rounded to multiples of 64 (same rule as vgl_hip_partition_rows)
+    bounds = [0]
+    for p in range(1, world):
+        b = int(np.searchsorted(rowptr, len(adj) * p // world))
+        bounds.append(min(V, max(bounds[-1], (b + 32) // 64 * 64)))
+    bounds.append(V)
+    ops = NumpyShardOps(V, rowptr, adj, w, bounds[rank], bounds[rank + 1])
+    source = O.pick_source(rowptr, seed)
+    levels, _ = vd.bfs_sharded(ops, source)
+    d, _ = vd.sssp_sharded(ops, source)
+    comp, _ = vd.cc_sharded(ops)
+    ranks = vd.page_rank_sharded(ops, 3, bounds[rank], bounds[rank + 1])
+    ok = [(levels.numpy() == O.bfs_top_down(rowptr, adj, source)[0]).all(),
+          (d.numpy().view(np.int32) == O.sssp_bellman_ford(rowptr, adj, w, source)[0].view(np.int32)).all(),
+          (comp.numpy() == O.cc_sv(rowptr, adj)[0]).all(),
+          (ranks.numpy().view(np.int32) == O.pagerank(rowptr, adj, 3, 1).view(np.int32)).all()]
+    results[rank] = [bool(x) for x in ok]
+    dist.destroy_process_group()
+
+
+def test_sharded_drivers_gloo_world2():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+    assert len(results) == world
+    for r in range(world):
+        assert results[r] == [True, True, True, True], f"rank {r}: bfs/sssp/cc/pr = {results[r]}"
+
+
+def test_single_process_driver_without_process_group(oracle):
+    O = oracle
+    from vectorgraphlibrary_amd import distributed as vd
+    V = 256
+    src, dst = O.gen_uniform(8, 4, 3)
+    rowptr, adj, perm = O.coo_to_csr(V, src, dst)
+    ops = NumpyShardOps(V, rowptr, adj, O.gen_weights(len(src), 3)[perm], 0, V)
+    source = O.pick_source(rowptr, 3)
+    assert (vd.bfs_sharded(ops, source)[0].numpy() == O.bfs_top_down(rowptr, adj, source)[0]).all()
+    assert (vd.cc_sharded(ops)[0].numpy() == O.cc_sv(rowptr, adj)[0]).all()
