@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sssp", action="store_true")
     ap.add_argument("--cpu-sources", type=int, default=3)
+    ap.add_argument("--renumber", default="total", choices=["none", "out", "in", "total"],
+                    help="VectCSR-style degree renumbering of the stored graph (vect_csr/import.hpp:61-99)")
     args = ap.parse_args()
 
     import torch
@@ -63,10 +65,13 @@ def main():
     V, E = 1 << scale, (1 << scale) * ef
     t_build = time.time()
     src, dst = ctx.gen_rmat(scale, ef, seed)
-    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True, want_perm=not args.no_sssp)
+    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True, want_perm=not args.no_sssp,
+                           renumber=None if args.renumber == "none" else args.renumber)
     del src, dst
     ctx.sync()
     t_build = time.time() - t_build
+    # sources are ids of the stored (renumbered) graph; like the reference, conversions to/from ORIGINAL ids happen outside
+    # the timed region (bfs.hpp:62-85), so the timed calls use raw=True
     sources = pick_sources(g.out_rowptr, args.steps + args.warmup, seed)
 
     def barrier():
@@ -79,13 +84,13 @@ def main():
     cpu_baseline = None
     if world == 1:
         for s in sources[:args.warmup]:
-            api.bfs(g, s, api.BFS_DIRECTION_OPT)
+            api.bfs(g, s, api.BFS_DIRECTION_OPT, raw=True)
         ctx.timing(True)
         barrier()
         t0 = time.perf_counter()
         stats = []
         for s in sources[args.warmup:]:
-            stats.append(api.bfs(g, s, api.BFS_DIRECTION_OPT)[1])
+            stats.append(api.bfs(g, s, api.BFS_DIRECTION_OPT, raw=True)[1])
         barrier()
         dt = time.perf_counter() - t0
         # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----
@@ -125,7 +130,7 @@ def main():
                         "whole_bfs_frac_of_hbm_peak": round(total_alg / dt / 1e9 / HBM_PEAK_GBS, 5)}
         # reference algorithm (pure top-down, bfs.hpp:6-51) for comparison
         t1 = time.perf_counter()
-        td_stats = [api.bfs(g, s, api.BFS_TOP_DOWN)[1] for s in sources[args.warmup:args.warmup + 4]]
+        td_stats = [api.bfs(g, s, api.BFS_TOP_DOWN, raw=True)[1] for s in sources[args.warmup:args.warmup + 4]]
         torch.cuda.synchronize()
         dt_td = (time.perf_counter() - t1) / len(td_stats)
         extra["bfs_top_down_reference_algorithm"] = {
@@ -137,11 +142,11 @@ def main():
             w = ctx.gather_u32(g.perm, ctx.gen_weights(E, seed))
             res = {}
             for mode, name in ((api.SSSP_ACTIVE_TILES, "active_tiles"), (api.SSSP_ALL_ACTIVE, "all_active")):
-                api.sssp(g, w, sources[0], mode)
+                api.sssp(g, w, sources[0], mode, raw=True)
                 ctx.timing(True)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                sst = [api.sssp(g, w, s, mode)[1] for s in sources[args.warmup:args.warmup + 3]]
+                sst = [api.sssp(g, w, s, mode, raw=True)[1] for s in sources[args.warmup:args.warmup + 3]]
                 torch.cuda.synchronize()
                 dts = (time.perf_counter() - t1) / len(sst)
                 n, ms = ctx.timing_get("sssp_relax")
@@ -199,6 +204,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload, "vertices": V, "edges": E, "seed": seed, "parallelism": f"edge-cut x{world}",
+                       "vertex_numbering": "identity" if args.renumber == "none" else f"degree-sorted ({args.renumber})",
                        "graph_build_s": round(t_build, 2)},
         }
         if roofline:

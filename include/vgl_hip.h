@@ -66,6 +66,22 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *ctx, int32_t V, int64_t count, const int32_t
 /* out[i] = in[perm[i]] for 4-byte elements (EdgesArray weights follow the CSR order,
  * csr_edges_array.hpp:31-40) */
 int vgl_hip_gather_u32(vgl_hip_ctx *ctx, int64_t n, const int64_t *d_perm, const void *d_in, void *d_out);
+/* VectCSR-style vertex renumbering (VectorCSRGraph::import, vect_csr/import.hpp:61-99): sorted position =
+ * (degree descending, original id ascending).  degree_kind 0 = out-degree, 1 = in-degree, 2 = in+out.  The reference
+ * renumbers each direction separately; this backend keeps ONE numbering for both directions so that top-down and
+ * bottom-up steps share vertex arrays.  d_fwd[orig] = sorted id, d_bwd[sorted] = orig id (forward/backward_conversion).
+ * Hot (high-degree) vertices become contiguous, so the per-edge 4-byte gathers of dist/levels/labels/contrib[dst]
+ * mostly hit the XCD L2 instead of costing a fabric line each.  Synchronises. */
+int vgl_hip_degree_order(vgl_hip_ctx *ctx, int32_t V, int64_t count, const int32_t *d_src, const int32_t *d_dst,
+                         int degree_kind, int32_t *d_fwd, int32_t *d_bwd);
+/* out[i] = map[in[i]] (relabel ids) and out[i] = in[idx[i]] (permute a vertex array) for 4-byte elements */
+int vgl_hip_relabel_i32(vgl_hip_ctx *ctx, int64_t n, const int32_t *d_map, const int32_t *d_in, int32_t *d_out);
+int vgl_hip_permute_u32(vgl_hip_ctx *ctx, int64_t n, const int32_t *d_idx, const void *d_in, void *d_out);
+/* CC labels computed on a renumbered graph -> labels in ORIGINAL ids: out[orig v] = min original id of v's component.
+ * d_comp: labels in sorted numbering (int32[V]); d_scratch: int32[V]. */
+int vgl_hip_cc_labels_to_original(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_comp, const int32_t *d_fwd,
+                                  const int32_t *d_bwd, int32_t *d_scratch, int32_t *d_out);
+
 /* edge-balanced contiguous vertex ranges (VectorCSRGraph::get_mpi_thresholds, vect_csr/get_api.hpp:66-94):
  * bounds[p] .. bounds[p+1] own ~E/parts edges each.  Host array of parts+1 entries.  Synchronises. */
 int vgl_hip_partition_rows(vgl_hip_ctx *ctx, int32_t V, const int64_t *d_rowptr, int parts, int32_t *bounds_host);

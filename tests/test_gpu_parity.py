@@ -354,3 +354,40 @@ def test_large_scale_properties(kind, scale, ctx):
     ranks, st = api.page_rank(g, 3)
     assert bool((ranks > 0).all()) and abs(st["ranks_sum"] - float(ranks.double().sum())) < 1e-9
     g.close()
+
+
+@pytest.mark.parametrize("kind", ["out", "in", "total"])
+@pytest.mark.parametrize("case", ["rmat_s12_e16_seed3", "ru_s12_e16_seed5"])
+def test_degree_renumbered_graph(kind, case, ctx, oracle):
+    """VectCSR-style renumbering (vect_csr/import.hpp:61-99): order = (degree desc, id asc) as the oracle's
+    vgo_degree_renumber; all four algorithms on the renumbered graph give the ORIGINAL-numbering results of the goldens."""
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", case + ".npz"))
+    gk, scale, ef, seed = str(z["kind"]), int(z["scale"]), int(z["edge_factor"]), int(z["seed"])
+    V = 1 << scale
+    src, dst = (ctx.gen_rmat if gk == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    hs, hd = (O.gen_rmat if gk == "rmat" else O.gen_uniform)(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True, renumber=kind)
+    # the order itself, against the oracle's restatement of the reference rule
+    deg_src = {"out": hs, "in": hd, "total": np.concatenate([hs, hd])}[kind]
+    fake_rowptr = np.concatenate([[0], np.cumsum(np.bincount(deg_src, minlength=V))]).astype(np.int64)
+    fwd, bwd = O.degree_renumber(fake_rowptr)
+    assert (g.fwd.cpu().numpy() == fwd).all() and (g.bwd.cpu().numpy() == bwd).all()
+    rowptr, adj, perm = O.coo_to_csr(V, fwd[hs], fwd[hd])
+    assert (g.out_adj.cpu().numpy() == adj).all() and (g.out_rowptr.cpu().numpy() == rowptr).all()
+    source = int(z["source"])
+    for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+        assert (api.bfs(g, source, mode)[0].cpu().numpy() == z["levels"]).all()
+    w = ctx.gather_u32(g.perm, ctx.gen_weights(len(hs), seed))
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+        assert (api.sssp(g, w, source, mode)[0].cpu().numpy().view(np.int32) == z["dist"].view(np.int32)).all()
+    rk = api.page_rank(g, int(z["pr_iters"]))[0].cpu().numpy()
+    ref = O.pagerank(*O.coo_to_csr(V, hs, hd)[:2], int(z["pr_iters"]), 1)
+    assert relerr(rk, ref) <= PR_RTOL
+    g.close()
+    s2, d2 = torch.cat([src, dst]), torch.cat([dst, src])
+    gs = api.Graph.from_coo(ctx, V, s2, d2, renumber=kind)
+    assert (api.connected_components(gs)[0].cpu().numpy() == z["comp_csr"]).all()
+    gs.close()

@@ -96,6 +96,24 @@ class Context:
         _l.check(self.L.vgl_hip_gather_u32(self.h, perm.numel(), _ptr(perm), _ptr(values), _ptr(out)))
         return out
 
+    def degree_order(self, V, src, dst, kind="total"):
+        """VectCSR-style renumbering: fwd[orig] = sorted id, bwd[sorted] = orig (degree descending, id ascending)."""
+        fwd, bwd = self.empty(V, torch.int32), self.empty(V, torch.int32)
+        k = {"out": 0, "in": 1, "total": 2}[kind]
+        _l.check(self.L.vgl_hip_degree_order(self.h, V, src.numel(), _ptr(src), _ptr(dst), k, _ptr(fwd), _ptr(bwd)))
+        return fwd, bwd
+
+    def relabel(self, mapping, ids):
+        out = torch.empty_like(ids)
+        _l.check(self.L.vgl_hip_relabel_i32(self.h, ids.numel(), _ptr(mapping), _ptr(ids), _ptr(out)))
+        return out
+
+    def permute(self, idx, values):
+        """out[i] = values[idx[i]] for a 4-byte vertex array"""
+        out = torch.empty_like(values)
+        _l.check(self.L.vgl_hip_permute_u32(self.h, values.numel(), _ptr(idx), _ptr(values), _ptr(out)))
+        return out
+
     def partition_rows(self, rowptr, parts):
         V = rowptr.numel() - 1
         bounds = (C.c_int32 * (parts + 1))()
@@ -111,6 +129,8 @@ class Graph:
         self.row_begin, self.row_end = int(row_begin), int(V if row_end is None else row_end)
         self.out_rowptr, self.out_adj, self.in_rowptr, self.in_adj = out_rowptr, out_adj, in_rowptr, in_adj
         self.E = int(out_adj.numel())
+        self.fwd = self.bwd = None            # set by from_coo(renumber=...): original <-> sorted vertex ids
+        self.perm = None
         h = C.c_void_p()
         _l.check(ctx.L.vgl_hip_graph_create(ctx.h, self.V, self.row_begin, self.row_end, _ptr(out_rowptr), _ptr(out_adj), self.E,
                                             _ptr(in_rowptr), _ptr(in_adj), int(in_adj.numel()) if in_adj is not None else 0,
@@ -118,9 +138,15 @@ class Graph:
         self.h = h
 
     @classmethod
-    def from_coo(cls, ctx, V, src, dst, with_incoming=True, want_perm=False):
+    def from_coo(cls, ctx, V, src, dst, with_incoming=True, want_perm=False, renumber=None):
         """VGL_Graph::import (vgl_graph.hpp:57-68): outgoing CSR from (src,dst), incoming CSR from the OUT-CSR-ordered
-        transposed list (the container is sorted in place by the outgoing import before it is transposed)."""
+        transposed list (the container is sorted in place by the outgoing import before it is transposed).
+        renumber in {None, "out", "in", "total"}: VectCSR-style degree renumbering of the vertices before the build
+        (vect_csr/import.hpp:61-99); vertex arrays of such a graph live in the sorted numbering (see to_original)."""
+        fwd = bwd = None
+        if renumber:
+            fwd, bwd = ctx.degree_order(V, src, dst, renumber)
+            src, dst = ctx.relabel(fwd, src), ctx.relabel(fwd, dst)
         rowptr, adj, perm = ctx.coo_to_csr(V, src, dst, want_perm=want_perm)
         in_rowptr = in_adj = None
         if with_incoming:
@@ -129,8 +155,16 @@ class Graph:
             in_rowptr, in_adj, _ = ctx.coo_to_csr(V, adj, csr_src)
             del csr_src
         g = cls(ctx, V, rowptr, adj, in_rowptr, in_adj)
-        g.perm = perm
+        g.perm, g.fwd, g.bwd = perm, fwd, bwd
         return g
+
+    def vertex_id(self, original_id):
+        """original vertex id -> id in this graph's numbering (VGL_Graph::reorder(v, ORIGINAL, SCATTER))"""
+        return int(self.fwd[original_id]) if self.fwd is not None else int(original_id)
+
+    def to_original(self, values):
+        """vertex array in this graph's numbering -> ORIGINAL numbering (VerticesArray::reorder(ORIGINAL))"""
+        return self.ctx.permute(self.fwd, values) if self.fwd is not None else values
 
     def shard(self, row_begin, row_end):
         """edge-cut shard owning rows [row_begin,row_end) of both directions (own, aligned copies of the slices)."""
@@ -141,7 +175,9 @@ class Graph:
             return (rowptr[row_begin:row_end + 1] - lo).contiguous(), adj[lo:hi].clone()
         orp, oadj = cut(self.out_rowptr, self.out_adj)
         irp, iadj = cut(self.in_rowptr, self.in_adj)
-        return Graph(self.ctx, self.V, orp, oadj, irp, iadj, row_begin, row_end)
+        s = Graph(self.ctx, self.V, orp, oadj, irp, iadj, row_begin, row_end)
+        s.fwd, s.bwd = self.fwd, self.bwd
+        return s
 
     def out_edge_range(self, row_begin, row_end):
         return int(self.out_rowptr[row_begin]), int(self.out_rowptr[row_end])
@@ -214,36 +250,48 @@ def _stats(s):
     return {k: getattr(s, k) for k, _ in s._fields_}
 
 
-def bfs(graph, source, mode=BFS_DIRECTION_OPT, levels=None):
+# The entry points below take the source in ORIGINAL vertex ids and, by default, return the result in ORIGINAL
+# numbering.  raw=True skips both conversions (source and result in the graph's own numbering): that is the timed region
+# of the reference, which reorders before tm.start() and after tm.end() (bfs.hpp:62-85, verify_results.h:33-92).
+
+def bfs(graph, source, mode=BFS_DIRECTION_OPT, levels=None, raw=False):
     ctx = graph.ctx
     levels = ctx.empty(graph.V, torch.int32) if levels is None else levels
     st = _l.BfsStats()
-    _l.check(ctx.L.vgl_hip_bfs_run(ctx.h, graph.h, int(source), mode, _ptr(levels), C.byref(st)))
-    return levels, _stats(st)
+    s = int(source) if raw else graph.vertex_id(source)
+    _l.check(ctx.L.vgl_hip_bfs_run(ctx.h, graph.h, s, mode, _ptr(levels), C.byref(st)))
+    return (levels if raw else graph.to_original(levels)), _stats(st)
 
 
-def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None):
+def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False):
     ctx = graph.ctx
     dist = ctx.empty(graph.V, torch.float32) if dist is None else dist
     st = _l.SsspStats()
-    _l.check(ctx.L.vgl_hip_sssp_run(ctx.h, graph.h, _ptr(weights), int(source), mode, _ptr(dist), C.byref(st)))
-    return dist, _stats(st)
+    s = int(source) if raw else graph.vertex_id(source)
+    _l.check(ctx.L.vgl_hip_sssp_run(ctx.h, graph.h, _ptr(weights), s, mode, _ptr(dist), C.byref(st)))
+    return (dist if raw else graph.to_original(dist)), _stats(st)
 
 
-def page_rank(graph, iterations, indeg_noloops=None, ranks=None):
+def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False):
+    """indeg_noloops (optional) is indexed in the graph's own numbering."""
     ctx = graph.ctx
     ranks = ctx.empty(graph.V, torch.float32) if ranks is None else ranks
     st = _l.PrStats()
     _l.check(ctx.L.vgl_hip_pr_run(ctx.h, graph.h, _ptr(indeg_noloops), int(iterations), _ptr(ranks), C.byref(st)))
-    return ranks, _stats(st)
+    return (ranks if raw else graph.to_original(ranks)), _stats(st)
 
 
-def connected_components(graph, comp=None):
+def connected_components(graph, comp=None, raw=False):
+    """labels = smallest ORIGINAL vertex id that reaches each vertex (raw=True: smallest id in the graph's numbering)."""
     ctx = graph.ctx
     comp = ctx.empty(graph.V, torch.int32) if comp is None else comp
     st = _l.CcStats()
     _l.check(ctx.L.vgl_hip_cc_run(ctx.h, graph.h, _ptr(comp), C.byref(st)))
-    return comp, _stats(st)
+    if raw or graph.fwd is None:
+        return comp, _stats(st)
+    out, scratch = ctx.empty(graph.V, torch.int32), ctx.empty(graph.V, torch.int32)
+    _l.check(ctx.L.vgl_hip_cc_labels_to_original(ctx.h, graph.V, _ptr(comp), _ptr(graph.fwd), _ptr(graph.bwd), _ptr(scratch), _ptr(out)))
+    return out, _stats(st)
 
 
 def count_not_equal(ctx, a, b):

@@ -30,6 +30,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_first(int32_t F, const i
         const int64_t t0 = (offs[p] + VGL_TILE - 1) / VGL_TILE;
         const int64_t t1 = (offs[p + 1] + VGL_TILE - 1) / VGL_TILE;
         for (int64_t t = t0; t < t1; t++) tile_first[t] = p;
+        // entry [#tiles] = the position that owns the LAST edge, so that trailing zero-degree frontier vertices (they sort to
+        // the end of a degree-sorted graph) are not walked by the last tile
+        if (offs[p] < offs[p + 1] && offs[p + 1] == offs[F]) tile_first[(offs[F] + VGL_TILE - 1) / VGL_TILE] = p;
     }
 }
 
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
     const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
     const int n = (int)min((int64_t)VGL_TILE, M - e0);
     const int p_first = tile_first[blockIdx.x];
-    const int p_last = (e0 + VGL_TILE < M) ? tile_first[blockIdx.x + 1] : F - 1;
+    const int p_last = tile_first[blockIdx.x + 1];      // last tile: owner of the last edge
     // per frontier position of this tile: (first adjacency index of the vertex) - (its edge offset in the frontier), staged
     // in LDS so that the per-edge path is LDS lookups + one adjacency load (falls back to global reads when a tile spans
     // more than 2048 frontier positions, i.e. thousands of zero-degree frontier vertices)
@@ -142,19 +145,39 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
     }
 }
 
-// pass 2: the deferred vertices of segment blockIdx.x, one wavefront per vertex, 64 incoming neighbours per step, early
-// exit on the first hit.  next-frontier bits are OR-ed in (different vertices of one word may be found by different waves).
+// exclusive prefix of the per-workgroup deferred counts (one workgroup, VGL_BU_BLOCKS entries -> VGL_BU_BLOCKS+1 offsets)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy_offsets(const int32_t *heavy_cnt, int32_t *heavy_off)
+{
+    __shared__ int s32[VGL_WAVES];
+    constexpr int PER = VGL_BU_BLOCKS / VGL_BLOCK;
+    int local[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { local[j] = heavy_cnt[threadIdx.x * PER + j]; sum += local[j]; }
+    int total;
+    int pre = vgl_block_excl_add(sum, s32, &total);
+#pragma unroll
+    for (int j = 0; j < PER; j++) { heavy_off[threadIdx.x * PER + j] = pre; pre += local[j]; }
+    if (threadIdx.x == 0) heavy_off[VGL_BU_BLOCKS] = total;
+}
+
+// pass 2: all deferred vertices, one wavefront per vertex, 64 incoming neighbours per step, early exit on the first hit.
+// The deferred lists are per-workgroup segments (pass 1); wavefronts stride over the CONCATENATION of the segments so the
+// work is balanced even when the deferred vertices cluster (in a degree-sorted graph they are the first ids).
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
                                                             const int32_t *in_adj, const uint64_t *front, uint64_t *next,
                                                             int32_t *levels, int32_t next_level, const int32_t *heavy,
-                                                            const int32_t *heavy_cnt, int64_t *partials)
+                                                            const int32_t *heavy_off, int64_t *partials)
 {
     __shared__ int64_t s64[VGL_WAVES];
-    const int32_t nheavy = heavy_cnt[blockIdx.x];
-    const int32_t *my_heavy = heavy + (int64_t)blockIdx.x * chunk;
+    __shared__ int s_off[VGL_BU_BLOCKS + 1];
+    for (int i = threadIdx.x; i <= VGL_BU_BLOCKS; i += VGL_BLOCK) s_off[i] = heavy_off[i];
+    __syncthreads();
+    const int total = s_off[VGL_BU_BLOCKS];
     int64_t found_cnt = 0, probes = 0;
-    for (int32_t h = vgl_wave(); h < nheavy; h += VGL_WAVES) {
-        const int32_t r = my_heavy[h];
+    for (int h = blockIdx.x * VGL_WAVES + vgl_wave(); h < total; h += gridDim.x * VGL_WAVES) {
+        int lo = 0, hi = VGL_BU_BLOCKS;                     // segment s with s_off[s] <= h < s_off[s+1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
+        const int32_t r = heavy[(int64_t)lo * chunk + (h - s_off[lo])];
         const int64_t b = in_rowptr[r] + VGL_BU_PROBES, e = in_rowptr[r + 1];
         bool hit_any = false;
         for (int64_t p = b; p < e && !hit_any; p += 64) {
@@ -327,10 +350,11 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                                    g->in.rowptr, g->in.adj, g->bm_visited, g->bm_in_nz, g->bm_front, g->bm_next, d_levels, cur + 1,
                                    g->heavy, g->heavy_cnt, g->bu_partials);
             }
+            hipLaunchKernelGGL(vgl_k_bu_heavy_offsets, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->heavy_cnt, g->heavy_off);
             {
                 vgl_timed_launch tl(c, "bfs_bottom_up_heavy");
                 hipLaunchKernelGGL(vgl_k_bu_heavy, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,
-                                   g->in.adj, g->bm_front, g->bm_next, d_levels, cur + 1, g->heavy, g->heavy_cnt, g->bu_partials);
+                                   g->in.adj, g->bm_front, g->bm_next, d_levels, cur + 1, g->heavy, g->heavy_off, g->bu_partials);
             }
             hipLaunchKernelGGL(vgl_k_bu_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->bu_partials, c->d_counters);
             hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,

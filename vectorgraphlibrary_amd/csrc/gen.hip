@@ -106,6 +106,40 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_keys(int64_t n, const int64_t
     }
 }
 
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_degree_hist(int64_t n, const int32_t *src, const int32_t *dst, int kind, uint32_t *deg)
+{
+    for (int64_t i = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * VGL_BLOCK) {
+        if (kind != 1) atomicAdd(&deg[src[i]], 1u);
+        if (kind != 0) atomicAdd(&deg[dst[i]], 1u);
+    }
+}
+// key = ~degree (ascending radix sort of the complement == descending degree; stable => original id ascending)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_order_keys(int32_t V, const uint32_t *deg, uint32_t *keys, int32_t *ids)
+{
+    for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK) { keys[v] = ~deg[v]; ids[v] = v; }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_invert(int32_t V, const int32_t *bwd, int32_t *fwd)
+{
+    for (int32_t s = blockIdx.x * VGL_BLOCK + threadIdx.x; s < V; s += gridDim.x * VGL_BLOCK) fwd[bwd[s]] = s;
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_relabel(int64_t n, const int32_t *map, const int32_t *in, int32_t *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * VGL_BLOCK) out[i] = map[in[i]];
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_permute(int64_t n, const int32_t *idx, const uint32_t *in, uint32_t *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * VGL_BLOCK) out[i] = in[idx[i]];
+}
+// scratch[label] = min original id over the component (label = sorted id of the component's root)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_min_orig(int32_t V, const int32_t *comp, const int32_t *bwd, int32_t *scratch)
+{
+    for (int32_t s = blockIdx.x * VGL_BLOCK + threadIdx.x; s < V; s += gridDim.x * VGL_BLOCK) atomicMin(&scratch[comp[s]], bwd[s]);
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_emit_orig(int32_t V, const int32_t *comp, const int32_t *fwd, const int32_t *scratch, int32_t *out)
+{
+    for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK) out[v] = scratch[comp[fwd[v]]];
+}
+
 struct vgl_in_range {
     const int32_t *src; int32_t lo, hi;
     __device__ bool operator()(const int64_t &i) const { const int32_t s = src[i]; return s >= lo && s < hi; }
@@ -221,6 +255,62 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
     if (keys) hipFree(keys);
     if (keys_sorted) hipFree(keys_sorted);
     if (sorted_idx) hipFree(sorted_idx);
+    return 0;
+}
+
+int vgl_hip_degree_order(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *d_src, const int32_t *d_dst, int degree_kind,
+                         int32_t *d_fwd, int32_t *d_bwd)
+{
+    if (!c || !d_src || !d_dst || !d_fwd || !d_bwd) VGL_FAIL("degree_order: null argument");
+    if (degree_kind < 0 || degree_kind > 2) VGL_FAIL("degree_order: degree_kind must be 0 (out), 1 (in) or 2 (in+out)");
+    hipStream_t st = c->stream;
+    uint32_t *deg = nullptr, *keys = nullptr, *keys_out = nullptr;
+    int32_t *ids = nullptr;
+    void *temp = nullptr;
+    size_t need = 0;
+    VGL_HIP_TRY(hipMalloc((void **)&deg, sizeof(uint32_t) * (size_t)V));
+    VGL_HIP_TRY(hipMalloc((void **)&keys, sizeof(uint32_t) * (size_t)V));
+    VGL_HIP_TRY(hipMalloc((void **)&keys_out, sizeof(uint32_t) * (size_t)V));
+    VGL_HIP_TRY(hipMalloc((void **)&ids, sizeof(int32_t) * (size_t)V));
+    VGL_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(uint32_t) * (size_t)V, st));
+    if (count > 0) hipLaunchKernelGGL(vgl_k_degree_hist, dim3(vgl_grid_for(count)), dim3(VGL_BLOCK), 0, st, count, d_src, d_dst, degree_kind, deg);
+    hipLaunchKernelGGL(vgl_k_order_keys, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, st, V, deg, keys, ids);
+    VGL_HIP_TRY(hipGetLastError());
+    VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys_out, ids, d_bwd, (size_t)V, 0, 32, st));
+    VGL_HIP_TRY(hipMalloc(&temp, need ? need : 16));
+    VGL_HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys, keys_out, ids, d_bwd, (size_t)V, 0, 32, st));
+    hipLaunchKernelGGL(vgl_k_invert, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, st, V, d_bwd, d_fwd);
+    VGL_HIP_TRY(hipGetLastError());
+    VGL_HIP_TRY(hipStreamSynchronize(st));
+    hipFree(temp); hipFree(deg); hipFree(keys); hipFree(keys_out); hipFree(ids);
+    return 0;
+}
+
+int vgl_hip_relabel_i32(vgl_hip_ctx *c, int64_t n, const int32_t *d_map, const int32_t *d_in, int32_t *d_out)
+{
+    if (!c || !d_map || !d_in || !d_out) VGL_FAIL("relabel_i32: null argument");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(vgl_k_relabel, dim3(vgl_grid_for(n)), dim3(VGL_BLOCK), 0, c->stream, n, d_map, d_in, d_out);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int vgl_hip_permute_u32(vgl_hip_ctx *c, int64_t n, const int32_t *d_idx, const void *d_in, void *d_out)
+{
+    if (!c || !d_idx || !d_in || !d_out) VGL_FAIL("permute_u32: null argument");
+    if (d_in == d_out) VGL_FAIL("permute_u32: in-place permutation is not supported");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(vgl_k_permute, dim3(vgl_grid_for(n)), dim3(VGL_BLOCK), 0, c->stream, n, d_idx, (const uint32_t *)d_in, (uint32_t *)d_out);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int vgl_hip_cc_labels_to_original(vgl_hip_ctx *c, int32_t V, const int32_t *d_comp, const int32_t *d_fwd, const int32_t *d_bwd,
+                                  int32_t *d_scratch, int32_t *d_out)
+{
+    if (!c || !d_comp || !d_fwd || !d_bwd || !d_scratch || !d_out) VGL_FAIL("cc_labels_to_original: null argument");
+    VGL_HIP_TRY(hipMemsetAsync(d_scratch, 0x7f, sizeof(int32_t) * (size_t)V, c->stream));      // 0x7f7f7f7f > any id
+    hipLaunchKernelGGL(vgl_k_cc_min_orig, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, c->stream, V, d_comp, d_bwd, d_scratch);
+    hipLaunchKernelGGL(vgl_k_cc_emit_orig, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, c->stream, V, d_comp, d_fwd, d_scratch, d_out);
+    VGL_HIP_TRY(hipGetLastError());
     return 0;
 }
 

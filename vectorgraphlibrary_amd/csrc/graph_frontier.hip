@@ -10,8 +10,10 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_rows(int32_t nrows, cons
         const int64_t t0 = (rowptr[r] + VGL_TILE - 1) / VGL_TILE;
         const int64_t t1 = (rowptr[r + 1] + VGL_TILE - 1) / VGL_TILE;
         for (int64_t t = t0; t < t1; t++) tile_row[t] = r;
+        // sentinel for the last tile = the row that owns the LAST edge (not nrows-1: trailing empty rows -- 45 % of a
+        // degree-sorted RMAT graph -- would otherwise all be walked by the last tile's row map)
+        if (rowptr[r] < rowptr[r + 1] && rowptr[r + 1] == rowptr[nrows]) tile_row[ntiles] = r;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) tile_row[ntiles] = nrows > 0 ? nrows - 1 : 0;
 }
 
 // bit (row_base + r) = row r is non-empty; whole words are written (row_base is a multiple of 64)
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_plan_tile_first(int32_t F, co
         const int64_t t0 = (offs[p] + VGL_TILE - 1) / VGL_TILE;
         const int64_t t1 = (offs[p + 1] + VGL_TILE - 1) / VGL_TILE;
         for (int64_t t = t0; t < t1; t++) tile_first[t] = p;
+        if (offs[p] < offs[p + 1] && offs[p + 1] == offs[F]) tile_first[(offs[F] + VGL_TILE - 1) / VGL_TILE] = p;   // owner of the last edge
     }
 }
 
@@ -180,6 +183,7 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_TRY(vgl_alloc(&g->tile_first, (size_t)g->out.ntiles + 2));
     VGL_TRY(vgl_alloc(&g->heavy, (size_t)g->nrows + 2048 * VGL_BLOCK));
     VGL_TRY(vgl_alloc(&g->heavy_cnt, (size_t)2048));
+    VGL_TRY(vgl_alloc(&g->heavy_off, (size_t)2049));
     VGL_TRY(vgl_alloc(&g->bu_partials, (size_t)2048 * 4));
     VGL_TRY(vgl_alloc(&g->epoch, (size_t)V));
     VGL_TRY(vgl_alloc(&g->fscratch, (size_t)V));
@@ -205,7 +209,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     if (!g) return 0;
     if (c) hipStreamSynchronize(c->stream);
     void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->ids, g->offs, g->vt_cnt,
-                    g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->bu_partials, g->epoch, g->fscratch, g->fscratch2,
+                    g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch};
     for (void *p : ptrs) if (p) hipFree(p);
     delete g;

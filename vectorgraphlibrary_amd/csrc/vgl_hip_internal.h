@@ -79,6 +79,7 @@ struct vgl_hip_graph {
     int32_t *tile_first = nullptr;   // out.ntiles + 2
     int32_t *heavy = nullptr;        // nrows + slack: per-workgroup segments of deferred bottom-up vertices
     int32_t *heavy_cnt = nullptr;    // one count per bottom-up workgroup
+    int32_t *heavy_off = nullptr;    // exclusive prefix of heavy_cnt (+ total)
     int64_t *bu_partials = nullptr;  // 4 partial counters per bottom-up workgroup
     int32_t *epoch = nullptr;        // V (SSSP active filter)
     float *fscratch = nullptr;       // V (PR contrib)

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_sparse(const int *ids
     const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
     const int n = (int)min((int64_t)VGL_TILE, (int64_t)M - e0);
     const int p_first = tile_first[blockIdx.x];
-    const int p_last = (e0 + VGL_TILE < M) ? tile_first[blockIdx.x + 1] : F - 1;
+    const int p_last = tile_first[blockIdx.x + 1];      // last tile: owner of the last edge (written by the plan)
     vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) {

@@ -54,6 +54,10 @@ _SIGNATURES = {
     "vgl_hip_gen_weights": [_p, _i64, _i64, _u64, _p],
     "vgl_hip_coo_to_csr": [_p, _i32, _i64, _p, _p, _i32, _i32, _p, _p, _p, C.POINTER(_i64)],
     "vgl_hip_gather_u32": [_p, _i64, _p, _p, _p],
+    "vgl_hip_degree_order": [_p, _i32, _i64, _p, _p, _int, _p, _p],
+    "vgl_hip_relabel_i32": [_p, _i64, _p, _p, _p],
+    "vgl_hip_permute_u32": [_p, _i64, _p, _p, _p],
+    "vgl_hip_cc_labels_to_original": [_p, _i32, _p, _p, _p, _p, _p],
     "vgl_hip_partition_rows": [_p, _i32, _p, _int, C.POINTER(_i32)],
     "vgl_hip_graph_create": [_p, _i32, _i32, _i32, _p, _p, _i64, _p, _p, _i64, _pp],
     "vgl_hip_graph_destroy": [_p, _p],
