@@ -19,6 +19,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+KERNEL_OF = {"bfs_bottom_up": "vgl_k_bu_probe", "bfs_top_down": "vgl_k_td_expand", "gnf": "vgl_k_gnf_count<vgl_pred_equal_i32>",
+             "sssp_relax": "vgl_k_sssp_relax<true>"}
+
+
+def pmc_traffic(timing_name):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summary (profiles/pmc_summarize.py; FETCH_SIZE and
+    WRITE_SIZE from separate passes of this same command).  Raw (FETCH+WRITE)*1024; see the summary script for the gfx950
+    half-count caveat on coalesced streams."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    rec = json.load(open(files[-1])).get(KERNEL_OF.get(timing_name, ""))
+    return rec["hbm_bytes_raw"] if rec else None
 
 
 def pick_sources(rowptr_dev, n, seed):
@@ -120,7 +134,7 @@ def main():
             per_launch_ms = kern[dom]["total_ms"] / kern[dom]["launches"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
                         "bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(per_launch_ms, 5),
                         "launches": kern[dom]["launches"]}
         total_alg = sum(s["algorithmic_bytes"] for s in stats)
