@@ -69,7 +69,7 @@ def test_algorithms_match_oracle_and_golden(path, ctx, oracle):
 
     # ---- SSSP: both schedules reach the same bit-exact fixed point ----
     ref_dist, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
-    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
         dist, st = api.sssp(g, w_d, source, mode)
         dv = dist.cpu().numpy()
         assert (dv.view(np.int32) == ref_dist.view(np.int32)).all(), f"SSSP mode {mode}: distances differ from the oracle"
@@ -151,7 +151,7 @@ def test_tiny_and_ragged_graphs(ctx, oracle):
             assert (api.bfs(g, source, mode)[0].cpu().numpy() == ref).all()
     w = O.gen_weights(len(src), 1)[perm]
     dref, _ = O.sssp_bellman_ford(rowptr, adj, w, 7)
-    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
         d, _ = api.sssp(g, torch.from_numpy(w).to(ctx.device), 7, mode)
         assert (d.cpu().numpy().view(np.int32) == dref.view(np.int32)).all()
     assert (api.connected_components(g)[0].cpu().numpy() == O.cc_sv(rowptr, adj)[0]).all()
@@ -336,6 +336,9 @@ def test_large_scale_properties(kind, scale, ctx):
     d1, s1 = api.sssp(g, w, source, api.SSSP_ACTIVE_TILES)
     d2, s2 = api.sssp(g, w, source, api.SSSP_ALL_ACTIVE)
     assert torch.equal(d1.view(torch.int32), d2.view(torch.int32))
+    for delta in (3.0, 16.0, 1000.0):
+        d3, s3 = api.sssp(g, w, source, api.SSSP_DELTA_STEPPING, delta=delta)
+        assert torch.equal(d1.view(torch.int32), d3.view(torch.int32)), f"delta-stepping (delta={delta}) changed the distances"
     assert s1["edges_relaxed"] <= s2["edges_relaxed"]
     fin = d1[csr_src] < 3.0e38
     cand = d1[csr_src][fin] + w[fin]
@@ -381,7 +384,7 @@ def test_degree_renumbered_graph(kind, case, ctx, oracle):
     for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
         assert (api.bfs(g, source, mode)[0].cpu().numpy() == z["levels"]).all()
     w = ctx.gather_u32(g.perm, ctx.gen_weights(len(hs), seed))
-    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
         assert (api.sssp(g, w, source, mode)[0].cpu().numpy().view(np.int32) == z["dist"].view(np.int32)).all()
     rk = api.page_rank(g, int(z["pr_iters"]))[0].cpu().numpy()
     ref = O.pagerank(*O.coo_to_csr(V, hs, hd)[:2], int(z["pr_iters"]), 1)

@@ -15,7 +15,7 @@ from . import lib as _l
 
 RMAT_ABCD = (57, 19, 19, 5)            # vgl_runtime.hpp:36
 BFS_TOP_DOWN, BFS_DIRECTION_OPT = 0, 1
-SSSP_ALL_ACTIVE, SSSP_ACTIVE_TILES = 0, 1
+SSSP_ALL_ACTIVE, SSSP_ACTIVE_TILES, SSSP_DELTA_STEPPING = 0, 1, 2
 DENSE, SPARSE, ALL_ACTIVE = 0, 1, 2    # framework_types.h:156-160
 
 
@@ -263,12 +263,15 @@ def bfs(graph, source, mode=BFS_DIRECTION_OPT, levels=None, raw=False):
     return (levels if raw else graph.to_original(levels)), _stats(st)
 
 
-def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False):
+def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False, delta=16.0):
     ctx = graph.ctx
     dist = ctx.empty(graph.V, torch.float32) if dist is None else dist
     st = _l.SsspStats()
     s = int(source) if raw else graph.vertex_id(source)
-    _l.check(ctx.L.vgl_hip_sssp_run(ctx.h, graph.h, _ptr(weights), s, mode, _ptr(dist), C.byref(st)))
+    if mode == SSSP_DELTA_STEPPING:
+        _l.check(ctx.L.vgl_hip_sssp_run_delta(ctx.h, graph.h, _ptr(weights), s, float(delta), _ptr(dist), C.byref(st)))
+    else:
+        _l.check(ctx.L.vgl_hip_sssp_run(ctx.h, graph.h, _ptr(weights), s, mode, _ptr(dist), C.byref(st)))
     return (dist if raw else graph.to_original(dist)), _stats(st)
 
 
