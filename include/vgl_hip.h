@@ -166,6 +166,14 @@ int vgl_hip_sssp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights,
  * launches.  delta > 0, in the unit of the weights (weights in [0,100): 10..25 works well). */
 int vgl_hip_sssp_run_delta(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, int32_t source, float delta,
                            float *d_dist, vgl_hip_sssp_stats *stats);
+/* The bucketed schedule works on a plan: a copy of the adjacency + weights in which every row's edges are stably
+ * partitioned light-first (w < delta), built once per (graph, weights, delta) -- preprocessing in the sense of the
+ * reference's graph import, reusable for any number of sources.  run_delta above = create + run + destroy. */
+typedef struct vgl_hip_sssp_plan vgl_hip_sssp_plan;
+int vgl_hip_sssp_plan_create(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, float delta, vgl_hip_sssp_plan **out);
+int vgl_hip_sssp_plan_destroy(vgl_hip_ctx *ctx, vgl_hip_sssp_plan *plan);
+int vgl_hip_sssp_run_plan(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_sssp_plan *plan, int32_t source, float *d_dist,
+                          vgl_hip_sssp_stats *stats);
 
 typedef struct {
     int32_t iterations;

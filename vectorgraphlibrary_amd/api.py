@@ -263,12 +263,29 @@ def bfs(graph, source, mode=BFS_DIRECTION_OPT, levels=None, raw=False):
     return (levels if raw else graph.to_original(levels)), _stats(st)
 
 
-def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False, delta=16.0):
+class SsspPlan:
+    """light/heavy partitioned copy of (adjacency, weights) for the bucketed SSSP schedule; reusable across sources."""
+
+    def __init__(self, graph, weights, delta):
+        self.g, self.ctx, self.delta = graph, graph.ctx, float(delta)
+        h = C.c_void_p()
+        _l.check(self.ctx.L.vgl_hip_sssp_plan_create(self.ctx.h, graph.h, _ptr(weights), self.delta, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.L.vgl_hip_sssp_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False, delta=16.0, plan=None):
     ctx = graph.ctx
     dist = ctx.empty(graph.V, torch.float32) if dist is None else dist
     st = _l.SsspStats()
     s = int(source) if raw else graph.vertex_id(source)
-    if mode == SSSP_DELTA_STEPPING:
+    if plan is not None:
+        _l.check(ctx.L.vgl_hip_sssp_run_plan(ctx.h, graph.h, plan.h, s, _ptr(dist), C.byref(st)))
+    elif mode == SSSP_DELTA_STEPPING:
         _l.check(ctx.L.vgl_hip_sssp_run_delta(ctx.h, graph.h, _ptr(weights), s, float(delta), _ptr(dist), C.byref(st)))
     else:
         _l.check(ctx.L.vgl_hip_sssp_run(ctx.h, graph.h, _ptr(weights), s, mode, _ptr(dist), C.byref(st)))

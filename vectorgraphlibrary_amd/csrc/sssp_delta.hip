@@ -1,31 +1,87 @@
-// sssp_delta.hip -- SSSP with bucketed scheduling (delta-stepping with a light / heavy edge split) on the same
-// edge-tile relax machinery as sssp.hip.  Same operators as SSSP::vgl_dijkstra_* (algorithms/sssp/shortest_paths.hpp:
-// relax d[dst] = min(d[dst], d[src] + w) in f32), different SCHEDULE: because the fixed point of the relaxation is unique,
-// the distances are bit-identical to the reference's Bellman-Ford / Dijkstra results (tests assert this).
+// sssp_delta.hip -- SSSP with a bucketed schedule (delta-stepping with a light / heavy edge split).
+// Same operators as SSSP::vgl_dijkstra_* (algorithms/sssp/shortest_paths.hpp: relax d[dst] = min(d[dst], d[src] + w) in
+// f32), different SCHEDULE: the fixed point of the relaxation is unique, so the distances are bit-identical to the
+// reference's Bellman-Ford / Dijkstra results (tests assert this for several deltas).
 //
-// Why: an all-edges relax pass costs ~3.4 ms on RMAT-24 of which ~0.7 ms is the coalesced adjacency+weight stream and the
-// rest is the per-edge 4-byte gather of dist[dst] (L2 request bound).  Plain Bellman-Ford re-relaxes every out-edge of a
-// vertex each time its distance improves (hubs improve many times): ~5 E gathers.  Here a vertex's LIGHT edges (w < delta)
-// are relaxed whenever it improves inside the current bucket [.., T), its HEAVY edges only once the bucket has settled:
-// ~1.2 E gathers (measured by simulation on RMAT-18), the stream is re-read but that is the cheap part.
+// Why (measured on RMAT-24, degree-sorted ids): one all-edges relax pass = 3.4 ms, of which 0.7 ms is the coalesced
+// adjacency + weight stream and 2.7 ms the per-edge 4-byte gather of dist[dst] (L2-request bound).  Bellman-Ford re-relaxes
+// every out-edge of a vertex each time its distance improves and hubs improve many times (~5 E gathers, ~18 sweeps).  Here
+//   * vertices are processed in distance buckets [.., T), T advancing by delta from the nearest pending vertex;
+//   * a vertex's LIGHT edges (w < delta) are relaxed whenever it improves inside the bucket, its HEAVY edges once, after the
+//     bucket has settled  (~1.3-1.6 E gathers in total);
+//   * each step works on a compacted, ascending-id FRONTIER of scheduled rows and only on the light (or heavy) SEGMENT of their
+//     adjacency: a per-(graph, weights, delta) plan stores every row's edges stably partitioned light-first, so a step
+//     streams exactly the edges it relaxes (the tile-granular first version re-streamed ~9 E per run).
 //
-// Robustness rule (no reliance on bucket theory for correctness): EVERY improvement of d[v] sets both dirty[v] (light
-// edges pending) and heavy[v] (heavy edges pending); a flag is cleared only by the select pass that schedules the row, so
-// every improvement is eventually followed by a relaxation of all out-edges => the loop ends exactly at the fixed point.
+// Robustness rule (no reliance on bucket theory for correctness): EVERY improvement of d[v] sets both pending bits of
+// state[v]; a bit is cleared only when the row is scheduled, so every improvement is eventually followed by a relaxation of
+// all out-edges => the loop ends exactly at the fixed point.
 //
-// Per step: vgl_k_ds_select (V scan: 6 B/vertex; builds the active-row bitmap + active-tile bytes, clears scheduled flags,
-// reduces counters without same-address atomics) -> vgl_k_ds_relax (persistent workgroups stride over the tiles, skip
-// inactive ones after a 1-byte probe) -> one host read of 4 counters.
+// One step = count / scan / write (frontier ids + exclusive edge offsets, 8 rows per thread like the GNF) -> tile_first ->
+// persistent relax over the frontier's edge tiles; all sized from DEVICE counters, one host read per step.
 #include "vgl_hip_internal.h"
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <rocprim/rocprim.hpp>
 
-constexpr int VGL_DS_BLOCKS = 1024;       // persistent grid of both kernels
+constexpr int VGL_DS_BLOCKS = 2048;       // persistent grid of the relax kernel
+constexpr int VGL_DS_SCAN_THREADS = 1024;
 
-// state[v]: bit 0 = light edges pending ("dirty"), bit 1 = heavy edges pending
+struct vgl_hip_sssp_plan {
+    float delta = 0.0f;
+    int32_t *adj_p = nullptr;     // E: every row light edges first (w < delta), then heavy, both in original relative order
+    float *w_p = nullptr;         // E
+    int32_t *light_cnt = nullptr; // nrows
+    uint8_t *state = nullptr;     // V: bit0 light edges pending, bit1 heavy edges pending
+    int32_t *vt_aux = nullptr;    // per vertex tile: rows with heavy pending below T
+    int64_t *partials = nullptr;  // min-pending reduction (1024) followed by the relax kernel's near-improvement flags
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plan construction
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_light_flags(int64_t E, const float *w, float delta, uint32_t *flags)
+{
+    for (int64_t e = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; e < E; e += (int64_t)gridDim.x * VGL_BLOCK) flags[e] = w[e] < delta;
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[E] = 0;
+}
+// S = exclusive scan of the light flags (E+1 entries).  Stable partition inside every row.
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_partition(const int64_t *rowptr, const int32_t *adj, const float *w, const int32_t *tile_row,
+                                                                int64_t E, const uint32_t *S, float delta, int32_t *adj_p, float *w_p)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, E - e0);
+    const int r_first = tile_row[blockIdx.x], r_last = tile_row[blockIdx.x + 1];
+    vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;
+        if (i < n) {
+            const int64_t e = e0 + i;
+            const int r = r_first + s_map[i];
+            const int64_t rb = rowptr[r], re = rowptr[r + 1];
+            const uint32_t lb = S[e] - S[rb];                       // light edges of this row before e
+            const float we = w[e];
+            const int64_t pos = (we < delta) ? rb + lb : rb + (S[re] - S[rb]) + (e - rb - lb);
+            adj_p[pos] = adj[e];
+            w_p[pos] = we;
+        }
+    }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_light_counts(int32_t nrows, const int64_t *rowptr, const uint32_t *S, int32_t *light_cnt)
+{
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK)
+        light_cnt[r] = (int32_t)(S[rowptr[r + 1]] - S[rowptr[r]]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-step kernels
+// ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_init(int32_t V, int32_t source, float *dist, uint8_t *state)
 {
     for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK) {
@@ -35,246 +91,382 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_init(int32_t V, int32_t so
     }
 }
 
-// mode 0: schedule rows with (state & 1) && d < T (light pass); mode 1: rows with (state & 2) && d < T (heavy pass).
-// Thread = 8 consecutive vertices: one 8-byte load of their state bytes (all zero for most vertices most of the time), one
-// byte of the active-row bitmap written back.  partials[b*4 + {0,1,2}] = scheduled rows, rows with heavy pending and d < T,
-// min d over flagged rows with d >= T (as int bits; non-negative floats order like ints).
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_select(int32_t nrows, int32_t row_base, const int64_t *__restrict__ rowptr,
-                                                             const float *__restrict__ dist, uint8_t *__restrict__ state, float T, int mode,
-                                                             uint8_t *__restrict__ active_bytes, uint8_t *__restrict__ tile_active,
-                                                             int64_t *__restrict__ partials)
+// bits of the 8 rows at v0 that are scheduled: (state & bit) && dist < T; *aux = rows with heavy pending and dist < T
+__device__ __forceinline__ uint32_t vgl_ds_bits8(const uint8_t *state, const float *dist, int32_t v0, int nvalid, uint8_t bit, float T,
+                                                 uint32_t *aux, uint64_t *st_out)
+{
+    uint64_t st8 = 0;
+    if (nvalid == 8) st8 = *reinterpret_cast<const uint64_t *>(state + v0);
+    else for (int j = 0; j < nvalid; j++) st8 |= (uint64_t)state[v0 + j] << (8 * j);
+    uint32_t act = 0, hv = 0;
+    if (st8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint8_t f = (uint8_t)(st8 >> (8 * j));
+            if (f && dist[v0 + j] < T) {
+                if (f & bit) act |= 1u << j;
+                if (f & 2) hv |= 1u << j;
+            }
+        }
+    }
+    *aux = hv; *st_out = st8;
+    return act;
+}
+__device__ __forceinline__ int64_t vgl_ds_degree(const int64_t *rowptr, const int32_t *light_cnt, int32_t r, uint8_t bit)
+{
+    return bit == 1 ? (int64_t)light_cnt[r] : (rowptr[r + 1] - rowptr[r]) - (int64_t)light_cnt[r];
+}
+
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_count(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *light_cnt,
+                                                            const uint8_t *state, const float *dist, uint8_t bit, float T,
+                                                            int32_t *vt_cnt, int64_t *vt_deg, int32_t *vt_aux)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
-    int64_t n_sched = 0, n_heavy_near = 0;
-    int min_far = __float_as_int(FLT_MAX);
-    const uint8_t bit = mode == 0 ? 1 : 2;
-    const int32_t ngroups = (nrows + 7) >> 3;
-    for (int32_t gidx = blockIdx.x * VGL_BLOCK + threadIdx.x; gidx < ngroups; gidx += gridDim.x * VGL_BLOCK) {
-        const int32_t r0 = gidx << 3;
-        const int32_t v0 = row_base + r0;
-        const int nvalid = min(8, nrows - r0);
-        uint64_t st8 = 0;
-        if (nvalid == 8) st8 = *reinterpret_cast<const uint64_t *>(state + v0);
-        else for (int j = 0; j < nvalid; j++) st8 |= (uint64_t)state[v0 + j] << (8 * j);
-        uint32_t act = 0;
-        if (st8) {
-            uint64_t st_new = st8;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint8_t f = (uint8_t)(st8 >> (8 * j));
-                if (f) {
-                    const float d = dist[v0 + j];
-                    if (d < T) {
-                        if (f & bit) {
-                            act |= 1u << j;
-                            st_new &= ~((uint64_t)bit << (8 * j));
-                            const int64_t b = rowptr[r0 + j], e = rowptr[r0 + j + 1];
-                            if (e > b) for (int64_t t = b / VGL_TILE; t * VGL_TILE < e; t++) tile_active[t] = 1;
-                        }
-                        n_heavy_near += (mode == 0) && (f & 2);
-                    } else {
-                        min_far = min(min_far, __float_as_int(d));
-                    }
-                }
-            }
-            if (st_new != st8) {
-                if (nvalid == 8) *reinterpret_cast<uint64_t *>(state + v0) = st_new;
-                else for (int j = 0; j < nvalid; j++) state[v0 + j] = (uint8_t)(st_new >> (8 * j));
-            }
-            n_sched += __popc(act);
-        }
-        active_bytes[v0 >> 3] = (uint8_t)act;
+    const int32_t r0 = blockIdx.x * VGL_TILE + threadIdx.x * VGL_EPT;
+    int cnt = 0, aux_cnt = 0;
+    int64_t deg = 0;
+    if (r0 < nrows) {
+        const int nvalid = min(VGL_EPT, nrows - r0);
+        uint32_t aux; uint64_t st8;
+        const uint32_t bits = vgl_ds_bits8(state, dist, row_base + r0, nvalid, bit, T, &aux, &st8);
+        cnt = __popc(bits); aux_cnt = __popc(aux);
+        if (bits)
+            for (int j = 0; j < nvalid; j++)
+                if ((bits >> j) & 1) deg += vgl_ds_degree(rowptr, light_cnt, r0 + j, bit);
     }
-    n_sched = vgl_block_reduce_add(n_sched, s64);
-    n_heavy_near = vgl_block_reduce_add(n_heavy_near, s64);
+    const int tc = vgl_block_reduce_add(cnt, s32);
+    const int ta = vgl_block_reduce_add(aux_cnt, s32);
+    const int64_t td = vgl_block_reduce_add(deg, s64);
+    if (threadIdx.x == 0) { vt_cnt[blockIdx.x] = tc; vt_deg[blockIdx.x] = td; vt_aux[blockIdx.x] = ta; }
+}
+
+// exclusive offsets per vertex tile; counters[C_FRONT] = F, [C_NEIGH] = M, [C_TMP1] = rows with heavy pending below T; offs[F] = M
+__global__ __launch_bounds__(VGL_DS_SCAN_THREADS) void vgl_k_ds_scan(int64_t ntiles, const int32_t *vt_cnt, const int64_t *vt_deg, const int32_t *vt_aux,
+                                                                     int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *counters, int64_t *offs)
+{
+    __shared__ int64_t s_c[VGL_DS_SCAN_THREADS / 64], s_d[VGL_DS_SCAN_THREADS / 64], s_a[VGL_DS_SCAN_THREADS / 64];
+    const int64_t per = (ntiles + VGL_DS_SCAN_THREADS - 1) / VGL_DS_SCAN_THREADS;
+    const int64_t lo = min(ntiles, (int64_t)threadIdx.x * per), hi = min(ntiles, lo + per);
+    int64_t c = 0, d = 0, a = 0;
+    for (int64_t t = lo; t < hi; t++) { c += vt_cnt[t]; d += vt_deg[t]; a += vt_aux[t]; }
+    const int64_t ci = vgl_wave_incl_add(c), di = vgl_wave_incl_add(d), ai = vgl_wave_reduce_add(a);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) { s_c[w] = ci; s_d[w] = di; s_a[w] = ai; }
+    __syncthreads();
+    int64_t cb = 0, db = 0, ctot = 0, dtot = 0, atot = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) min_far = min(min_far, __shfl_xor(min_far, o));
-    __syncthreads();
-    if (vgl_lane() == 0) s32[vgl_wave()] = min_far;
-    __syncthreads();
+    for (int i = 0; i < VGL_DS_SCAN_THREADS / 64; i++) {
+        if (i < w) { cb += s_c[i]; db += s_d[i]; }
+        ctot += s_c[i]; dtot += s_d[i]; atot += s_a[i];
+    }
+    int64_t cpre = cb + ci - c, dpre = db + di - d;
+    for (int64_t t = lo; t < hi; t++) {
+        vt_cnt_off[t] = (int32_t)cpre; vt_deg_off[t] = dpre;
+        cpre += vt_cnt[t]; dpre += vt_deg[t];
+    }
     if (threadIdx.x == 0) {
-        int m = s32[0];
-        for (int w = 1; w < VGL_WAVES; w++) m = min(m, s32[w]);
-        partials[blockIdx.x * 4 + 0] = n_sched;
-        partials[blockIdx.x * 4 + 1] = n_heavy_near;
-        partials[blockIdx.x * 4 + 2] = m;
+        counters[C_FRONT] = ctot; counters[C_NEIGH] = dtot; counters[C_TMP1] = atot;
+        offs[ctot] = dtot;
     }
 }
 
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_fold(const int64_t *partials, int64_t *counters)
+// ids / offs of the scheduled rows (ascending) and the scheduled bit is cleared (each row is owned by exactly one thread)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_write(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *light_cnt,
+                                                            uint8_t *state, const float *dist, uint8_t bit, float T,
+                                                            const int32_t *vt_cnt_off, const int64_t *vt_deg_off, int32_t *ids, int64_t *offs)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
-    int64_t a = 0, b = 0;
-    int m = __float_as_int(FLT_MAX);
-    for (int i = threadIdx.x; i < VGL_DS_BLOCKS; i += VGL_BLOCK) {
-        a += partials[i * 4 + 0]; b += partials[i * 4 + 1];
-        m = min(m, (int)partials[i * 4 + 2]);
+    const int32_t r0 = blockIdx.x * VGL_TILE + threadIdx.x * VGL_EPT;
+    uint32_t bits = 0;
+    int nvalid = 0;
+    int64_t degs[VGL_EPT], deg = 0;
+    uint64_t st8 = 0;
+    if (r0 < nrows) {
+        nvalid = min(VGL_EPT, nrows - r0);
+        uint32_t aux;
+        bits = vgl_ds_bits8(state, dist, row_base + r0, nvalid, bit, T, &aux, &st8);
+        if (bits) {
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) {
+                degs[j] = 0;
+                if (j < nvalid && ((bits >> j) & 1)) { degs[j] = vgl_ds_degree(rowptr, light_cnt, r0 + j, bit); deg += degs[j]; }
+            }
+        }
     }
-    a = vgl_block_reduce_add(a, s64);
-    b = vgl_block_reduce_add(b, s64);
+    int ctot; int64_t dtot;
+    int pos = vt_cnt_off[blockIdx.x] + vgl_block_excl_add((int)__popc(bits), s32, &ctot);
+    int64_t eoff = vt_deg_off[blockIdx.x] + vgl_block_excl_add(deg, s64, &dtot);
+    if (bits) {
+        uint64_t st_new = st8;
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            if ((bits >> j) & 1) {
+                ids[pos] = row_base + r0 + j;
+                offs[pos] = eoff; eoff += degs[j];
+                pos++;
+                st_new &= ~((uint64_t)bit << (8 * j));
+            }
+        }
+        const int32_t v0 = row_base + r0;
+        if (nvalid == 8) *reinterpret_cast<uint64_t *>(state + v0) = st_new;
+        else for (int j = 0; j < nvalid; j++) state[v0 + j] = (uint8_t)(st_new >> (8 * j));
+    }
+}
+
+// tile_first[t] = frontier position owning frontier edge t*VGL_TILE; entry [#tiles] = owner of the last edge.  F from the device.
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_tile_first(const int64_t *counters, const int64_t *offs, int32_t *tile_first)
+{
+    const int32_t F = (int32_t)counters[C_FRONT];
+    const int64_t M = counters[C_NEIGH];
+    for (int32_t p = blockIdx.x * VGL_BLOCK + threadIdx.x; p < F; p += gridDim.x * VGL_BLOCK) {
+        const int64_t t0 = (offs[p] + VGL_TILE - 1) / VGL_TILE;
+        const int64_t t1 = (offs[p + 1] + VGL_TILE - 1) / VGL_TILE;
+        for (int64_t t = t0; t < t1; t++) tile_first[t] = p;
+        if (offs[p] < offs[p + 1] && offs[p + 1] == M) tile_first[(M + VGL_TILE - 1) / VGL_TILE] = p;
+    }
+}
+
+// persistent relax over the frontier's edge tiles.  HEAVY selects which segment of every scheduled row is walked.
+template <bool HEAVY>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *counters, const int32_t *ids, const int64_t *offs, const int32_t *tile_first,
+                                                            const int64_t *rowptr, const int32_t *light_cnt, const int32_t *adj_p, const float *w_p,
+                                                            int32_t row_base, float T, float *dist, uint8_t *state, int64_t *near_partials, int hotskip)
+{
+    constexpr int STAGE = 1024;                             // rows staged per tile: 8 + 8 + 4 KB of LDS => 8 workgroups per CU
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int64_t s_base[STAGE];
+    __shared__ float s_dsrc[STAGE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t M = counters[C_NEIGH];
+    const int64_t ntiles = (M + VGL_TILE - 1) / VGL_TILE;
+    int near = 0;                                           // improvements that fall inside the current bucket
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                    // LDS of the previous tile is no longer read
+        const int64_t e0 = tile * VGL_TILE;
+        const int n = (int)min((int64_t)VGL_TILE, M - e0);
+        const int p_first = tile_first[tile];
+        const int p_last = tile_first[tile + 1];
+        const int np = p_last - p_first + 1;
+        const bool staged = np <= STAGE;
+        if (staged)
+            for (int k = threadIdx.x; k < np; k += VGL_BLOCK) {
+                const int p = p_first + k;
+                const int32_t u = ids[p];
+                const int32_t r = u - row_base;
+                s_base[k] = rowptr[r] + (HEAVY ? (int64_t)light_cnt[r] : 0) - offs[p];
+                s_dsrc[k] = dist[u];
+            }
+        vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);
+        int32_t dsts[VGL_EPT];
+        float nds[VGL_EPT], olds[VGL_EPT];
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            const int i = threadIdx.x + j * VGL_BLOCK;
+            dsts[j] = -1;
+            nds[j] = 0.0f;
+            if (i < n) {
+                const int k = s_map[i];
+                int64_t base; float d;
+                if (staged) { base = s_base[k]; d = s_dsrc[k]; }
+                else {
+                    const int p = p_first + k; const int32_t u = ids[p]; const int32_t r = u - row_base;
+                    base = rowptr[r] + (HEAVY ? (int64_t)light_cnt[r] : 0) - offs[p];
+                    d = dist[u];
+                }
+                const int64_t e = base + e0 + i;
+                dsts[j] = adj_p[e];
+                nds[j] = __fadd_rn(d, w_p[e]);                 // src_weight + weight (shortest_paths.hpp:126-130)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) olds[j] = dsts[j] >= 0 ? dist[dsts[j]] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            if (dsts[j] >= hotskip && olds[j] > nds[j]) {
+                const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
+                if (before > __float_as_int(nds[j])) {
+                    state[dsts[j]] = 3;                         // light and heavy edges pending again
+                    near |= nds[j] < T;
+                }
+            }
+        }
+    }
+    const int any_near = __syncthreads_or(near);
+    if (threadIdx.x == 0) near_partials[blockIdx.x] = any_near;
+}
+
+// min distance over all vertices with a pending bit (needed only when a bucket is exhausted)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_min_pending(int32_t V, const uint8_t *state, const float *dist, int64_t *partials)
+{
+    __shared__ int s32[VGL_WAVES];
+    int m = __float_as_int(FLT_MAX);
+    const int32_t ngroups = V >> 3;                          // state has 8 bytes of slack; the tail is handled below
+    for (int32_t gi = blockIdx.x * VGL_BLOCK + threadIdx.x; gi < ngroups; gi += gridDim.x * VGL_BLOCK) {
+        const uint64_t st8 = *reinterpret_cast<const uint64_t *>(state + ((int64_t)gi << 3));
+        if (st8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((st8 >> (8 * j)) & 0xff) m = min(m, __float_as_int(dist[(gi << 3) + j]));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (V & 7)) { const int32_t v = (V & ~7) + threadIdx.x; if (state[v]) m = min(m, __float_as_int(dist[v])); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
-    __syncthreads();
     if (vgl_lane() == 0) s32[vgl_wave()] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < VGL_WAVES; w++) m = min(m, s32[w]);
-        counters[C_TMP0] = a; counters[C_TMP1] = b; counters[C_JUMP] = min(m, s32[0]);
-    }
+    if (threadIdx.x == 0) { for (int w = 1; w < VGL_WAVES; w++) m = min(m, s32[w]); partials[blockIdx.x] = min(m, s32[0]); }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_min_fold(int n, const int64_t *partials, const int64_t *near_partials, int64_t *counters)
+{
+    __shared__ int s32[VGL_WAVES];
+    int m = __float_as_int(FLT_MAX);
+    int near = 0;
+    for (int i = threadIdx.x; i < VGL_DS_BLOCKS; i += VGL_BLOCK) near |= (int)near_partials[i];
+    near = __syncthreads_or(near);
+    if (threadIdx.x == 0) counters[C_TMP0] = near;
+    for (int i = threadIdx.x; i < n; i += VGL_BLOCK) m = min(m, (int)partials[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+    if (vgl_lane() == 0) s32[vgl_wave()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < VGL_WAVES; w++) m = min(m, s32[w]); counters[C_JUMP] = min(m, s32[0]); }
 }
 
-// persistent relax: HEAVY = false relaxes edges with w < delta of the scheduled rows, HEAVY = true the others
-template <bool HEAVY>
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *rowptr, const int32_t *adj, const float *w, const int32_t *tile_row,
-                                                            int64_t E, int64_t ntiles, int32_t row_base, float delta, float *dist,
-                                                            const uint64_t *active_bm, uint8_t *tile_active, uint8_t *state,
-                                                            int64_t *shards)
-{
-    __shared__ int s_map[VGL_TILE];
-    __shared__ int s_w[VGL_WAVES];
-    __shared__ int s_list[VGL_BLOCK];
-    __shared__ int s_count;
-    int64_t streamed = 0;
-    // the workgroup owns tiles blockIdx.x + k*gridDim.x; probe up to 256 of their flags at once (one byte per thread),
-    // compact the active ones through LDS, then walk only those (a serial 1-byte probe per tile cost ~1 us each)
-    for (int64_t k0 = 0; blockIdx.x + k0 * gridDim.x < ntiles; k0 += VGL_BLOCK) {
-        if (threadIdx.x == 0) s_count = 0;
-        __syncthreads();
-        const int64_t mine = blockIdx.x + (k0 + threadIdx.x) * gridDim.x;
-        if (mine < ntiles && tile_active[mine]) { tile_active[mine] = 0; s_list[atomicAdd(&s_count, 1)] = (int)(k0 + threadIdx.x); }
-        __syncthreads();
-        const int cnt = s_count;
-    for (int li = 0; li < cnt; li++) {
-        __syncthreads();          // every thread is done reading s_map of the previous tile before it is rebuilt
-        const int64_t tile = blockIdx.x + (int64_t)s_list[li] * gridDim.x;
-        const int64_t e0 = tile * VGL_TILE;
-        const int n = (int)min((int64_t)VGL_TILE, E - e0);
-        const int r_first = tile_row[tile];
-        const int r_last = tile_row[tile + 1];
-        vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
-        streamed += n;
-        const int i0 = threadIdx.x * VGL_EPT;
-        if (i0 < n) {
-            int32_t dsts[VGL_EPT];
-            float ws[VGL_EPT];
-            if (i0 + VGL_EPT <= n) {
-                const int4 a0 = *reinterpret_cast<const int4 *>(adj + e0 + i0);
-                const int4 a1 = *reinterpret_cast<const int4 *>(adj + e0 + i0 + 4);
-                const float4 w0 = *reinterpret_cast<const float4 *>(w + e0 + i0);
-                const float4 w1 = *reinterpret_cast<const float4 *>(w + e0 + i0 + 4);
-                dsts[0] = a0.x; dsts[1] = a0.y; dsts[2] = a0.z; dsts[3] = a0.w; dsts[4] = a1.x; dsts[5] = a1.y; dsts[6] = a1.z; dsts[7] = a1.w;
-                ws[0] = w0.x; ws[1] = w0.y; ws[2] = w0.z; ws[3] = w0.w; ws[4] = w1.x; ws[5] = w1.y; ws[6] = w1.z; ws[7] = w1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < VGL_EPT; j++) {
-                    const bool ok = i0 + j < n;
-                    dsts[j] = ok ? adj[e0 + i0 + j] : 0;
-                    ws[j] = ok ? w[e0 + i0 + j] : 0.0f;
-                }
-            }
-            float olds[VGL_EPT], dsrc[VGL_EPT];
-            int prev_row = -1;
-            float d = 0.0f;
-            bool live = false;
-#pragma unroll
-            for (int j = 0; j < VGL_EPT; j++) {
-                const int row = s_map[i0 + j];
-                if (row != prev_row) {
-                    prev_row = row;
-                    const int32_t u = row_base + r_first + row;
-                    live = (active_bm[u >> 6] >> (u & 63)) & 1ULL;
-                    d = live ? dist[u] : FLT_MAX;
-                }
-                const bool ok = live && (i0 + j < n) && ((ws[j] < delta) != HEAVY);
-                dsrc[j] = ok ? d : FLT_MAX;
-                olds[j] = ok ? dist[dsts[j]] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < VGL_EPT; j++) {
-                if (dsrc[j] < FLT_MAX) {
-                    const float nd = __fadd_rn(dsrc[j], ws[j]);
-                    if (olds[j] > nd) {
-                        const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nd));
-                        if (before > __float_as_int(nd)) state[dsts[j]] = 3;     // light and heavy edges pending again
-                    }
-                }
-            }
-        }
-    }
-        __syncthreads();          // s_list / s_count are reused by the next probe round
-    }
-    if (threadIdx.x == 0 && streamed) atomicAdd((unsigned long long *)&shards[blockIdx.x & (VGL_NSHARD - 1)], (unsigned long long)streamed);
-}
+static inline unsigned vgl_ds_grid(int64_t n, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
 
 extern "C" {
+
+int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, float delta, vgl_hip_sssp_plan **out)
+{
+    if (!c || !g || !d_weights || !out) VGL_FAIL("sssp_plan_create: null argument");
+    if (!(delta > 0.0f)) VGL_FAIL("sssp_plan_create: delta must be positive");
+    const int64_t E = g->out.edges;
+    if (E >= 0xFFFFFFF0LL) VGL_FAIL("sssp_plan_create: at most 2^32-16 edges per graph handle");
+    hipStream_t st = c->stream;
+    vgl_hip_sssp_plan *p = new vgl_hip_sssp_plan();
+    p->delta = delta;
+    VGL_HIP_TRY(hipMalloc((void **)&p->adj_p, sizeof(int32_t) * (size_t)std::max<int64_t>(E, 1)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->w_p, sizeof(float) * (size_t)std::max<int64_t>(E, 1)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->light_cnt, sizeof(int32_t) * (size_t)g->nrows));
+    VGL_HIP_TRY(hipMalloc((void **)&p->state, (size_t)g->V + 8));
+    VGL_HIP_TRY(hipMalloc((void **)&p->vt_aux, sizeof(int32_t) * (size_t)std::max<int64_t>(g->nvtiles, 1)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->partials, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS)));
+    uint32_t *flags = nullptr, *S = nullptr;
+    void *temp = nullptr;
+    size_t need = 0;
+    VGL_HIP_TRY(hipMalloc((void **)&flags, sizeof(uint32_t) * ((size_t)E + 1)));
+    VGL_HIP_TRY(hipMalloc((void **)&S, sizeof(uint32_t) * ((size_t)E + 1)));
+    hipLaunchKernelGGL(vgl_k_ds_light_flags, dim3(vgl_ds_grid(std::max<int64_t>(E, 1), 16384)), dim3(VGL_BLOCK), 0, st, E, d_weights, delta, flags);
+    VGL_HIP_TRY(rocprim::exclusive_scan(nullptr, need, flags, S, 0u, (size_t)E + 1, rocprim::plus<uint32_t>(), st));
+    VGL_HIP_TRY(hipMalloc(&temp, need ? need : 16));
+    VGL_HIP_TRY(rocprim::exclusive_scan(temp, need, flags, S, 0u, (size_t)E + 1, rocprim::plus<uint32_t>(), st));
+    if (g->out.ntiles > 0)
+        hipLaunchKernelGGL(vgl_k_ds_partition, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, st, g->out.rowptr, g->out.adj, d_weights,
+                           g->out.tile_row, E, S, delta, p->adj_p, p->w_p);
+    hipLaunchKernelGGL(vgl_k_ds_light_counts, dim3(vgl_ds_grid(g->nrows, 8192)), dim3(VGL_BLOCK), 0, st, g->nrows, g->out.rowptr, S, p->light_cnt);
+    VGL_HIP_TRY(hipGetLastError());
+    VGL_HIP_TRY(hipStreamSynchronize(st));
+    hipFree(temp); hipFree(flags); hipFree(S);
+    *out = p;
+    return 0;
+}
+
+int vgl_hip_sssp_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_plan *p)
+{
+    if (!p) return 0;
+    if (c) hipStreamSynchronize(c->stream);
+    hipFree(p->adj_p); hipFree(p->w_p); hipFree(p->light_cnt); hipFree(p->state); hipFree(p->vt_aux); hipFree(p->partials);
+    delete p;
+    return 0;
+}
+
+int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p, int32_t source, float *d_dist, vgl_hip_sssp_stats *stats)
+{
+    if (!c || !g || !p || !d_dist) VGL_FAIL("sssp_run_plan: null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("sssp_run_plan: graph handle must own all rows");
+    if (source < 0 || source >= g->V) VGL_FAIL("sssp_run_plan: source vertex out of range");
+    const int32_t V = g->V;
+    hipStream_t st = c->stream;
+    const bool debug = getenv("VGL_HIP_DEBUG") != nullptr;
+    const int hotskip = getenv("VGL_HIP_EXPERIMENT_HOTSKIP") ? atoi(getenv("VGL_HIP_EXPERIMENT_HOTSKIP")) : 0;
+    hipLaunchKernelGGL(vgl_k_ds_init, dim3(vgl_ds_grid(V, 8192)), dim3(VGL_BLOCK), 0, st, V, source, d_dist, p->state);
+    vgl_hip_sssp_stats s = {0, 0, 0};
+    float T = p->delta;
+    const unsigned nvt = (unsigned)g->nvtiles;
+    int64_t *near_partials = p->partials + 1024;
+    // one step: schedule rows with (state & bit) && dist < T, relax their light (bit 1) or heavy (bit 2) segment, then gather
+    // everything the host needs for the next decision in ONE read: F, M, heavy-pending-below-T (before the relax), whether
+    // the relax produced improvements below T, and the smallest pending distance after the relax.
+    auto step = [&](uint8_t bit) -> int {
+        hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, g->out.rowptr, p->light_cnt, p->state, d_dist,
+                           bit, T, g->vt_cnt, g->vt_deg, p->vt_aux);
+        hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
+                           g->vt_deg_off, c->d_counters, g->offs);
+        hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, g->out.rowptr, p->light_cnt, p->state, d_dist,
+                           bit, T, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
+        hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
+        {
+            vgl_timed_launch tl(c, "sssp_relax");
+            if (bit == 1)
+                hipLaunchKernelGGL(vgl_k_ds_relax<false>, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
+                                   g->out.rowptr, p->light_cnt, p->adj_p, p->w_p, g->row_begin, T, d_dist, p->state, near_partials, hotskip);
+            else
+                hipLaunchKernelGGL(vgl_k_ds_relax<true>, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
+                                   g->out.rowptr, p->light_cnt, p->adj_p, p->w_p, g->row_begin, T, d_dist, p->state, near_partials, hotskip);
+        }
+        hipLaunchKernelGGL(vgl_k_ds_min_pending, dim3(1024), dim3(VGL_BLOCK), 0, st, V, p->state, d_dist, p->partials);
+        hipLaunchKernelGGL(vgl_k_ds_min_fold, dim3(1), dim3(VGL_BLOCK), 0, st, 1024, p->partials, near_partials, c->d_counters);
+        VGL_HIP_TRY(hipGetLastError());
+        VGL_TRY(vgl_read_counters(c, false));
+        if (c->h_counters[C_FRONT] > 0) { s.iterations++; s.edges_relaxed += c->h_counters[C_NEIGH]; }
+        if (debug) fprintf(stderr, "ds %s T=%g rows=%lld edges=%lld heavy_pending_below_T=%lld near_improved=%lld\n", bit == 1 ? "light" : "heavy", T,
+                           (long long)c->h_counters[C_FRONT], (long long)c->h_counters[C_NEIGH], (long long)c->h_counters[C_TMP1],
+                           (long long)c->h_counters[C_TMP0]);
+        return 0;
+    };
+    // bucket width: delta, doubled through the sparse tail (fewer steps).  Narrower buckets in the dense core were measured
+    // (W0 = 1/4 .. 1/16): 10 % fewer relaxed edges but 2-3x the steps, i.e. slower -- the per-step passes dominate.  The
+    // light/heavy edge split always uses the plan's delta.  Any width is correct, it only changes the amount of re-relaxation.
+    auto envf = [](const char *n, double dflt) { const char *v = getenv(n); return v ? atof(v) : dflt; };
+    float width = (float)(p->delta * envf("VGL_DS_W0", 1.0));
+    const int64_t rows_hi = (int64_t)envf("VGL_DS_HI", 1.0e18), rows_lo = (int64_t)envf("VGL_DS_LO", 4096.0);
+    T = width;
+    int64_t bucket_rows = 0;
+    for (;;) {
+        VGL_TRY(step(1));
+        bucket_rows += c->h_counters[C_FRONT];
+        bool near = c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0;
+        if (near) continue;                                             // the bucket received improvements: light edges again
+        if (c->h_counters[C_TMP1] > 0) {                                // bucket settled: its heavy edges, once
+            VGL_TRY(step(2));
+            if (c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0) continue;
+        }
+        const int bits = (int)c->h_counters[C_JUMP];                    // smallest pending distance after the last relax
+        float min_far;
+        memcpy(&min_far, &bits, sizeof(float));
+        if (!(min_far < FLT_MAX)) break;                                // nothing pending anywhere: fixed point
+        if (min_far < T) continue;                                      // (defensive) something below T is still pending
+        if (bucket_rows > rows_hi && width > p->delta / 64.0f) width *= 0.5f;
+        else if (bucket_rows < rows_lo && width < 64.0f * p->delta) width *= 2.0f;
+        if (debug) fprintf(stderr, "ds bucket done: rows=%lld next width=%g\n", (long long)bucket_rows, width);
+        bucket_rows = 0;
+        T = std::max(min_far + width, std::nextafter(min_far, FLT_MAX));
+    }
+    s.algorithmic_bytes = 12 * s.edges_relaxed + 5 * (int64_t)V * s.iterations;
+    if (stats) *stats = s;
+    return 0;
+}
 
 int vgl_hip_sssp_run_delta(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, int32_t source, float delta, float *d_dist,
                            vgl_hip_sssp_stats *stats)
 {
-    if (!c || !g || !d_weights || !d_dist) VGL_FAIL("sssp_run_delta: null argument");
-    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("sssp_run_delta: graph handle must own all rows");
-    if (source < 0 || source >= g->V) VGL_FAIL("sssp_run_delta: source vertex out of range");
-    if (!(delta > 0.0f)) VGL_FAIL("sssp_run_delta: delta must be positive");
-    const int32_t V = g->V;
-    hipStream_t st = c->stream;
-    uint8_t *state = reinterpret_cast<uint8_t *>(g->epoch);          // V bytes carved from the int32[V] epoch scratch
-    if (!g->ds_tile_active) {
-        VGL_HIP_TRY(hipMalloc((void **)&g->ds_tile_active, (size_t)g->out.ntiles + 1));
-        VGL_HIP_TRY(hipMalloc((void **)&g->ds_partials, sizeof(int64_t) * VGL_DS_BLOCKS * 4));
-        VGL_HIP_TRY(hipMemsetAsync(g->ds_tile_active, 0, (size_t)g->out.ntiles + 1, st));
-    }
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, vgl_ceil_div(V, VGL_BLOCK)));
-    hipLaunchKernelGGL(vgl_k_ds_init, dim3(grid), dim3(VGL_BLOCK), 0, st, V, source, d_dist, state);
-    VGL_TRY(vgl_zero_counters(c, C_EDGES, 1));
-    vgl_hip_sssp_stats s = {0, 0, 0};
-    float T = delta;
-    const bool debug = getenv("VGL_HIP_DEBUG") != nullptr;
-    auto select = [&](int mode) -> int {
-        vgl_timed_launch tl(c, "sssp_select");
-        hipLaunchKernelGGL(vgl_k_ds_select, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, g->out.rowptr,
-                           d_dist, state, T, mode, (uint8_t *)g->bm_front, g->ds_tile_active, g->ds_partials);
-        hipLaunchKernelGGL(vgl_k_ds_fold, dim3(1), dim3(VGL_BLOCK), 0, st, g->ds_partials, c->d_counters);
-        VGL_HIP_TRY(hipGetLastError());
-        return vgl_read_counters(c, false);
-    };
-    auto relax = [&](bool heavy_pass) -> int {
-        if (g->out.ntiles == 0) return 0;
-        vgl_timed_launch tl(c, "sssp_relax");
-        if (heavy_pass)
-            hipLaunchKernelGGL(vgl_k_ds_relax<true>, dim3(VGL_DS_BLOCKS * 2), dim3(VGL_BLOCK), 0, st, g->out.rowptr, g->out.adj, d_weights,
-                               g->out.tile_row, g->out.edges, g->out.ntiles, g->row_begin, delta, d_dist, g->bm_front, g->ds_tile_active,
-                               state, c->d_shards);
-        else
-            hipLaunchKernelGGL(vgl_k_ds_relax<false>, dim3(VGL_DS_BLOCKS * 2), dim3(VGL_BLOCK), 0, st, g->out.rowptr, g->out.adj, d_weights,
-                               g->out.tile_row, g->out.edges, g->out.ntiles, g->row_begin, delta, d_dist, g->bm_front, g->ds_tile_active,
-                               state, c->d_shards);
-        VGL_HIP_TRY(hipGetLastError());
-        s.iterations++;
-        return 0;
-    };
-    for (;;) {
-        VGL_TRY(select(0));
-        const int64_t n_light = c->h_counters[C_TMP0], n_heavy_near = c->h_counters[C_TMP1];
-        const int min_far_bits = (int)c->h_counters[C_JUMP];
-        if (debug) fprintf(stderr, "ds step %d: T=%g light=%lld heavy_near=%lld\n", s.iterations, T, (long long)n_light, (long long)n_heavy_near);
-        if (n_light > 0) { VGL_TRY(relax(false)); continue; }
-        if (n_heavy_near > 0) {                       // bucket settled: heavy edges of everything below T
-            VGL_TRY(select(1));
-            if (c->h_counters[C_TMP0] > 0) VGL_TRY(relax(true));
-            continue;
-        }
-        float min_far;
-        memcpy(&min_far, &min_far_bits, sizeof(float));
-        if (!(min_far < FLT_MAX)) break;              // nothing flagged anywhere: fixed point
-        T = std::max(min_far + delta, std::nextafter(min_far, FLT_MAX));   // always admits the nearest flagged vertex
-    }
-    VGL_TRY(vgl_read_counters(c, true));
-    s.edges_relaxed = c->h_counters[C_EDGES];
-    s.algorithmic_bytes = 12 * s.edges_relaxed + 6 * (int64_t)V * s.iterations;
-    if (stats) *stats = s;
-    return 0;
+    vgl_hip_sssp_plan *p = nullptr;
+    VGL_TRY(vgl_hip_sssp_plan_create(c, g, d_weights, delta, &p));
+    const int rc = vgl_hip_sssp_run_plan(c, g, p, source, d_dist, stats);
+    vgl_hip_sssp_plan_destroy(c, p);
+    return rc;
 }
 
 }  // extern "C"

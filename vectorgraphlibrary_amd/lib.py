@@ -78,6 +78,9 @@ _SIGNATURES = {
     "vgl_hip_bfs_run": [_p, _p, _i32, _int, _p, C.POINTER(BfsStats)],
     "vgl_hip_sssp_run": [_p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
     "vgl_hip_sssp_run_delta": [_p, _p, _p, _i32, C.c_float, _p, C.POINTER(SsspStats)],
+    "vgl_hip_sssp_plan_create": [_p, _p, _p, C.c_float, _pp],
+    "vgl_hip_sssp_plan_destroy": [_p, _p],
+    "vgl_hip_sssp_run_plan": [_p, _p, _p, _i32, _p, C.POINTER(SsspStats)],
     "vgl_hip_pr_run": [_p, _p, _p, _int, _p, C.POINTER(PrStats)],
     "vgl_hip_cc_run": [_p, _p, _p, C.POINTER(CcStats)],
     "vgl_hip_bfs_init": [_p, _i32, _i32, _p],
