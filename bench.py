@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sssp", action="store_true")
     ap.add_argument("--cpu-sources", type=int, default=3)
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU super-step path even with one rank (debug)")
+    ap.add_argument("--sssp-delta", type=float, default=16.0)
     ap.add_argument("--renumber", default="total", choices=["none", "out", "in", "total"],
                     help="VectCSR-style degree renumbering of the stored graph (vect_csr/import.hpp:61-99)")
     args = ap.parse_args()
@@ -96,7 +98,7 @@ def main():
     extra = {}
     roofline = None
     cpu_baseline = None
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         for s in sources[:args.warmup]:
             api.bfs(g, s, api.BFS_DIRECTION_OPT, raw=True)
         ctx.timing(True)
@@ -171,7 +173,27 @@ def main():
                              "relax_kernel": {"launches": n, "total_ms": round(ms, 3),
                                               "algorithmic_GBps": round(12 * edges / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
                                               "frac_of_hbm_peak": round(12 * edges / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None}}
+            t1 = time.perf_counter()
+            plan = api.SsspPlan(g, w, args.sssp_delta)
+            torch.cuda.synchronize()
+            t_plan = time.perf_counter() - t1
+            api.sssp(g, w, sources[0], plan=plan, raw=True)
+            ctx.timing(True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sst = [api.sssp(g, w, s, plan=plan, raw=True)[1] for s in sources[args.warmup:args.warmup + 6]]
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / len(sst)
+            n, ms = ctx.timing_get("sssp_relax")
+            ctx.timing(False)
+            edges = sum(s["edges_relaxed"] for s in sst)
+            res["delta_stepping"] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "delta": args.sssp_delta, "steps": sst[0]["iterations"],
+                                     "edges_relaxed_per_run": edges // len(sst), "plan_build_ms_once_per_weights": round(t_plan * 1e3, 2),
+                                     "relax_kernel": {"launches": n, "total_ms": round(ms, 3),
+                                                      "algorithmic_GBps": round(12 * edges / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}}
+            plan.close()
             extra["sssp"] = res
+            extra["sssp_value_teps"] = res["delta_stepping"]["teps"]
             del w
 
         # ---- CPU baseline: the oracle's OpenMP port of the reference top-down BFS, same graph, host cores ----
@@ -196,20 +218,24 @@ def main():
     else:
         # edge-cut shards of the SAME graph: strong scaling.  Top-down super-steps with bitmap all-gather.
         bounds = ctx.partition_rows(g.out_rowptr, world)
-        shard = g.shard(bounds[rank], bounds[rank + 1])
+        shard = g.shard(bounds[rank], bounds[rank + 1]) if world > 1 else g
         ops = vd.HipShardOps(shard)
+        degrees = (g.out_rowptr[1:] - g.out_rowptr[:-1]).to(torch.int32)      # replicated out-degrees for the direction rule
         for s in sources[:args.warmup]:
-            vd.bfs_sharded(ops, s)
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E)
         barrier()
         t0 = time.perf_counter()
         for s in sources[args.warmup:]:
-            vd.bfs_sharded(ops, s)
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E)
         barrier()
         dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        workload = f"BFS (top-down super-steps, bitmap exchange) on RMAT scale-{scale} (edge factor {ef}), edge-cut over {world} GPUs"
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        extra["shard_edges"] = int(shard.E)
+        workload = (f"BFS direction-optimising super-steps (bitmap all-gather per level) on RMAT scale-{scale} "
+                    f"(edge factor {ef}), edge-cut over {world} GPUs")
         scaling = "strong"
 
     if rank == 0:

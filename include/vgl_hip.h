@@ -196,15 +196,25 @@ int vgl_hip_cc_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_
  *      RCCL collective issued by the host side, replacing common/mpi_exchange.hpp:110-150,222-271) ---- */
 int vgl_hip_bfs_init(vgl_hip_ctx *ctx, int32_t V, int32_t source, int32_t *d_levels);
 /* expand the owned part of level `level`: frontier = owned rows with levels == level.  Writes levels[dst] = level+1
- * anywhere in the replicated array.  local_frontier/local_edges are host outputs.  Synchronises. */
+ * anywhere in the replicated array.  d_visited_bits: replicated visited bitmap (V bits) or NULL to have it rebuilt from
+ * levels.  local_frontier/local_edges are host outputs (the frontier is compacted before the expand, which is left enqueued). */
 int vgl_hip_bfs_step_top_down(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_levels, int32_t level,
-                              int64_t *local_frontier, int64_t *local_edges);
+                              const uint64_t *d_visited_bits, int64_t *local_frontier, int64_t *local_edges);
+/* bottom-up step over the owned rows (needs the incoming CSR): unvisited owned vertices with an in-neighbour in the frontier
+ * bitmap get levels = level+1.  d_next_bits (V bits) receives exactly this rank's discoveries (other words zero), ready for
+ * the bitmap exchange.  found / probed (optional, synchronise): discovered vertices, adjacency entries examined. */
+int vgl_hip_bfs_step_bottom_up(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_levels, int32_t level,
+                               const uint64_t *d_visited_bits, const uint64_t *d_front_bits, uint64_t *d_next_bits,
+                               int64_t *found, int64_t *probed);
 /* bitmap (V bits, little-endian within uint64 words) of vertices with d_levels == level */
 int vgl_hip_levels_to_bitmap(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_levels, int32_t level, uint64_t *d_bits);
-/* OR `parts` bitmaps (each V/64 words, contiguous) and set levels[v] = level where a bit is set and v is unvisited;
+/* OR `parts` bitmaps (each V/64 words, contiguous) and set levels[v] = level where a bit is set and v is unvisited.
+ * Optional replicated state for the next direction decision: d_visited_bits |= new frontier, d_front_bits = new frontier,
+ * d_degrees (int32[V] out-degrees of ALL vertices) -> *newly_degree = sum of the new frontier's out-degrees.
  * *newly = number of vertices that now have d_levels == level.  Synchronises. */
-int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *ctx, int32_t V, int parts, const uint64_t *d_bits_all,
-                              int32_t *d_levels, int32_t level, int64_t *newly);
+int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *ctx, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
+                              uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
+                              int64_t *newly_degree);
 int vgl_hip_sssp_init(vgl_hip_ctx *ctx, int32_t V, int32_t source, float *d_dist);
 /* one all-active push relaxation over the owned rows; *changed = 1 if any distance decreased. Synchronises. */
 int vgl_hip_sssp_relax_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, float *d_dist, int *changed);

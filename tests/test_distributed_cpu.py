@@ -25,6 +25,8 @@ class NumpyShardOps:
         e0, e1 = rowptr[lo], rowptr[hi]
         self.es, self.ed = self.src[e0:e1], adj[e0:e1].astype(np.int64)
         self.ew = w[e0:e1] if w is not None else None
+        own = (adj >= lo) & (adj < hi)                    # incoming edges of the owned vertices (bottom-up steps)
+        self.in_src, self.in_dst = self.src[own], adj[own].astype(np.int64)
 
     def new_i32(self): return torch.empty(self.V, dtype=torch.int32)
     def new_f32(self): return torch.empty(self.V, dtype=torch.float32)
@@ -35,7 +37,7 @@ class NumpyShardOps:
     def bfs_init(self, levels, source):
         levels.fill_(-1); levels[source] = 1
 
-    def bfs_step(self, levels, level):
+    def bfs_step(self, levels, level, visited=None):
         lv = levels.numpy()
         m = lv[self.es] == level
         tgt = self.ed[m]
@@ -48,14 +50,40 @@ class NumpyShardOps:
         b[:self.V] = levels.numpy() == level
         bits.numpy().view(np.uint8)[:] = np.packbits(b, bitorder="little")
 
-    def apply_bitmaps(self, parts, bits_all, levels, level):
+    def apply_bitmaps(self, parts, bits_all, levels, level, visited=None, front=None, degrees=None):
         words = (self.V + 63) // 64
         w = bits_all.numpy().reshape(parts, words)
         merged = np.bitwise_or.reduce(w, axis=0)
         on = np.unpackbits(merged.view(np.uint8), bitorder="little")[:self.V].astype(bool)
         lv = levels.numpy()
         lv[on & (lv == -1)] = level
-        return int((lv == level).sum())
+        new = on & (lv == level)
+        if front is not None:
+            self._pack(new, front)
+        if visited is not None:
+            visited.numpy()[:] |= self._packed(new)
+        return int(new.sum()), (int(degrees.numpy()[new].sum()) if degrees is not None else 0)
+
+    def _packed(self, mask):
+        b = np.zeros(((self.V + 63) // 64) * 64, np.uint8)
+        b[:self.V] = mask
+        return np.packbits(b, bitorder="little").view(np.int64)
+
+    def _pack(self, mask, out):
+        out.numpy()[:] = self._packed(mask)
+
+    def _unpack(self, bits):
+        return np.unpackbits(bits.numpy().view(np.uint8), bitorder="little")[:self.V].astype(bool)
+
+    def bfs_step_bu(self, levels, level, visited, front, mine):
+        """owned unvisited vertices with an in-neighbour in the frontier get level+1 (uses the transposed owned edges)"""
+        lv = levels.numpy()
+        fr, vis = self._unpack(front), self._unpack(visited)
+        found = np.zeros(self.V, bool)
+        m = fr[self.in_src] & ~vis[self.in_dst]
+        found[self.in_dst[m]] = True
+        lv[found] = level + 1
+        self._pack(found, mine)
 
     def sssp_init(self, d, source):
         d.fill_(float(FLT_MAX)); d[source] = 0
@@ -129,6 +157,9 @@ def _worker(rank, world, port, results):
     ops = NumpyShardOps(V, rowptr, adj, w, bounds[rank], bounds[rank + 1])
     source = O.pick_source(rowptr, seed)
     levels, _ = vd.bfs_sharded(ops, source)
+    degrees = torch.from_numpy(np.diff(rowptr).astype(np.int32))
+    levels_do, _ = vd.bfs_sharded(ops, source, degrees=degrees, edges=len(adj))
+    assert (levels_do.numpy() == levels.numpy()).all(), "direction-optimising sharded BFS != top-down sharded BFS"
     d, _ = vd.sssp_sharded(ops, source)
     comp, _ = vd.cc_sharded(ops)
     ranks = vd.page_rank_sharded(ops, 3, bounds[rank], bounds[rank + 1])

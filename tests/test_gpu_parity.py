@@ -245,7 +245,7 @@ def test_sharded_super_steps_single_process(ctx, oracle):
         for p, (o, r) in enumerate(zip(ops, reps)):
             o.bfs_step(r, level)
             o.levels_to_bitmap(r, level + 1, everyone[p * words:(p + 1) * words])
-        newly = [o.apply_bitmaps(P, everyone, r, level + 1) for o, r in zip(ops, reps)]
+        newly = [o.apply_bitmaps(P, everyone, r, level + 1)[0] for o, r in zip(ops, reps)]
         assert len(set(newly)) == 1
         if newly[0] == 0:
             break
@@ -253,6 +253,34 @@ def test_sharded_super_steps_single_process(ctx, oracle):
     ref, _ = O.bfs_top_down(rowptr, adj, source)
     for r in reps:
         assert (r.cpu().numpy() == ref).all()
+
+    # the driver itself (world size 1, one shard = whole graph): top-down and direction-optimising must agree with the oracle
+    from vectorgraphlibrary_amd import distributed as vd
+    whole = HipShardOps(g, w)
+    degrees = (g.out_rowptr[1:] - g.out_rowptr[:-1]).to(torch.int32)
+    assert (vd.bfs_sharded(whole, source)[0].cpu().numpy() == ref).all()
+    assert (vd.bfs_sharded(whole, source, degrees=degrees, edges=len(adj))[0].cpu().numpy() == ref).all()
+    # bottom-up step on shards: every shard scans its own rows, bitmaps are OR-ed
+    reps = [o.new_i32() for o in ops]
+    for o, r in zip(ops, reps):
+        o.bfs_init(r, source)
+    vis = [o.new_words(1) for o in ops]
+    fr = [o.new_words(1) for o in ops]
+    for o, r, v_, f_ in zip(ops, reps, vis, fr):
+        o.levels_to_bitmap(r, 1, f_)
+        v_.copy_(f_)
+    level = 1
+    while True:
+        everyone = ops[0].new_words(P)
+        for p, (o, r) in enumerate(zip(ops, reps)):
+            o.bfs_step_bu(r, level, vis[p], fr[p], everyone[p * words:(p + 1) * words])
+        res = [o.apply_bitmaps(P, everyone, r, level + 1, vis[p], fr[p], degrees) for p, (o, r) in enumerate(zip(ops, reps))]
+        assert len(set(res)) == 1
+        if res[0][0] == 0:
+            break
+        level += 1
+    for r in reps:
+        assert (r.cpu().numpy() == ref).all(), "sharded bottom-up BFS differs from the oracle"
 
     # SSSP: relax owned rows, elementwise min across replicas
     reps = [o.new_f32() for o in ops]

@@ -239,23 +239,44 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_levels_to_bitmap(int32_t V, c
     }
 }
 
+// OR the per-rank discovery bitmaps, mark the newly discovered vertices in levels, and (optionally) keep the replicated
+// visited / frontier bitmaps and the frontier's out-degree sum up to date for the direction decision of the next level
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_bitmaps(int32_t V, int parts, int64_t words, const uint64_t *bits_all,
-                                                                 int32_t *levels, int32_t level, int64_t *counters)
+                                                                 int32_t *levels, int32_t level, uint64_t *visited, uint64_t *front,
+                                                                 const int32_t *degrees, int64_t *partials)
 {
     __shared__ int64_t s64[VGL_WAVES];
-    int64_t cnt = 0;
+    int64_t cnt = 0, deg = 0;
     const int32_t vround = (V + 63) & ~63;
     for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < vround; v += gridDim.x * VGL_BLOCK) {
         uint64_t w = 0;
         for (int p = 0; p < parts; p++) w |= bits_all[(int64_t)p * words + (v >> 6)];   // wave-uniform loads
-        if (v < V) {
-            int32_t l = levels[v];
-            if (((w >> (v & 63)) & 1ULL) && l == -1) { levels[v] = level; l = level; }
-            cnt += (l == level);
+        bool is_new = false;
+        if (v < V && ((w >> (v & 63)) & 1ULL)) {
+            const int32_t l = levels[v];
+            if (l == -1) levels[v] = level;
+            is_new = (l == -1) || (l == level);
         }
+        const unsigned long long nm = __ballot(is_new);
+        if (vgl_lane() == 0) {
+            if (front) front[v >> 6] = nm;
+            if (visited) visited[v >> 6] |= nm;
+        }
+        cnt += is_new;
+        if (is_new && degrees) deg += degrees[v];
     }
     cnt = vgl_block_reduce_add(cnt, s64);
-    if (threadIdx.x == 0 && cnt) atomicAdd((unsigned long long *)&counters[C_TMP0], (unsigned long long)cnt);
+    deg = vgl_block_reduce_add(deg, s64);
+    if (threadIdx.x == 0) { partials[blockIdx.x * 2] = cnt; partials[blockIdx.x * 2 + 1] = deg; }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_fold(int n, const int64_t *partials, int64_t *counters)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    int64_t a = 0, b = 0;
+    for (int i = threadIdx.x; i < n; i += VGL_BLOCK) { a += partials[i * 2]; b += partials[i * 2 + 1]; }
+    a = vgl_block_reduce_add(a, s64);
+    b = vgl_block_reduce_add(b, s64);
+    if (threadIdx.x == 0) { counters[C_TMP0] = a; counters[C_TMP1] = b; }
 }
 
 static inline unsigned vgl_grid(int64_t n, int64_t cap = 8192) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
@@ -271,6 +292,28 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
         hipLaunchKernelGGL(vgl_k_td_expand, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
                            g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level);
     }
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// one bottom-up step over the owned rows: probe + balanced heavy pass + fold (counters C_BU_FOUND / C_BU_EDGES)
+static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, int32_t next_level, const uint64_t *visited,
+                             const uint64_t *front, uint64_t *next)
+{
+    const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
+    {
+        vgl_timed_launch tl(c, "bfs_bottom_up");
+        hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
+                           g->in.rowptr, g->in.adj, visited, g->bm_in_nz, front, next, levels, next_level,
+                           g->heavy, g->heavy_cnt, g->bu_partials);
+    }
+    hipLaunchKernelGGL(vgl_k_bu_heavy_offsets, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->heavy_cnt, g->heavy_off);
+    {
+        vgl_timed_launch tl(c, "bfs_bottom_up_heavy");
+        hipLaunchKernelGGL(vgl_k_bu_heavy, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,
+                           g->in.adj, front, next, levels, next_level, g->heavy, g->heavy_off, g->bu_partials);
+    }
+    hipLaunchKernelGGL(vgl_k_bu_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->bu_partials, c->d_counters);
     VGL_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -343,20 +386,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
         } else {
             if (!have_bitmaps) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
-            const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
-            {
-                vgl_timed_launch tl(c, "bfs_bottom_up");
-                hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
-                                   g->in.rowptr, g->in.adj, g->bm_visited, g->bm_in_nz, g->bm_front, g->bm_next, d_levels, cur + 1,
-                                   g->heavy, g->heavy_cnt, g->bu_partials);
-            }
-            hipLaunchKernelGGL(vgl_k_bu_heavy_offsets, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->heavy_cnt, g->heavy_off);
-            {
-                vgl_timed_launch tl(c, "bfs_bottom_up_heavy");
-                hipLaunchKernelGGL(vgl_k_bu_heavy, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,
-                                   g->in.adj, g->bm_front, g->bm_next, d_levels, cur + 1, g->heavy, g->heavy_off, g->bu_partials);
-            }
-            hipLaunchKernelGGL(vgl_k_bu_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->bu_partials, c->d_counters);
+            VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next));
             hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
                                g->bm_front, g->bm_next);
             VGL_HIP_TRY(hipGetLastError());
@@ -375,20 +405,46 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     return 0;
 }
 
-int vgl_hip_bfs_step_top_down(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_levels, int32_t level, int64_t *local_frontier,
-                              int64_t *local_edges)
+int vgl_hip_bfs_step_top_down(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_levels, int32_t level, const uint64_t *d_visited_bits,
+                              int64_t *local_frontier, int64_t *local_edges)
 {
     if (!c || !g || !d_levels) VGL_FAIL("bfs_step_top_down: null argument");
-    // visited bitmap over ALL vertices (destinations may live in any shard), then the owned part of the frontier
-    hipLaunchKernelGGL(vgl_k_levels_to_bitmap<true>, dim3(vgl_grid(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, d_levels, -1,
-                       g->bm_visited);
+    // visited bitmap over ALL vertices (destinations may live in any shard): the caller's replicated one, or rebuilt here
+    const uint64_t *visited = d_visited_bits;
+    if (!visited) {
+        hipLaunchKernelGGL(vgl_k_levels_to_bitmap<true>, dim3(vgl_grid(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, d_levels, -1,
+                           g->bm_visited);
+        visited = g->bm_visited;
+    }
     vgl_pred_equal_i32 pred{d_levels, level};
     VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, nullptr, nullptr, nullptr, true, true));
     const int64_t F = c->h_counters[C_FRONT], M = c->h_counters[C_NEIGH];
     if (local_frontier) *local_frontier = F;
     if (local_edges) *local_edges = M;
-    VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, level + 1));
-    return vgl_hip_ctx_sync(c);
+    if (F > 0 && M > 0) {
+        hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, (int32_t)F, g->offs, g->tile_first);
+        vgl_timed_launch tl(c, "bfs_top_down");
+        hipLaunchKernelGGL(vgl_k_td_expand, dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
+                           g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, visited, d_levels, level + 1);
+    }
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;                                    // enqueued; the caller's next call on this context orders after it
+}
+
+int vgl_hip_bfs_step_bottom_up(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_levels, int32_t level, const uint64_t *d_visited_bits,
+                               const uint64_t *d_front_bits, uint64_t *d_next_bits, int64_t *found, int64_t *probed)
+{
+    if (!c || !g || !d_levels || !d_visited_bits || !d_front_bits || !d_next_bits) VGL_FAIL("bfs_step_bottom_up: null argument");
+    if (!g->in.rowptr) VGL_FAIL("bfs_step_bottom_up: the incoming CSR of the owned rows is required");
+    // only the owned words of d_next_bits are written by the kernels: clear the rest so the buffer can be exchanged as is
+    VGL_HIP_TRY(hipMemsetAsync(d_next_bits, 0, sizeof(uint64_t) * (size_t)vgl_ceil_div(g->V, 64), c->stream));
+    VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, level + 1, d_visited_bits, d_front_bits, d_next_bits));
+    if (found || probed) {
+        VGL_TRY(vgl_read_counters(c, false));
+        if (found) *found = c->h_counters[C_BU_FOUND];
+        if (probed) *probed = c->h_counters[C_BU_EDGES];
+    }
+    return 0;
 }
 
 int vgl_hip_levels_to_bitmap(vgl_hip_ctx *c, int32_t V, const int32_t *d_levels, int32_t level, uint64_t *d_bits)
@@ -400,16 +456,21 @@ int vgl_hip_levels_to_bitmap(vgl_hip_ctx *c, int32_t V, const int32_t *d_levels,
 }
 
 int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *c, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
-                              int64_t *newly)
+                              uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
+                              int64_t *newly_degree)
 {
     if (!c || !d_bits_all || !d_levels) VGL_FAIL("bfs_apply_bitmaps: null argument");
     if (parts < 1) VGL_FAIL("bfs_apply_bitmaps: parts must be >= 1");
-    VGL_TRY(vgl_zero_counters(c, C_TMP0, 1));
-    hipLaunchKernelGGL(vgl_k_apply_bitmaps, dim3(vgl_grid(V, 1024)), dim3(VGL_BLOCK), 0, c->stream, V, parts, vgl_ceil_div(V, 64), d_bits_all,
-                       d_levels, level, c->d_counters);
+    const int nb = (int)vgl_grid(V, 1024);
+    VGL_TRY(vgl_ensure_partials(c, (size_t)nb * 2 + 2));
+    int64_t *partials = reinterpret_cast<int64_t *>(c->d_partials);
+    hipLaunchKernelGGL(vgl_k_apply_bitmaps, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, V, parts, vgl_ceil_div(V, 64), d_bits_all,
+                       d_levels, level, d_visited_bits, d_front_bits, d_degrees, partials);
+    hipLaunchKernelGGL(vgl_k_apply_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, nb, partials, c->d_counters);
     VGL_HIP_TRY(hipGetLastError());
-    VGL_TRY(vgl_read_counters(c));
+    VGL_TRY(vgl_read_counters(c, false));
     if (newly) *newly = c->h_counters[C_TMP0];
+    if (newly_degree) *newly_degree = c->h_counters[C_TMP1];
     return 0;
 }
 

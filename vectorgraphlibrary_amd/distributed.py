@@ -52,18 +52,23 @@ class HipShardOps:
     def bfs_init(self, levels, source):
         _l.check(self.L.vgl_hip_bfs_init(self.ctx.h, self.V, int(source), _ptr(levels)))
 
-    def bfs_step(self, levels, level):
+    def bfs_step(self, levels, level, visited=None):
         f, m = C.c_int64(), C.c_int64()
-        _l.check(self.L.vgl_hip_bfs_step_top_down(self.ctx.h, self.g.h, _ptr(levels), int(level), C.byref(f), C.byref(m)))
+        _l.check(self.L.vgl_hip_bfs_step_top_down(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), C.byref(f), C.byref(m)))
         return f.value, m.value
+
+    def bfs_step_bu(self, levels, level, visited, front, mine):
+        _l.check(self.L.vgl_hip_bfs_step_bottom_up(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), _ptr(front), _ptr(mine),
+                                                   None, None))
 
     def levels_to_bitmap(self, levels, level, bits):
         _l.check(self.L.vgl_hip_levels_to_bitmap(self.ctx.h, self.V, _ptr(levels), int(level), _ptr(bits)))
 
-    def apply_bitmaps(self, parts, bits_all, levels, level):
-        n = C.c_int64()
-        _l.check(self.L.vgl_hip_bfs_apply_bitmaps(self.ctx.h, self.V, parts, _ptr(bits_all), _ptr(levels), int(level), C.byref(n)))
-        return n.value
+    def apply_bitmaps(self, parts, bits_all, levels, level, visited=None, front=None, degrees=None):
+        n, d = C.c_int64(), C.c_int64()
+        _l.check(self.L.vgl_hip_bfs_apply_bitmaps(self.ctx.h, self.V, parts, _ptr(bits_all), _ptr(levels), int(level), _ptr(visited),
+                                                  _ptr(front), _ptr(degrees), C.byref(n), C.byref(d)))
+        return n.value, d.value
 
     def sssp_init(self, d, source):
         _l.check(self.L.vgl_hip_sssp_init(self.ctx.h, self.V, int(source), _ptr(d)))
@@ -102,27 +107,51 @@ def _allreduce(t, op, group):
         dist.all_reduce(t, op=op, group=group)
 
 
-def bfs_sharded(ops, source, group=None):
-    """top-down BFS over edge-cut shards; returns the replicated levels array and the number of levels."""
+ALPHA, BETA = 15, 18          # change_state.hpp:5-6
+
+
+def bfs_sharded(ops, source, group=None, degrees=None, edges=None):
+    """BFS over edge-cut shards; returns the replicated levels array and the number of levels.
+    degrees (int32[V] out-degrees of ALL vertices, replicated) + edges (global E) enable direction optimisation: every rank
+    evaluates the same switch rule (gpu_change_state, change_state.hpp:100-141) on replicated counters, bottom-up steps scan
+    the owned rows' incoming edges.  Without them the traversal is top-down only.
+    Exchange per level: all-gather of V/8-byte discovery bitmaps."""
     P, rank = _world(group)
+    V = ops.V
     levels = ops.new_i32()
     ops.bfs_init(levels, source)
-    words = (ops.V + 63) // 64
     mine = ops.new_words(1)
     everyone = ops.new_words(P) if P > 1 else mine
+    visited, front = ops.new_words(1), ops.new_words(1)
+    ops.levels_to_bitmap(levels, 1, front)
+    visited.copy_(front)
+    direction_opt = degrees is not None and edges is not None
+    F, M = 1, (int(degrees[source]) if direction_opt else 0)
+    prevF, visited_total, bottom_up = 0, 0, False
+    factor = max(1, (edges // V) // 2) if direction_opt else 1
     level, nlevels = 1, 0
     while True:
-        ops.bfs_step(levels, level)                       # owned frontier vertices expand; levels[dst] = level+1
+        visited_total += F
+        if direction_opt:
+            if not bottom_up:
+                if F > prevF and M >= ((V - visited_total) * factor + V) // ALPHA:
+                    bottom_up = True
+            elif F < prevF and F < ((V - visited_total) * factor + V) // (factor * BETA):
+                bottom_up = False
+        prevF = F
+        if bottom_up:
+            ops.bfs_step_bu(levels, level, visited, front, mine)          # owned unvisited vertices look for a parent
+        else:
+            ops.bfs_step(levels, level, visited)                          # owned frontier vertices expand
+            ops.levels_to_bitmap(levels, level + 1, mine)                 # what this rank discovered
         nlevels += 1
-        ops.levels_to_bitmap(levels, level + 1, mine)     # what this rank discovered
         if P > 1:
             ops.sync()
             dist.all_gather_into_tensor(everyone, mine, group=group)
-        newly = ops.apply_bitmaps(P, everyone, levels, level + 1)
-        if newly == 0:
+        F, M = ops.apply_bitmaps(P, everyone, levels, level + 1, visited, front, degrees if direction_opt else None)
+        if F == 0:
             break
         level += 1
-    assert everyone.numel() == P * words
     return levels, nlevels
 
 

@@ -84,9 +84,10 @@ _SIGNATURES = {
     "vgl_hip_pr_run": [_p, _p, _p, _int, _p, C.POINTER(PrStats)],
     "vgl_hip_cc_run": [_p, _p, _p, C.POINTER(CcStats)],
     "vgl_hip_bfs_init": [_p, _i32, _i32, _p],
-    "vgl_hip_bfs_step_top_down": [_p, _p, _p, _i32, C.POINTER(_i64), C.POINTER(_i64)],
+    "vgl_hip_bfs_step_top_down": [_p, _p, _p, _i32, _p, C.POINTER(_i64), C.POINTER(_i64)],
+    "vgl_hip_bfs_step_bottom_up": [_p, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_levels_to_bitmap": [_p, _i32, _p, _i32, _p],
-    "vgl_hip_bfs_apply_bitmaps": [_p, _i32, _int, _p, _p, _i32, C.POINTER(_i64)],
+    "vgl_hip_bfs_apply_bitmaps": [_p, _i32, _int, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_sssp_init": [_p, _i32, _i32, _p],
     "vgl_hip_sssp_relax_owned": [_p, _p, _p, _p, C.POINTER(_int)],
     "vgl_hip_cc_init": [_p, _i32, _p],
