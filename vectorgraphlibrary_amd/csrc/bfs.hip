@@ -38,10 +38,13 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_first(int32_t F, const i
 
 // top-down advance over a sparse frontier, edge-balanced: workgroup = 2048 consecutive frontier edges.
 // edge_op of bfs.hpp:28-36: if levels[dst] == UNVISITED then levels[dst] = cur+1 (benign race, same value).
+// EMIT: every newly discovered vertex also sets its bit in the next-frontier bitmap (idempotent atomicOr), so that the next
+// level's frontier can be generated from 2 MiB of bitmap instead of a 64 MiB scan of levels.  Used for small frontiers only.
+template <bool EMIT>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids, const int64_t *offs, const int32_t *tile_first,
                                                              int32_t F, int64_t M, const int64_t *rowptr, const int32_t *adj,
                                                              int32_t row_base, const uint64_t *visited, int32_t *levels,
-                                                             int32_t next_level)
+                                                             int32_t next_level, uint64_t *next)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int64_t s_base[VGL_TILE];
@@ -78,8 +81,68 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
         unvis[j] = dsts[j] >= 0 && !((visited[dsts[j] >> 6] >> (dsts[j] & 63)) & 1ULL);
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++)
-        if (unvis[j] && levels[dsts[j]] == -1) levels[dsts[j]] = next_level;
+        if (unvis[j] && levels[dsts[j]] == -1) {
+            levels[dsts[j]] = next_level;
+            if (EMIT) atomicOr((unsigned long long *)&next[dsts[j] >> 6], 1ULL << (dsts[j] & 63));
+        }
 }
+
+// ---- frontier generation from the frontier BITMAP (small frontiers): one 64-bit word per thread, 256 words per workgroup ----
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
+                                                                const int64_t *rowptr, int32_t *vt_cnt, int64_t *vt_deg)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    __shared__ int s32[VGL_WAVES];
+    const int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x;
+    int cnt = 0;
+    int64_t deg = 0;
+    if (wi < nwords) {
+        uint64_t w = front[word0 + wi];
+        cnt = __popcll(w);
+        while (w) {
+            const int b = __ffsll((long long)w) - 1;
+            w &= w - 1;
+            const int64_t r = ((word0 + wi) << 6) + b - row_base;
+            deg += rowptr[r + 1] - rowptr[r];
+        }
+    }
+    const int tc = vgl_block_reduce_add(cnt, s32);
+    const int64_t td = vgl_block_reduce_add(deg, s64);
+    if (threadIdx.x == 0) { vt_cnt[blockIdx.x] = tc; vt_deg[blockIdx.x] = td; }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
+                                                                const int64_t *rowptr, const int32_t *vt_cnt_off, const int64_t *vt_deg_off,
+                                                                int32_t *ids, int64_t *offs)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    __shared__ int s32[VGL_WAVES];
+    const int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x;
+    uint64_t w = 0;
+    int64_t deg = 0;
+    if (wi < nwords) {
+        w = front[word0 + wi];
+        uint64_t t = w;
+        while (t) {
+            const int b = __ffsll((long long)t) - 1;
+            t &= t - 1;
+            const int64_t r = ((word0 + wi) << 6) + b - row_base;
+            deg += rowptr[r + 1] - rowptr[r];
+        }
+    }
+    int ctot; int64_t dtot;
+    int pos = vt_cnt_off[blockIdx.x] + vgl_block_excl_add((int)__popcll(w), s32, &ctot);
+    int64_t eoff = vt_deg_off[blockIdx.x] + vgl_block_excl_add(deg, s64, &dtot);
+    while (w) {
+        const int b = __ffsll((long long)w) - 1;
+        w &= w - 1;
+        const int32_t v = (int32_t)(((word0 + wi) << 6) + b);
+        const int64_t r = v - row_base;
+        ids[pos] = v; offs[pos] = eoff;
+        eoff += rowptr[r + 1] - rowptr[r];
+        pos++;
+    }
+}
+__global__ void vgl_k_set_bit(int32_t v, uint64_t *a, uint64_t *b) { a[v >> 6] = 1ULL << (v & 63); b[v >> 6] = 1ULL << (v & 63); }
 
 // Bottom-up step.  No global atomics: a single same-address device atomic costs ~12 ns and serialises (65 536 blocks
 // adding to one counter took 1.5 ms per launch in the first version); instead a fixed grid of VGL_BU_BLOCKS persistent
@@ -281,18 +344,48 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_fold(int n, const int64
 
 static inline unsigned vgl_grid(int64_t n, int64_t cap = 8192) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
 
-// expand frontier (ids/offs with F vertices, M edges already produced by the GNF write pass)
-static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_t M, int32_t *levels, int32_t next_level)
+// expand frontier (ids/offs with F vertices, M edges already produced by a frontier-generation write pass)
+static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_t M, int32_t *levels, int32_t next_level, bool emit)
 {
     if (F <= 0 || M <= 0) return 0;
     hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, F, g->offs, g->tile_first);
     const int64_t nt = vgl_ceil_div(M, VGL_TILE);
     {
         vgl_timed_launch tl(c, "bfs_top_down");
-        hipLaunchKernelGGL(vgl_k_td_expand, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                           g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level);
+        if (emit)
+            hipLaunchKernelGGL(vgl_k_td_expand<true>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
+                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next);
+        else
+            hipLaunchKernelGGL(vgl_k_td_expand<false>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
+                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next);
     }
     VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// frontier of the current level from bm_front (owned words): counts + totals (read back), optionally ids + edge offsets
+static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, bool count, bool write)
+{
+    const int64_t word0 = g->row_begin >> 6;
+    const int64_t nwords = vgl_ceil_div(g->row_end, 64) - word0;
+    const unsigned nb = (unsigned)vgl_ceil_div(nwords, VGL_BLOCK);
+    if (count) {
+        {
+            vgl_timed_launch tl(c, "gnf");
+            hipLaunchKernelGGL(vgl_k_bm_gnf_count, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, g->bm_front,
+                               g->out.rowptr, g->vt_cnt, g->vt_deg);
+        }
+        hipLaunchKernelGGL(vgl_k_gnf_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, (int64_t)nb, g->vt_cnt, g->vt_deg, g->vt_cnt_off,
+                           g->vt_deg_off, c->d_counters, g->offs);
+        VGL_HIP_TRY(hipGetLastError());
+        VGL_TRY(vgl_read_counters(c, false));
+    }
+    if (write) {
+        vgl_timed_launch tl(c, "gnf");
+        hipLaunchKernelGGL(vgl_k_bm_gnf_write, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, g->bm_front,
+                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
+        VGL_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -339,22 +432,36 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     const int64_t E = g->out.edges;
     const int64_t words = vgl_ceil_div(V, 64);
     VGL_TRY(vgl_hip_bfs_init(c, V, source, d_levels));
+    VGL_HIP_TRY(hipMemsetAsync(g->bm_visited, 0, sizeof(uint64_t) * (size_t)words, c->stream));
+    VGL_HIP_TRY(hipMemsetAsync(g->bm_front, 0, sizeof(uint64_t) * (size_t)words, c->stream));
+    hipLaunchKernelGGL(vgl_k_set_bit, dim3(1), dim3(1), 0, c->stream, source, g->bm_visited, g->bm_front);
 
     vgl_hip_bfs_stats st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int32_t cur = 1;
     bool bottom_up = false;          // state used to PROCESS level `cur`
-    bool have_bitmaps = false;       // bm_front / bm_visited describe level `cur`
+    // Frontier of level `cur`: bm_front when front_valid (bm_visited is then current too); otherwise only `levels` knows it and
+    // the levels-scanning GNF rebuilds both bitmaps.  Frontiers are kept as bitmaps whenever the level that produced them was
+    // small (bottom-up steps always; top-down steps with at most VGL_TD_EMIT_EDGES edges, which OR their discoveries in).
+    bool front_valid = true;
+    bool counted = false;            // vt_cnt_off / vt_deg_off describe the frontier (needed by the write pass)
+    bool counted_from_bitmap = false;
     int64_t F = 0, M = 0, prevF = 0, visited_total = 0;
     const int64_t factor = std::max<int64_t>(1, (E / V) / 2);     // change_state.hpp:104
-    for (;;) {
-        if (!bottom_up) {
-            // frontier of level cur from the levels array: counts + bitmaps, then ids + edge offsets
+    constexpr int64_t VGL_TD_EMIT_EDGES = 16 << 20;
+    auto count_frontier = [&]() -> int {
+        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, true, false)); counted_from_bitmap = true; }
+        else {
             vgl_pred_equal_i32 pred{d_levels, cur};
-            VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited,
-                                nullptr, false, true));
-            F = c->h_counters[C_FRONT]; M = c->h_counters[C_NEIGH];
-            have_bitmaps = true;
+            VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, nullptr, false, true));
+            front_valid = true; counted_from_bitmap = false;
         }
+        F = c->h_counters[C_FRONT]; M = c->h_counters[C_NEIGH];
+        counted = true;
+        return 0;
+    };
+    for (;;) {
+        counted = false;
+        if (!bottom_up) VGL_TRY(count_frontier());      // after a bottom-up step F is already known (M is not needed to stay bottom-up)
         if (F == 0) break;
         visited_total += F;
         st.levels++; st.frontier_total += F;
@@ -362,30 +469,31 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         if (mode == VGL_HIP_BFS_DIRECTION_OPT) {
             if (!bottom_up) {
                 if (F > prevF && M >= ((V - visited_total) * factor + V) / VGL_DO_ALPHA) bottom_up = true;
-            } else {
-                if (F < prevF && F < ((V - visited_total) * factor + V) / (factor * VGL_DO_BETA)) {
-                    bottom_up = false;
-                    // need ids/offs of level cur: regenerate from levels
-                    vgl_pred_equal_i32 pred{d_levels, cur};
-                    VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited,
-                                        nullptr, false, true));
-                    F = c->h_counters[C_FRONT]; M = c->h_counters[C_NEIGH];
-                    have_bitmaps = true;
-                }
+            } else if (F < prevF && F < ((V - visited_total) * factor + V) / (factor * VGL_DO_BETA)) {
+                bottom_up = false;
+                VGL_TRY(count_frontier());              // ids / offsets of level cur are needed again (bm_front is valid: cheap)
             }
         }
         prevF = F;
         if (!bottom_up) {
-            vgl_pred_equal_i32 pred{d_levels, cur};
-            {
+            if (!counted) VGL_FAIL("bfs_run: internal error (frontier not counted)");
+            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, false, true));
+            else {
+                vgl_pred_equal_i32 pred{d_levels, cur};
                 vgl_timed_launch tl(c, "gnf");
                 hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_equal_i32>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred,
                                    g->nrows, g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
             }
-            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1));
+            const bool emit = M <= VGL_TD_EMIT_EDGES;
+            if (emit) VGL_HIP_TRY(hipMemsetAsync(g->bm_next, 0, sizeof(uint64_t) * (size_t)words, c->stream));
+            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit));
+            if (emit)
+                hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
+                                   g->bm_front, g->bm_next);
+            front_valid = emit;
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
         } else {
-            if (!have_bitmaps) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
+            if (!front_valid) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
             VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next));
             hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
                                g->bm_front, g->bm_next);
@@ -394,7 +502,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             st.bu_steps++; st.edges_examined += c->h_counters[C_BU_EDGES];
             st.bu_edges += c->h_counters[C_BU_EDGES]; st.bu_found += c->h_counters[C_BU_FOUND];
             F = c->h_counters[C_BU_FOUND]; M = 0;      // next frontier; bitmaps now describe level cur+1
-            have_bitmaps = true;
+            front_valid = true;
         }
         cur++;
     }
@@ -424,8 +532,9 @@ int vgl_hip_bfs_step_top_down(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_level
     if (F > 0 && M > 0) {
         hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, (int32_t)F, g->offs, g->tile_first);
         vgl_timed_launch tl(c, "bfs_top_down");
-        hipLaunchKernelGGL(vgl_k_td_expand, dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
-                           g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, visited, d_levels, level + 1);
+        hipLaunchKernelGGL(vgl_k_td_expand<false>, dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
+                           g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, visited, d_levels, level + 1,
+                           (uint64_t *)nullptr);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;                                    // enqueued; the caller's next call on this context orders after it

@@ -33,11 +33,11 @@ int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out)
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
     VGL_HIP_TRY(hipMalloc((void **)&c->d_counters, sizeof(int64_t) * C_NSLOTS));
-    VGL_HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(int64_t) * C_NSLOTS, hipHostMallocDefault));
+    VGL_HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(int64_t) * (C_NSLOTS + 8), hipHostMallocDefault));
     VGL_HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(int64_t) * C_NSLOTS, c->stream));
     VGL_HIP_TRY(hipMalloc((void **)&c->d_shards, sizeof(int64_t) * VGL_NSHARD));
     VGL_HIP_TRY(hipMemsetAsync(c->d_shards, 0, sizeof(int64_t) * VGL_NSHARD, c->stream));
-    memset(c->h_counters, 0, sizeof(int64_t) * C_NSLOTS);
+    memset(c->h_counters, 0, sizeof(int64_t) * (C_NSLOTS + 8));
     *out = c;
     return 0;
 }
@@ -179,11 +179,32 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_fold_shards(int64_t *shards, 
     if (threadIdx.x == 0) counters[C_EDGES] += acc;
 }
 
+// One wavefront copies the counter slots into pinned host memory and then publishes a sequence number with system scope.
+// The host spins on the sequence number: a few microseconds after the producing kernels finish, instead of a
+// hipMemcpyAsync (blit/SDMA setup) + hipStreamSynchronize round trip per BFS level / SSSP step.
+__global__ void vgl_k_publish(const int64_t *counters, volatile int64_t *host, int64_t seq)
+{
+    if (threadIdx.x < C_NSLOTS) host[threadIdx.x] = counters[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { host[C_NSLOTS] = seq; __threadfence_system(); }
+}
+
 int vgl_read_counters(vgl_hip_ctx *c, bool fold_shards)
 {
     if (fold_shards) hipLaunchKernelGGL(vgl_k_fold_shards, dim3(1), dim3(VGL_BLOCK), 0, c->stream, c->d_shards, c->d_counters);
-    VGL_HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(int64_t) * C_NSLOTS, hipMemcpyDeviceToHost, c->stream));
-    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t seq = ++c->publish_seq;
+    hipLaunchKernelGGL(vgl_k_publish, dim3(1), dim3(64), 0, c->stream, c->d_counters, (volatile int64_t *)c->h_counters, seq);
+    VGL_HIP_TRY(hipGetLastError());
+    volatile int64_t *flag = (volatile int64_t *)c->h_counters + C_NSLOTS;
+    for (long spin = 0; *flag != seq; spin++) {
+        if (spin > 2000000) {                          // ~1 s: fall back to a blocking wait (surfaces launch failures too)
+            VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+            if (*flag != seq) VGL_FAIL("counter publish did not arrive");
+            break;
+        }
+        __builtin_ia32_pause();
+    }
     return 0;
 }
 int vgl_zero_counters(vgl_hip_ctx *c, int first, int count)

@@ -49,7 +49,8 @@ struct vgl_hip_ctx {
     bool own_stream = false;
     int64_t *d_counters = nullptr;   // C_NSLOTS
     int64_t *d_shards = nullptr;     // VGL_NSHARD accumulators folded into d_counters[C_EDGES]
-    int64_t *h_counters = nullptr;   // pinned mirror
+    int64_t *h_counters = nullptr;   // pinned mirror (+ publish sequence number at [C_NSLOTS])
+    int64_t publish_seq = 0;
     double *d_partials = nullptr;    // reduction partials (f64), capacity partials_cap
     size_t partials_cap = 0;
     bool timing = false;
