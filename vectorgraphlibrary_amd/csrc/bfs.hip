@@ -154,8 +154,10 @@ constexpr int VGL_BU_BLOCKS = 2048;
 // bitmap, built once per graph: ~45 % of RMAT vertices have none and would otherwise re-read 16 B of row offsets in every
 // bottom-up level).  The first VGL_BU_PROBES incoming neighbours are loaded together and their frontier bits tested
 // together (two dependent memory round trips per vertex).  Writes whole words of the next-frontier bitmap.
+typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte load from a 4-byte aligned address
+
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
-                                                            const int32_t *in_adj, const uint64_t *visited, const uint64_t *in_nz,
+                                                            const int32_t *in_adj, int64_t in_edges, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
                                                             int32_t next_level, int32_t *heavy, int32_t *heavy_cnt, int64_t *partials)
 {
@@ -175,13 +177,26 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
             if (r < nrows && ((cand_word >> (v & 63)) & 1ULL)) {
                 const int64_t b = in_rowptr[r], e = in_rowptr[r + 1];
                 const int n = (int)min((int64_t)VGL_BU_PROBES, e - b);
-                int32_t u[VGL_BU_PROBES];
-#pragma unroll
-                for (int j = 0; j < VGL_BU_PROBES; j++) u[j] = (j < n) ? in_adj[b + j] : -1;
+                // two stages of 4 probes: most candidates find their parent among the first neighbours, and each stage is one
+                // 16-byte (4-byte aligned) adjacency load when it stays inside the array instead of four scattered dword loads
                 uint32_t hit = 0;
 #pragma unroll
-                for (int j = 0; j < VGL_BU_PROBES; j++)
-                    if (u[j] >= 0) hit |= (uint32_t)((front[u[j] >> 6] >> (u[j] & 63)) & 1ULL) << j;
+                for (int stage = 0; stage < VGL_BU_PROBES / 4; stage++) {
+                    if (hit == 0 && stage * 4 < n) {
+                        int32_t u[4];
+                        const int64_t p0 = b + stage * 4;
+                        if (p0 + 4 <= in_edges) {
+                            const vgl_int4_u q = *reinterpret_cast<const vgl_int4_u *>(in_adj + p0);
+                            u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) u[j] = (p0 + j < in_edges) ? in_adj[p0 + j] : 0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (stage * 4 + j < n) hit |= (uint32_t)((front[u[j] >> 6] >> (u[j] & 63)) & 1ULL) << (stage * 4 + j);
+                    }
+                }
                 found = hit != 0;
                 probes += found ? __ffs(hit) : n;        // adjacency entries a sequential scan would have examined
                 defer = !found && (e - b) > VGL_BU_PROBES;
@@ -397,7 +412,7 @@ static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, 
     {
         vgl_timed_launch tl(c, "bfs_bottom_up");
         hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
-                           g->in.rowptr, g->in.adj, visited, g->bm_in_nz, front, next, levels, next_level,
+                           g->in.rowptr, g->in.adj, g->in.edges, visited, g->bm_in_nz, front, next, levels, next_level,
                            g->heavy, g->heavy_cnt, g->bu_partials);
     }
     hipLaunchKernelGGL(vgl_k_bu_heavy_offsets, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->heavy_cnt, g->heavy_off);
