@@ -15,7 +15,7 @@ struct Parser {
     int scale = 10, avg_degree = 5, rounds = 1, source = -1;
     bool rmat = true, check = false, direction_optimising = false, fused = false;
     unsigned long long seed = 1;
-    std::string dump;
+    std::string dump, import_file;
     void parse_args(int argc, char **argv)
     {
         for (int i = 1; i < argc; i++) {
@@ -29,6 +29,7 @@ struct Parser {
             else if (a == "-seed") seed = strtoull(next(), nullptr, 10);
             else if (a == "-dump") dump = next();
             else if (a == "-source") source = atoi(next());
+            else if (a == "-import") import_file = next();          // .el_container written by the reference's create_vgl_graphs
             else if (a == "-do") direction_optimising = true;
             else if (a == "-td") direction_optimising = false;
             else if (a == "-fused") fused = true;
@@ -45,6 +46,11 @@ inline void prepare_graph(VGL_Graph &graph, const Parser &p, DirectionType dir =
 {
     GraphGenerationAPI::seed() = p.seed;
     EdgesContainer ec;
+    if (!p.import_file.empty()) {
+        if (!ec.load_from_binary_file(p.import_file)) throw "Error: can not open the graph file given with -import";
+        graph.import(ec);
+        return;
+    }
     const int v = 1 << p.scale;
     const long long e = (long long)v * p.avg_degree;
     if (p.rmat) GraphGenerationAPI::R_MAT(ec, v, e, 57, 19, 19, 5, dir);      // vgl_runtime.hpp:36

@@ -140,6 +140,9 @@ def main():
                         "bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(per_launch_ms, 5),
                         "launches": kern[dom]["launches"]}
         total_alg = sum(s["algorithmic_bytes"] for s in stats)
+        # the reference's own accounting (settings.h:140-155, INT_ELEMENTS_PER_EDGE = 4 for BFS, apps/bfs/bfs.cpp:3): 16 B per edge
+        # of the GRAPH per traversal, whatever was actually touched -- reported for comparability only
+        extra["vgl_accounting_GBps"] = round(16.0 * E * args.steps / dt / 1e9, 1)
         extra["bfs"] = {"kernels": kern, "levels_per_bfs": levels / len(stats), "td_steps": td_steps, "bu_steps": bu_steps,
                         "edges_examined_per_bfs": (bu_edges + td_edges) / len(stats),
                         "whole_bfs_algorithmic_GBps": round(total_alg / dt / 1e9, 2),

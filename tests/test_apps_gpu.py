@@ -85,3 +85,21 @@ def test_operator_api_error_convention(tmp_path, ctx):
     """errors surface as thrown C strings caught in main, like the reference (apps/bfs/bfs.cpp:53-61)."""
     out = subprocess.run([os.path.join(BIN, "bfs_hip"), "-bogus"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "unknown command line option" in out.stdout
+
+
+def test_import_el_container(tmp_path, oracle, ctx):
+    """-import reads the reference's EdgesContainer binary format (edges_container.h:58-99), here written by the oracle helper
+    with an arbitrary (non power-of-two) vertex count."""
+    O = oracle
+    rng = np.random.default_rng(7)
+    V, E = 3001, 20000
+    src, dst = rng.integers(0, V, E).astype(np.int32), rng.integers(0, V, E).astype(np.int32)
+    path = str(tmp_path / "g.el_container")
+    O.write_el_container(path, V, src, dst)
+    rowptr, adj, _ = O.coo_to_csr(V, src, dst)
+    source = O.pick_source(rowptr, 7)
+    ref = O.bfs_top_down(rowptr, adj, source)[0]
+    for mode in ([], ["-fused", "-do"]):
+        out, dump = run_app("bfs", ["-import", path, "-source", source, "-check"] + mode, tmp_path)
+        assert "error count: 0" in out
+        assert (np.fromfile(dump, np.int32) == ref).all()

@@ -118,6 +118,34 @@ public:
     int *get_dst_ids() { return dst_ids; }
     int get_vertices_count() const { return vertices_count; }
     long long get_edges_count() const { return edges_count; }
+    // EdgesContainer binary file (edges_container.h:58-99): int V; long long E; int type = EDGES_CONTAINER (4); int src[E]; int dst[E]
+    bool save_to_binary_file(const std::string &file_name)
+    {
+        FILE *f = fopen(file_name.c_str(), "wb");
+        if (!f) return false;
+        std::vector<int> s((size_t)edges_count), d((size_t)edges_count);
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), s.data(), src_ids, s.size() * sizeof(int)));
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), d.data(), dst_ids, d.size() * sizeof(int)));
+        const int type = 4;
+        fwrite(&vertices_count, sizeof(int), 1, f); fwrite(&edges_count, sizeof(long long), 1, f); fwrite(&type, sizeof(int), 1, f);
+        fwrite(s.data(), sizeof(int), s.size(), f); fwrite(d.data(), sizeof(int), d.size(), f);
+        fclose(f);
+        return true;
+    }
+    bool load_from_binary_file(const std::string &file_name)
+    {
+        FILE *f = fopen(file_name.c_str(), "rb");
+        if (!f) return false;
+        int v = 0, type = 0; long long e = 0;
+        if (fread(&v, sizeof(int), 1, f) != 1 || fread(&e, sizeof(long long), 1, f) != 1 || fread(&type, sizeof(int), 1, f) != 1) { fclose(f); return false; }
+        if (type != 4) { fclose(f); throw "Error in EdgesContainer::load_from_binary_file : incorrect type of graph in file"; }
+        std::vector<int> s((size_t)e), d((size_t)e);
+        const bool ok = fread(s.data(), sizeof(int), (size_t)e, f) == (size_t)e && fread(d.data(), sizeof(int), (size_t)e, f) == (size_t)e;
+        fclose(f);
+        if (!ok) return false;
+        load_from_host(v, s, d);
+        return true;
+    }
     void load_from_host(int v, const std::vector<int> &s, const std::vector<int> &d)
     {
         resize(v, (long long)s.size());
