@@ -422,3 +422,36 @@ def test_degree_renumbered_graph(kind, case, ctx, oracle):
     gs = api.Graph.from_coo(ctx, V, s2, d2, renumber=kind)
     assert (api.connected_components(gs)[0].cpu().numpy() == z["comp_csr"]).all()
     gs.close()
+
+
+@pytest.mark.parametrize("V,edges", [(1, []), (1, [(0, 0)]), (5, []), (5, [(0, 1), (1, 2), (4, 4), (2, 0)]), (70, [(69, 0), (0, 69), (3, 3)])])
+def test_degenerate_graphs(V, edges, ctx, oracle):
+    """smallest inputs: a single vertex, no edges at all, only a self loop, V below one wavefront / one bitmap word."""
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    src = np.array([e[0] for e in edges], np.int32)
+    dst = np.array([e[1] for e in edges], np.int32)
+    g = api.Graph.from_coo(ctx, V, torch.from_numpy(src).to(ctx.device), torch.from_numpy(dst).to(ctx.device), want_perm=True)
+    rowptr, adj, perm = O.coo_to_csr(V, src, dst)
+    assert (g.out_rowptr.cpu().numpy() == rowptr).all()
+    for source in {0, V - 1}:
+        ref, _ = O.bfs_top_down(rowptr, adj, source)
+        for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+            lv, st = api.bfs(g, source, mode)
+            assert (lv.cpu().numpy() == ref).all() and st["discovered"] == int((ref > 0).sum())
+        w = np.linspace(1.0, 2.0, len(src), dtype=np.float32)[perm] if len(src) else np.zeros(0, np.float32)
+        w_d = torch.from_numpy(w).to(ctx.device) if len(src) else torch.zeros(1, device=ctx.device)
+        dref, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
+        for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
+            d, _ = api.sssp(g, w_d, source, mode, delta=0.5)
+            assert (d.cpu().numpy().view(np.int32) == dref.view(np.int32)).all()
+    assert (api.connected_components(g)[0].cpu().numpy() == O.cc_sv(rowptr, adj)[0]).all()
+    rk = api.page_rank(g, 3)[0].cpu().numpy()
+    assert (rk.view(np.int32) == O.pagerank(rowptr, adj, 3, 1).view(np.int32)).all()
+    f = api.Frontier(g)
+    assert f.info() == (V, len(src), api.ALL_ACTIVE)
+    f.generate_from_flags(torch.zeros(V, dtype=torch.int32, device=ctx.device))
+    assert f.size() == 0 and f.ids().numel() == 0
+    f.close()
+    g.close()
