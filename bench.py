@@ -4,7 +4,9 @@
 One "step" = one BFS traversal of the synthetic graph from a fresh random non-isolated source
 (apps/bfs/bfs.cpp:36-40; TEPS = E_graph / time, performance_stats.hpp:272-275).
 N=1   : BASELINE configs[1] "BFS direction-optimising on RMAT scale-24, 1xMI355X" (graph resident in HBM).
-N>1   : the same graph, edge-cut into N shards (one process per GPU, bitmap exchange over RCCL) -> strong scaling.
+N>1   : weak scaling (default): RMAT scale 24+log2(N) (RMAT-27 at 8 GPUs, BASELINE configs[2]), every rank streams the
+        counter-based generator and keeps its edge-cut shard (~2^29 edges per GPU at every N), one process per GPU, bitmap
+        all-gather over RCCL per level.  `--scaling strong` shards the scale-24 graph instead.
 Prints ONE JSON line on rank 0 with the driver contract keys plus `roofline` (dominant kernel, algorithmic bytes per
 launch / HIP-event duration measured in the timed region) and `cpu_baseline` (the oracle's OpenMP port of the
 reference top-down BFS on the same graph, timed on the host cores; N=1 only).  Extra keys carry the SSSP numbers.
@@ -35,10 +37,10 @@ def pmc_traffic(timing_name):
     return rec["hbm_bytes_raw"] if rec else None
 
 
-def pick_sources(rowptr_dev, n, seed):
+def pick_sources(rowptr_dev, n, seed, degrees=None):
     """deterministic random non-isolated sources (VGL_Graph::select_random_nz_vertex)."""
     import torch
-    deg = rowptr_dev[1:] - rowptr_dev[:-1]
+    deg = degrees if degrees is not None else rowptr_dev[1:] - rowptr_dev[:-1]
     nz = torch.nonzero(deg > 0).flatten()
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
@@ -58,6 +60,9 @@ def main():
     ap.add_argument("--no-sssp", action="store_true")
     ap.add_argument("--cpu-sources", type=int, default=3)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU super-step path even with one rank (debug)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = RMAT scale+log2(N) built shard-by-shard (default), strong = the scale-24 graph cut N ways")
+    ap.add_argument("--chunk-edges", type=int, default=1 << 27, help="generator chunk of the streaming shard build")
     ap.add_argument("--sssp-delta", type=float, default=16.0)
     ap.add_argument("--renumber", default="total", choices=["none", "out", "in", "total"],
                     help="VectCSR-style degree renumbering of the stored graph (vect_csr/import.hpp:61-99)")
@@ -78,17 +83,27 @@ def main():
     ctx = api.Context(local_rank if world > 1 else 0)
 
     scale, ef, seed = args.scale, args.edge_factor, args.seed
+    renumber = None if args.renumber == "none" else args.renumber
+    sharded = world > 1 or args.force_sharded
+    weak = sharded and args.scaling == "weak"
+    if weak:
+        scale += max(world, 1).bit_length() - 1              # per-GPU edges stay ~2^scale * ef
     V, E = 1 << scale, (1 << scale) * ef
     t_build = time.time()
-    src, dst = ctx.gen_rmat(scale, ef, seed)
-    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True, want_perm=not args.no_sssp,
-                           renumber=None if args.renumber == "none" else args.renumber)
-    del src, dst
+    if weak:
+        g = None
+        shard, degrees, bounds = vd.build_generated_shard(ctx, scale, ef, seed, rank, world, kind="rmat", renumber=renumber,
+                                                          chunk_edges=args.chunk_edges, placement="dealt")
+        sources = pick_sources(None, args.steps + args.warmup, seed, degrees=degrees)
+    else:
+        src, dst = ctx.gen_rmat(scale, ef, seed)
+        g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True, want_perm=not args.no_sssp and not sharded, renumber=renumber)
+        del src, dst
+        # sources are ids of the stored (renumbered) graph; like the reference, conversions to/from ORIGINAL ids happen
+        # outside the timed region (bfs.hpp:62-85), so the timed calls use raw=True
+        sources = pick_sources(g.out_rowptr, args.steps + args.warmup, seed)
     ctx.sync()
     t_build = time.time() - t_build
-    # sources are ids of the stored (renumbered) graph; like the reference, conversions to/from ORIGINAL ids happen outside
-    # the timed region (bfs.hpp:62-85), so the timed calls use raw=True
-    sources = pick_sources(g.out_rowptr, args.steps + args.warmup, seed)
 
     def barrier():
         if world > 1:
@@ -98,7 +113,7 @@ def main():
     extra = {}
     roofline = None
     cpu_baseline = None
-    if world == 1 and not args.force_sharded:
+    if not sharded:
         for s in sources[:args.warmup]:
             api.bfs(g, s, api.BFS_DIRECTION_OPT, raw=True)
         ctx.timing(True)
@@ -219,17 +234,21 @@ def main():
         workload = f"BFS direction-optimising on RMAT scale-{scale} (edge factor {ef}), 1xMI355X"
         scaling = "weak"
     else:
-        # edge-cut shards of the SAME graph: strong scaling.  Top-down super-steps with bitmap all-gather.
-        bounds = ctx.partition_rows(g.out_rowptr, world)
-        shard = g.shard(bounds[rank], bounds[rank + 1]) if world > 1 else g
+        # edge-cut shards, direction-optimising super-steps with a bitmap all-gather per level
+        if not weak:
+            bounds = ctx.partition_rows(g.out_rowptr, world)
+            shard = g.shard(bounds[rank], bounds[rank + 1]) if world > 1 else g
+            degrees = (g.out_rowptr[1:] - g.out_rowptr[:-1]).to(torch.int32)  # replicated out-degrees for the direction rule
+            if world > 1:
+                g.close()
+                g.out_adj = g.in_adj = None                                   # keep only the shard resident
         ops = vd.HipShardOps(shard)
-        degrees = (g.out_rowptr[1:] - g.out_rowptr[:-1]).to(torch.int32)      # replicated out-degrees for the direction rule
         for s in sources[:args.warmup]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E)
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1)
         barrier()
         t0 = time.perf_counter()
         for s in sources[args.warmup:]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E)
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -239,14 +258,14 @@ def main():
         extra["shard_edges"] = int(shard.E)
         workload = (f"BFS direction-optimising super-steps (bitmap all-gather per level) on RMAT scale-{scale} "
                     f"(edge factor {ef}), edge-cut over {world} GPUs")
-        scaling = "strong"
+        scaling = "weak" if weak else "strong"
 
     if rank == 0:
         out = {
             "metric": "TEPS (edges/s) BFS on RMAT-%d" % scale, "value": round(args.steps * E / dt, 1), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": workload, "vertices": V, "edges": E, "seed": seed, "parallelism": f"edge-cut x{world}",
+            "config": {"workload": workload, "vertices": V, "edges": E, "seed": seed, "parallelism": f"edge-cut x{world}" + (" (64-vertex blocks dealt round-robin)" if weak else ""),
                        "vertex_numbering": "identity" if args.renumber == "none" else f"degree-sorted ({args.renumber})",
                        "graph_build_s": round(t_build, 2)},
         }

@@ -74,6 +74,11 @@ int vgl_hip_gather_u32(vgl_hip_ctx *ctx, int64_t n, const int64_t *d_perm, const
  * mostly hit the XCD L2 instead of costing a fabric line each.  Synchronises. */
 int vgl_hip_degree_order(vgl_hip_ctx *ctx, int32_t V, int64_t count, const int32_t *d_src, const int32_t *d_dst,
                          int degree_kind, int32_t *d_fwd, int32_t *d_bwd);
+/* the two halves of vgl_hip_degree_order for inputs that are produced in chunks (scale-27 shards): accumulate degrees of a
+ * chunk into d_degree (uint32[V], zeroed by the caller), then derive the order from the finished histogram. */
+int vgl_hip_degree_hist_add(vgl_hip_ctx *ctx, int64_t count, const int32_t *d_src, const int32_t *d_dst, int degree_kind,
+                            uint32_t *d_degree);
+int vgl_hip_degree_order_from_degrees(vgl_hip_ctx *ctx, int32_t V, const uint32_t *d_degree, int32_t *d_fwd, int32_t *d_bwd);
 /* out[i] = map[in[i]] (relabel ids) and out[i] = in[idx[i]] (permute a vertex array) for 4-byte elements */
 int vgl_hip_relabel_i32(vgl_hip_ctx *ctx, int64_t n, const int32_t *d_map, const int32_t *d_in, int32_t *d_out);
 int vgl_hip_permute_u32(vgl_hip_ctx *ctx, int64_t n, const int32_t *d_idx, const void *d_in, void *d_out);
@@ -203,6 +208,12 @@ int vgl_hip_bfs_step_top_down(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_lev
 /* bottom-up step over the owned rows (needs the incoming CSR): unvisited owned vertices with an in-neighbour in the frontier
  * bitmap get levels = level+1.  d_next_bits (V bits) receives exactly this rank's discoveries (other words zero), ready for
  * the bitmap exchange.  found / probed (optional, synchronise): discovered vertices, adjacency entries examined. */
+/* top-down step driven by the replicated bitmaps: the owned part of the frontier is read from d_front_bits (V/64 words instead
+ * of a scan of levels), every vertex this shard discovers gets levels[v] = level+1 and its bit in d_next_bits (cleared here,
+ * full length: destinations live in any shard).  d_next_bits is what the shard contributes to the exchange. */
+int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *ctx, vgl_hip_graph *graph, int32_t *d_levels, int32_t level,
+                                   const uint64_t *d_visited_bits, const uint64_t *d_front_bits, uint64_t *d_next_bits,
+                                   int64_t *local_frontier, int64_t *local_edges);
 int vgl_hip_bfs_step_bottom_up(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_levels, int32_t level,
                                const uint64_t *d_visited_bits, const uint64_t *d_front_bits, uint64_t *d_next_bits,
                                int64_t *found, int64_t *probed);

@@ -45,6 +45,21 @@ class NumpyShardOps:
         lv[tgt] = level + 1
         return int(((lv[self.lo:self.hi]) == level).sum()), int(m.sum())
 
+    def row_range(self):
+        return self.lo, self.hi
+
+    def bfs_step_bits(self, levels, level, visited, front, mine):
+        lv = levels.numpy()
+        fr, vis = self._unpack(front), self._unpack(visited)
+        m = fr[self.es]
+        tgt = self.ed[m]
+        tgt = tgt[~vis[tgt]]
+        lv[tgt] = level + 1
+        found = np.zeros(self.V, bool)
+        found[tgt] = True
+        self._pack(found, mine)
+        return int(fr[self.lo:self.hi].sum()), int(m.sum())
+
     def levels_to_bitmap(self, levels, level, bits):
         b = np.zeros(((self.V + 63) // 64) * 64, np.uint8)
         b[:self.V] = levels.numpy() == level
@@ -160,6 +175,10 @@ def _worker(rank, world, port, results):
     degrees = torch.from_numpy(np.diff(rowptr).astype(np.int32))
     levels_do, _ = vd.bfs_sharded(ops, source, degrees=degrees, edges=len(adj))
     assert (levels_do.numpy() == levels.numpy()).all(), "direction-optimising sharded BFS != top-down sharded BFS"
+    # equal row ranges: bottom-up levels exchange owned slices only
+    eq = NumpyShardOps(V, rowptr, adj, w, rank * (V // world), (rank + 1) * (V // world))
+    levels_eq, _ = vd.bfs_sharded(eq, source, degrees=degrees, edges=len(adj), equal_ranges=True)
+    assert (levels_eq.numpy() == levels.numpy()).all(), "sliced exchange (equal ranges) != full-bitmap exchange"
     d, _ = vd.sssp_sharded(ops, source)
     comp, _ = vd.cc_sharded(ops)
     ranks = vd.page_rank_sharded(ops, 3, bounds[rank], bounds[rank + 1])

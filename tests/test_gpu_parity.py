@@ -455,3 +455,107 @@ def test_degenerate_graphs(V, edges, ctx, oracle):
     assert f.size() == 0 and f.ids().numel() == 0
     f.close()
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,renumber,placement", [("rmat", "total", "ranges"), ("rmat", None, "ranges"), ("ru", "out", "ranges"),
+                                                     ("rmat", "total", "dealt"), ("ru", None, "dealt")])
+def test_generated_shards_match_whole_graph_build(kind, renumber, placement, ctx, oracle):
+    """distributed.build_generated_shard (chunked streaming build for graphs larger than one GPU) produces exactly the
+    shards Graph.from_coo(...).shard() cuts from the whole graph (incoming lists as per-row multisets), and the sharded
+    direction-optimising BFS over them reproduces the oracle's levels."""
+    import torch
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import distributed as vd
+    O = oracle
+    scale, ef, seed = 13, 16, 77
+    P = 4 if placement == "dealt" else 3
+    V, E = 1 << scale, (1 << scale) * ef
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    if placement == "dealt":
+        # reference build: relabel the edge list with the shard's own original->stored map, cut equal ranges
+        s0, _, bounds = vd.build_generated_shard(ctx, scale, ef, seed, 0, P, kind=kind, renumber=renumber, placement=placement)
+        assert bounds == [p * (V // P) for p in range(P + 1)]
+        f = s0.fwd
+        assert torch.equal(torch.sort(f).values, torch.arange(V, device=ctx.device, dtype=torch.int32))
+        assert torch.equal(s0.bwd[f.long()], torch.arange(V, device=ctx.device, dtype=torch.int32))
+        if renumber:       # the stored order deals the 64-blocks of the degree order round-robin
+            pure = api.Graph.from_coo(ctx, V, src, dst, renumber=renumber, with_incoming=False)
+            pos = pure.fwd.long()
+            want = ((pos >> 6) % P) * (V // P) + ((pos >> 6) // P) * 64 + (pos & 63)
+            assert torch.equal(f.long(), want)
+            pure.close()
+        whole = api.Graph.from_coo(ctx, V, ctx.relabel(f, src), ctx.relabel(f, dst))
+        whole.fwd, whole.bwd = s0.fwd, s0.bwd
+        s0.close()
+        edges = [int(whole.out_rowptr[bounds[p + 1]] - whole.out_rowptr[bounds[p]]) for p in range(P)]
+        assert sum(edges) == E and (kind == "rmat" or max(edges) < 1.25 * E / P), edges   # tiny RMAT: the first 64 hubs dominate
+    else:
+        whole = api.Graph.from_coo(ctx, V, src, dst, renumber=renumber)
+        bounds = ctx.partition_rows(whole.out_rowptr, P)
+    shards = []
+    for p in range(P):
+        s, degrees, b = vd.build_generated_shard(ctx, scale, ef, seed, p, P, kind=kind, renumber=renumber, chunk_edges=30011,
+                                                 placement=placement)
+        assert b == bounds
+        ref = whole.shard(bounds[p], bounds[p + 1])
+        assert torch.equal(s.out_rowptr, ref.out_rowptr) and torch.equal(s.out_adj, ref.out_adj)
+        assert torch.equal(s.in_rowptr, ref.in_rowptr)
+        rows = torch.repeat_interleave(torch.arange(s.in_rowptr.numel() - 1, device=ctx.device), s.in_rowptr[1:] - s.in_rowptr[:-1])
+        key = lambda g: torch.sort(rows * V + g.in_adj.to(torch.int64)).values
+        assert torch.equal(key(s), key(ref))
+        assert torch.equal(degrees, (whole.out_rowptr[1:] - whole.out_rowptr[:-1]).to(torch.int32))
+        if renumber or placement == "dealt":
+            assert torch.equal(s.fwd, whole.fwd) and torch.equal(s.bwd, whole.bwd)
+        ref.close()
+        shards.append(s)
+    rowptr, adj = whole.out_rowptr.cpu().numpy(), whole.out_adj.cpu().numpy()
+    source = O.pick_source(rowptr, seed)
+    want, _ = O.bfs_top_down(rowptr, adj, source)
+    # shards driven in lock-step from one process (the collective is the concatenation of the per-shard bitmaps)
+    ops = [vd.HipShardOps(s) for s in shards]
+    words = (V + 63) // 64
+    reps = [o.new_i32() for o in ops]
+    vis, fr = [o.new_words(1) for o in ops], [o.new_words(1) for o in ops]
+    for o, r, v_, f_ in zip(ops, reps, vis, fr):
+        o.bfs_init(r, source)
+        o.levels_to_bitmap(r, 1, f_)
+        v_.copy_(f_)
+    level = 1
+    while True:
+        everyone = ops[0].new_words(P)
+        parts, bits = P, everyone
+        for p, (o, r) in enumerate(zip(ops, reps)):
+            mine = everyone[p * words:(p + 1) * words]
+            if level % 3 == 1:
+                o.bfs_step_bits(r, level, vis[p], fr[p], mine)
+            elif level % 3 == 2:
+                o.bfs_step(r, level, vis[p])
+                o.levels_to_bitmap(r, level + 1, mine)
+            else:
+                o.bfs_step_bu(r, level, vis[p], fr[p], mine)
+        if placement == "dealt" and level % 3 == 0:          # bottom-up level: owned slices concatenate to the merged bitmap
+            lo = [b // 64 for b in bounds]
+            parts, bits = 1, torch.cat([everyone[p * words + lo[p]:p * words + lo[p + 1]] for p in range(P)])
+        res = [o.apply_bitmaps(parts, bits, r, level + 1, vis[p], fr[p], degrees) for p, (o, r) in enumerate(zip(ops, reps))]
+        assert len(set(res)) == 1
+        if res[0][0] == 0:
+            break
+        level += 1
+    for r in reps:
+        assert (r.cpu().numpy() == want).all()
+    # world size 1 through the driver
+    one, degrees, _ = vd.build_generated_shard(ctx, scale, ef, seed, 0, 1, kind=kind, renumber=renumber, chunk_edges=50000,
+                                               placement=placement)
+    got, _ = vd.bfs_sharded(vd.HipShardOps(one), source, degrees=degrees, edges=E)
+    if placement == "dealt":       # world 1: dealing is the identity on positions, i.e. the plain renumbered graph
+        src1 = one.vertex_id(int(whole.bwd[source]))
+        got, _ = vd.bfs_sharded(vd.HipShardOps(one), src1, degrees=degrees, edges=E)
+        got = one.to_original(got)
+        want1 = whole.to_original(torch.from_numpy(want).to(ctx.device))
+        assert torch.equal(got, want1)
+    else:
+        assert (got.cpu().numpy() == want).all()
+    for s in shards + [one]:
+        s.close()
+    whole.close()

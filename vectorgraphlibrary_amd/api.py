@@ -103,6 +103,17 @@ class Context:
         _l.check(self.L.vgl_hip_degree_order(self.h, V, src.numel(), _ptr(src), _ptr(dst), k, _ptr(fwd), _ptr(bwd)))
         return fwd, bwd
 
+    def degree_hist_add(self, src, dst, kind, degree):
+        """degree[v] += degree of v in the chunk (src,dst); degree is a zero-initialised 4-byte vertex array"""
+        k = {"out": 0, "in": 1, "total": 2}[kind]
+        _l.check(self.L.vgl_hip_degree_hist_add(self.h, src.numel(), _ptr(src), _ptr(dst), k, _ptr(degree)))
+
+    def degree_order_from_degrees(self, degree):
+        V = degree.numel()
+        fwd, bwd = self.empty(V, torch.int32), self.empty(V, torch.int32)
+        _l.check(self.L.vgl_hip_degree_order_from_degrees(self.h, V, _ptr(degree), _ptr(fwd), _ptr(bwd)))
+        return fwd, bwd
+
     def relabel(self, mapping, ids):
         out = torch.empty_like(ids)
         _l.check(self.L.vgl_hip_relabel_i32(self.h, ids.numel(), _ptr(mapping), _ptr(ids), _ptr(out)))

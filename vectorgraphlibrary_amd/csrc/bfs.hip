@@ -323,25 +323,45 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_bitmaps(int32_t V, int 
                                                                  int32_t *levels, int32_t level, uint64_t *visited, uint64_t *front,
                                                                  const int32_t *degrees, int64_t *partials)
 {
+    // one bitmap word per lane (coalesced OR over the parts; almost all words are zero on small levels), then the wavefront
+    // walks its non-zero words together so that the levels / degrees accesses of a word are one coalesced 256-byte row
     __shared__ int64_t s64[VGL_WAVES];
     int64_t cnt = 0, deg = 0;
-    const int32_t vround = (V + 63) & ~63;
-    for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < vround; v += gridDim.x * VGL_BLOCK) {
+    const int lane = vgl_lane();
+    const int64_t wround = (words + 63) & ~(int64_t)63;
+    for (int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; wi < wround; wi += (int64_t)gridDim.x * VGL_BLOCK) {
         uint64_t w = 0;
-        for (int p = 0; p < parts; p++) w |= bits_all[(int64_t)p * words + (v >> 6)];   // wave-uniform loads
-        bool is_new = false;
-        if (v < V && ((w >> (v & 63)) & 1ULL)) {
-            const int32_t l = levels[v];
-            if (l == -1) levels[v] = level;
-            is_new = (l == -1) || (l == level);
+        if (wi < words) {
+            for (int p = 0; p < parts; p++) w |= bits_all[(int64_t)p * words + wi];
+            if (visited) {                       // replicated visited bitmap: new = reported and not yet visited
+                const uint64_t vis = visited[wi];
+                w &= ~vis;
+                if (w) visited[wi] = vis | w;
+            }
         }
-        const unsigned long long nm = __ballot(is_new);
-        if (vgl_lane() == 0) {
-            if (front) front[v >> 6] = nm;
-            if (visited) visited[v >> 6] |= nm;
+        unsigned long long todo = __ballot(w != 0);
+        uint64_t mine_new = visited ? w : 0;
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint64_t ww = __shfl(w, l);
+            const int64_t v = ((wi - lane + l) << 6) + lane;
+            bool is_new = false;
+            if (v < V && ((ww >> lane) & 1ULL)) {
+                if (visited) { levels[v] = level; is_new = true; }
+                else {                            // no bitmap: levels decides (vertices of this level were marked by their finder)
+                    const int32_t lv = levels[v];
+                    if (lv == -1) levels[v] = level;
+                    is_new = (lv == -1) || (lv == level);
+                }
+                if (is_new && degrees) deg += degrees[v];
+            }
+            if (!visited) { const unsigned long long nm = __ballot(is_new); if (lane == l) mine_new = nm; }
         }
-        cnt += is_new;
-        if (is_new && degrees) deg += degrees[v];
+        if (wi < words) {
+            if (front) front[wi] = mine_new;
+            cnt += __popcll(mine_new);
+        }
     }
     cnt = vgl_block_reduce_add(cnt, s64);
     deg = vgl_block_reduce_add(deg, s64);
@@ -379,7 +399,7 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
 }
 
 // frontier of the current level from bm_front (owned words): counts + totals (read back), optionally ids + edge offsets
-static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, bool count, bool write)
+static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write)
 {
     const int64_t word0 = g->row_begin >> 6;
     const int64_t nwords = vgl_ceil_div(g->row_end, 64) - word0;
@@ -387,7 +407,7 @@ static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, bool count, bool wri
     if (count) {
         {
             vgl_timed_launch tl(c, "gnf");
-            hipLaunchKernelGGL(vgl_k_bm_gnf_count, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, g->bm_front,
+            hipLaunchKernelGGL(vgl_k_bm_gnf_count, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, front,
                                g->out.rowptr, g->vt_cnt, g->vt_deg);
         }
         hipLaunchKernelGGL(vgl_k_gnf_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, (int64_t)nb, g->vt_cnt, g->vt_deg, g->vt_cnt_off,
@@ -397,7 +417,7 @@ static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, bool count, bool wri
     }
     if (write) {
         vgl_timed_launch tl(c, "gnf");
-        hipLaunchKernelGGL(vgl_k_bm_gnf_write, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, g->bm_front,
+        hipLaunchKernelGGL(vgl_k_bm_gnf_write, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, front,
                            g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
         VGL_HIP_TRY(hipGetLastError());
     }
@@ -464,7 +484,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     const int64_t factor = std::max<int64_t>(1, (E / V) / 2);     // change_state.hpp:104
     constexpr int64_t VGL_TD_EMIT_EDGES = 16 << 20;
     auto count_frontier = [&]() -> int {
-        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, true, false)); counted_from_bitmap = true; }
+        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false)); counted_from_bitmap = true; }
         else {
             vgl_pred_equal_i32 pred{d_levels, cur};
             VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, nullptr, false, true));
@@ -492,7 +512,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         prevF = F;
         if (!bottom_up) {
             if (!counted) VGL_FAIL("bfs_run: internal error (frontier not counted)");
-            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, false, true));
+            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, false, true));
             else {
                 vgl_pred_equal_i32 pred{d_levels, cur};
                 vgl_timed_launch tl(c, "gnf");
@@ -555,6 +575,27 @@ int vgl_hip_bfs_step_top_down(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_level
     return 0;                                    // enqueued; the caller's next call on this context orders after it
 }
 
+int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_levels, int32_t level, const uint64_t *d_visited_bits,
+                                   const uint64_t *d_front_bits, uint64_t *d_next_bits, int64_t *local_frontier, int64_t *local_edges)
+{
+    if (!c || !g || !d_levels || !d_visited_bits || !d_front_bits || !d_next_bits) VGL_FAIL("bfs_step_top_down_bits: null argument");
+    if (g->row_begin & 63) VGL_FAIL("bfs_step_top_down_bits: the first owned row must be a multiple of 64");
+    VGL_HIP_TRY(hipMemsetAsync(d_next_bits, 0, sizeof(uint64_t) * (size_t)vgl_ceil_div(g->V, 64), c->stream));
+    VGL_TRY(vgl_bfs_bm_gnf(c, g, d_front_bits, true, true));     // owned part of the frontier: ids + edge offsets
+    const int64_t F = c->h_counters[C_FRONT], M = c->h_counters[C_NEIGH];
+    if (local_frontier) *local_frontier = F;
+    if (local_edges) *local_edges = M;
+    if (F > 0 && M > 0) {
+        hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, (int32_t)F, g->offs, g->tile_first);
+        vgl_timed_launch tl(c, "bfs_top_down");
+        hipLaunchKernelGGL(vgl_k_td_expand<true>, dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
+                           g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, d_visited_bits, d_levels, level + 1,
+                           d_next_bits);
+    }
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int vgl_hip_bfs_step_bottom_up(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_levels, int32_t level, const uint64_t *d_visited_bits,
                                const uint64_t *d_front_bits, uint64_t *d_next_bits, int64_t *found, int64_t *probed)
 {
@@ -585,7 +626,7 @@ int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *c, int32_t V, int parts, const uint64
 {
     if (!c || !d_bits_all || !d_levels) VGL_FAIL("bfs_apply_bitmaps: null argument");
     if (parts < 1) VGL_FAIL("bfs_apply_bitmaps: parts must be >= 1");
-    const int nb = (int)vgl_grid(V, 1024);
+    const int nb = (int)vgl_grid(vgl_ceil_div(V, 64), 1024);
     VGL_TRY(vgl_ensure_partials(c, (size_t)nb * 2 + 2));
     int64_t *partials = reinterpret_cast<int64_t *>(c->d_partials);
     hipLaunchKernelGGL(vgl_k_apply_bitmaps, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, V, parts, vgl_ceil_div(V, 64), d_bits_all,

@@ -258,22 +258,40 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
     return 0;
 }
 
+int vgl_hip_degree_hist_add(vgl_hip_ctx *c, int64_t count, const int32_t *d_src, const int32_t *d_dst, int degree_kind, uint32_t *d_degree)
+{
+    if (!c || !d_src || !d_dst || !d_degree) VGL_FAIL("degree_hist_add: null argument");
+    if (degree_kind < 0 || degree_kind > 2) VGL_FAIL("degree_hist_add: degree_kind must be 0 (out), 1 (in) or 2 (in+out)");
+    if (count > 0) hipLaunchKernelGGL(vgl_k_degree_hist, dim3(vgl_grid_for(count)), dim3(VGL_BLOCK), 0, c->stream, count, d_src, d_dst, degree_kind, d_degree);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int vgl_hip_degree_order(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *d_src, const int32_t *d_dst, int degree_kind,
                          int32_t *d_fwd, int32_t *d_bwd)
 {
     if (!c || !d_src || !d_dst || !d_fwd || !d_bwd) VGL_FAIL("degree_order: null argument");
-    if (degree_kind < 0 || degree_kind > 2) VGL_FAIL("degree_order: degree_kind must be 0 (out), 1 (in) or 2 (in+out)");
+    uint32_t *deg = nullptr;
+    VGL_HIP_TRY(hipMalloc((void **)&deg, sizeof(uint32_t) * (size_t)V));
+    VGL_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(uint32_t) * (size_t)V, c->stream));
+    int rc = vgl_hip_degree_hist_add(c, count, d_src, d_dst, degree_kind, deg);
+    if (rc == 0) rc = vgl_hip_degree_order_from_degrees(c, V, deg, d_fwd, d_bwd);
+    hipStreamSynchronize(c->stream);
+    hipFree(deg);
+    return rc;
+}
+
+int vgl_hip_degree_order_from_degrees(vgl_hip_ctx *c, int32_t V, const uint32_t *deg, int32_t *d_fwd, int32_t *d_bwd)
+{
+    if (!c || !deg || !d_fwd || !d_bwd) VGL_FAIL("degree_order_from_degrees: null argument");
     hipStream_t st = c->stream;
-    uint32_t *deg = nullptr, *keys = nullptr, *keys_out = nullptr;
+    uint32_t *keys = nullptr, *keys_out = nullptr;
     int32_t *ids = nullptr;
     void *temp = nullptr;
     size_t need = 0;
-    VGL_HIP_TRY(hipMalloc((void **)&deg, sizeof(uint32_t) * (size_t)V));
     VGL_HIP_TRY(hipMalloc((void **)&keys, sizeof(uint32_t) * (size_t)V));
     VGL_HIP_TRY(hipMalloc((void **)&keys_out, sizeof(uint32_t) * (size_t)V));
     VGL_HIP_TRY(hipMalloc((void **)&ids, sizeof(int32_t) * (size_t)V));
-    VGL_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(uint32_t) * (size_t)V, st));
-    if (count > 0) hipLaunchKernelGGL(vgl_k_degree_hist, dim3(vgl_grid_for(count)), dim3(VGL_BLOCK), 0, st, count, d_src, d_dst, degree_kind, deg);
     hipLaunchKernelGGL(vgl_k_order_keys, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, st, V, deg, keys, ids);
     VGL_HIP_TRY(hipGetLastError());
     VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys_out, ids, d_bwd, (size_t)V, 0, 32, st));
@@ -282,7 +300,7 @@ int vgl_hip_degree_order(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t
     hipLaunchKernelGGL(vgl_k_invert, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, st, V, d_bwd, d_fwd);
     VGL_HIP_TRY(hipGetLastError());
     VGL_HIP_TRY(hipStreamSynchronize(st));
-    hipFree(temp); hipFree(deg); hipFree(keys); hipFree(keys_out); hipFree(ids);
+    hipFree(temp); hipFree(keys); hipFree(keys_out); hipFree(ids);
     return 0;
 }
 

@@ -57,6 +57,16 @@ class HipShardOps:
         _l.check(self.L.vgl_hip_bfs_step_top_down(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), C.byref(f), C.byref(m)))
         return f.value, m.value
 
+    def row_range(self):
+        return self.g.row_begin, self.g.row_end
+
+    def bfs_step_bits(self, levels, level, visited, front, mine):
+        """top-down step from the replicated frontier bitmap; `mine` receives the bitmap of this shard's discoveries"""
+        f, m = C.c_int64(), C.c_int64()
+        _l.check(self.L.vgl_hip_bfs_step_top_down_bits(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), _ptr(front),
+                                                       _ptr(mine), C.byref(f), C.byref(m)))
+        return f.value, m.value
+
     def bfs_step_bu(self, levels, level, visited, front, mine):
         _l.check(self.L.vgl_hip_bfs_step_bottom_up(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), _ptr(front), _ptr(mine),
                                                    None, None))
@@ -102,6 +112,87 @@ class HipShardOps:
         self.ctx.sync()
 
 
+def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat", renumber="total", chunk_edges=1 << 27,
+                          placement="ranges"):
+    """This rank's edge-cut shard of a synthetic graph that is too large to materialise on one GPU (RMAT-27 over 8 GPUs,
+    BASELINE.json configs[2]).  Every rank streams the whole counter-based edge list in chunks twice -- once for the degree
+    histograms (renumbering + partition bounds, identical on all ranks), once to keep the edges whose source (outgoing
+    direction) or destination (incoming direction) it owns -- so no rank ever holds more than chunk + E/P edges and there is
+    no build-time communication.  The result equals Graph.from_coo(whole graph, renumber).shard(lo, hi) up to the order of
+    the incoming adjacency lists (generation order here, outgoing-CSR order there; vgl_graph.hpp:57-68).
+    placement="ranges": contiguous edge-balanced row ranges of the (renumbered) graph (get_mpi_thresholds,
+    vect_csr/get_api.hpp:66-94).  placement="dealt": the 64-vertex blocks of the (renumbered) order are dealt round-robin to the
+    ranks and the stored numbering is made rank-major, so that every rank owns exactly V/P consecutive stored ids with the
+    same mix of hubs and leaves -- rows AND edges are balanced (bottom-up work follows rows, not edges) and bottom-up levels can
+    exchange owned bitmap slices (bfs_sharded(equal_ranges=True)).  shard.fwd/bwd map original <-> stored ids either way.
+    Returns (shard, out_degrees[V] replicated, bounds)."""
+    from .api import Graph
+    V, E = 1 << scale, (1 << scale) * edge_factor
+
+    def chunk(e0, n):
+        if kind == "rmat":
+            return ctx.gen_rmat(scale, edge_factor, seed, first_edge=e0, count=n)
+        return ctx.gen_uniform(scale, edge_factor, seed, first_edge=e0, count=n)
+
+    chunks = [(e0, min(chunk_edges, E - e0)) for e0 in range(0, E, chunk_edges)]
+    outdeg = torch.zeros(V, dtype=torch.int32, device=ctx.device)
+    key = torch.zeros(V, dtype=torch.int32, device=ctx.device) if renumber in ("in", "total") else None
+    for e0, n in chunks:
+        s, d = chunk(e0, n)
+        ctx.degree_hist_add(s, d, "out", outdeg)
+        if key is not None:
+            ctx.degree_hist_add(s, d, renumber, key)
+        del s, d
+    fwd = bwd = None
+    if renumber:
+        fwd, bwd = ctx.degree_order_from_degrees(outdeg if key is None else key)
+        outdeg = ctx.permute(bwd, outdeg)                       # out-degrees in the sorted numbering
+    del key
+    if placement == "dealt":
+        if V % (64 * world):
+            raise ValueError("placement='dealt' needs V to be a multiple of 64 * world")
+        pos = torch.arange(V, device=ctx.device, dtype=torch.int64)
+        blk = pos >> 6
+        deal = ((blk % world) * (V // world) + (blk // world) * 64 + (pos & 63)).to(torch.int32)    # position -> stored id
+        undeal = torch.empty_like(deal)
+        undeal[deal.long()] = pos.to(torch.int32)
+        del pos, blk
+        fwd = deal if fwd is None else ctx.relabel(deal, fwd)
+        bwd = undeal if bwd is None else ctx.permute(undeal, bwd)      # bwd'[stored] = bwd[position of stored]
+        outdeg = ctx.permute(undeal, outdeg)
+        del deal, undeal
+        bounds = [p * (V // world) for p in range(world + 1)]
+    elif placement == "ranges":
+        rowptr = torch.zeros(V + 1, dtype=torch.int64, device=ctx.device)
+        torch.cumsum(outdeg, 0, dtype=torch.int64, out=rowptr[1:])
+        bounds = ctx.partition_rows(rowptr, world)
+        del rowptr
+    else:
+        raise ValueError("placement must be 'ranges' or 'dealt'")
+    lo, hi = bounds[rank], bounds[rank + 1]
+    keep = {"os": [], "od": [], "is": [], "id": []}
+    for e0, n in chunks:
+        s, d = chunk(e0, n)
+        if fwd is not None:
+            s, d = ctx.relabel(fwd, s), ctx.relabel(fwd, d)
+        m = (s >= lo) & (s < hi)
+        keep["os"].append(s[m])
+        keep["od"].append(d[m])
+        m = (d >= lo) & (d < hi)
+        keep["is"].append(d[m])                                 # transposed: rows of the incoming direction are destinations
+        keep["id"].append(s[m])
+        del s, d, m
+    cat = {k: (torch.cat(v) if v else torch.empty(0, dtype=torch.int32, device=ctx.device)) for k, v in keep.items()}
+    del keep
+    orp, oadj, _ = ctx.coo_to_csr(V, cat["os"], cat["od"], lo, hi)
+    del cat["os"], cat["od"]
+    irp, iadj, _ = ctx.coo_to_csr(V, cat["is"], cat["id"], lo, hi)
+    del cat
+    g = Graph(ctx, V, orp, oadj.clone(), irp, iadj.clone(), lo, hi)
+    g.fwd, g.bwd = fwd, bwd
+    return g, outdeg, bounds
+
+
 def _allreduce(t, op, group):
     if _world(group)[0] > 1:
         dist.all_reduce(t, op=op, group=group)
@@ -110,18 +201,26 @@ def _allreduce(t, op, group):
 ALPHA, BETA = 15, 18          # change_state.hpp:5-6
 
 
-def bfs_sharded(ops, source, group=None, degrees=None, edges=None):
+def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False):
     """BFS over edge-cut shards; returns the replicated levels array and the number of levels.
     degrees (int32[V] out-degrees of ALL vertices, replicated) + edges (global E) enable direction optimisation: every rank
     evaluates the same switch rule (gpu_change_state, change_state.hpp:100-141) on replicated counters, bottom-up steps scan
     the owned rows' incoming edges.  Without them the traversal is top-down only.
-    Exchange per level: all-gather of V/8-byte discovery bitmaps."""
+    Exchange per level: all-gather of V/8-byte discovery bitmaps.  equal_ranges=True (every rank owns V/P rows, V/P a multiple
+    of 64; build_generated_shard(placement="dealt")) lets the bottom-up levels -- which only discover owned vertices -- gather
+    the owned V/(8P)-byte slices instead, P times less traffic; the caller guarantees the flag is the same on all ranks."""
     P, rank = _world(group)
     V = ops.V
     levels = ops.new_i32()
     ops.bfs_init(levels, source)
     mine = ops.new_words(1)
     everyone = ops.new_words(P) if P > 1 else mine
+    merged = None
+    if equal_ranges and P > 1:
+        lo, hi = ops.row_range()
+        if V % (64 * P) or lo != rank * (V // P) or hi != lo + V // P:
+            raise ValueError("bfs_sharded: equal_ranges needs rank r to own rows [r*V/P, (r+1)*V/P) with V/P a multiple of 64")
+        merged = ops.new_words(1)
     visited, front = ops.new_words(1), ops.new_words(1)
     ops.levels_to_bitmap(levels, 1, front)
     visited.copy_(front)
@@ -139,16 +238,20 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None):
             elif F < prevF and F < ((V - visited_total) * factor + V) // (factor * BETA):
                 bottom_up = False
         prevF = F
+        parts, bits = P, everyone
         if bottom_up:
             ops.bfs_step_bu(levels, level, visited, front, mine)          # owned unvisited vertices look for a parent
         else:
-            ops.bfs_step(levels, level, visited)                          # owned frontier vertices expand
-            ops.levels_to_bitmap(levels, level + 1, mine)                 # what this rank discovered
+            ops.bfs_step_bits(levels, level, visited, front, mine)        # owned frontier vertices expand; mine = discoveries
         nlevels += 1
         if P > 1:
             ops.sync()
-            dist.all_gather_into_tensor(everyone, mine, group=group)
-        F, M = ops.apply_bitmaps(P, everyone, levels, level + 1, visited, front, degrees if direction_opt else None)
+            if bottom_up and merged is not None:
+                dist.all_gather_into_tensor(merged, mine[lo // 64:hi // 64], group=group)
+                parts, bits = 1, merged
+            else:
+                dist.all_gather_into_tensor(everyone, mine, group=group)
+        F, M = ops.apply_bitmaps(parts, bits, levels, level + 1, visited, front, degrees if direction_opt else None)
         if F == 0:
             break
         level += 1

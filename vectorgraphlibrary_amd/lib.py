@@ -55,6 +55,8 @@ _SIGNATURES = {
     "vgl_hip_coo_to_csr": [_p, _i32, _i64, _p, _p, _i32, _i32, _p, _p, _p, C.POINTER(_i64)],
     "vgl_hip_gather_u32": [_p, _i64, _p, _p, _p],
     "vgl_hip_degree_order": [_p, _i32, _i64, _p, _p, _int, _p, _p],
+    "vgl_hip_degree_hist_add": [_p, _i64, _p, _p, _int, _p],
+    "vgl_hip_degree_order_from_degrees": [_p, _i32, _p, _p, _p],
     "vgl_hip_relabel_i32": [_p, _i64, _p, _p, _p],
     "vgl_hip_permute_u32": [_p, _i64, _p, _p, _p],
     "vgl_hip_cc_labels_to_original": [_p, _i32, _p, _p, _p, _p, _p],
@@ -85,6 +87,7 @@ _SIGNATURES = {
     "vgl_hip_cc_run": [_p, _p, _p, C.POINTER(CcStats)],
     "vgl_hip_bfs_init": [_p, _i32, _i32, _p],
     "vgl_hip_bfs_step_top_down": [_p, _p, _p, _i32, _p, C.POINTER(_i64), C.POINTER(_i64)],
+    "vgl_hip_bfs_step_top_down_bits": [_p, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_bfs_step_bottom_up": [_p, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_levels_to_bitmap": [_p, _i32, _p, _i32, _p],
     "vgl_hip_bfs_apply_bitmaps": [_p, _i32, _int, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
