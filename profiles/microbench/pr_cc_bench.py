@@ -10,7 +10,7 @@ def t(f, n=3):
 for kind, scale in (('ru',25),('rmat',24)):
     ef=32; V=1<<scale; E=V*ef
     src,dst = (ctx.gen_uniform if kind=='ru' else ctx.gen_rmat)(scale, ef, 1)
-    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=False, renumber='total' if kind=='rmat' else None)
+    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True, renumber='total' if kind=='rmat' else None)   # in-CSR: in-degrees without atomics
     del src,dst
     ctx.timing(True)
     dt,(rk,st) = t(lambda: api.page_rank(g, 10, raw=True), 2)

@@ -87,8 +87,9 @@ struct vgl_hip_graph {
     float *fscratch2 = nullptr;      // V (PR rdeg)
     float *fscratch3 = nullptr;      // V (PR new ranks)
     int32_t *iscratch = nullptr;     // V (PR indeg when not supplied)
-    int32_t *pr_hub_rows = nullptr;      // PageRank: rows with >= 512 edges (lazy; last entry = device counter)
+    int32_t *pr_hub_rows = nullptr;      // PageRank: rows with >= 512 edges grouped per wavefront + offsets (lazy)
     int32_t pr_nhubs = 0;
+    int pr_hub_blocks = 0;               // workgroups of the pull kernel that run the hub schedule
     uint8_t *ds_tile_active = nullptr;   // delta-stepping SSSP: one byte per out-edge tile (lazy)
     int64_t *ds_partials = nullptr;
 };
