@@ -40,14 +40,17 @@ struct ConnectedComponents {
         return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
     }
 
-    static double hip_fused(VGL_Graph &graph, VerticesArray<int> &components)
+    // symmetric: the caller knows that every edge is stored in both directions (graphs generated as UNDIRECTED_GRAPH); the labels
+    // are the same, computed by the union-find path instead of repeated sweeps
+    static double hip_fused(VGL_Graph &graph, VerticesArray<int> &components, bool symmetric = false)
     {
         Timer tm;
         tm.start();
         vgl_hip_cc_stats st;
-        VGL_HIP_CALL(vgl_hip_cc_run(VGL_RUNTIME::ctx(), graph.get_handle(), components.get_ptr(), &st));
+        if (symmetric) VGL_HIP_CALL(vgl_hip_cc_run_symmetric(VGL_RUNTIME::ctx(), graph.get_handle(), components.get_ptr(), &st));
+        else VGL_HIP_CALL(vgl_hip_cc_run(VGL_RUNTIME::ctx(), graph.get_handle(), components.get_ptr(), &st));
         tm.end();
-        performance_stats.print_algorithm_performance_stats("CC (fused)", tm.get_time(), graph.get_edges_count());
+        performance_stats.print_algorithm_performance_stats(symmetric ? "CC (fused, union-find)" : "CC (fused)", tm.get_time(), graph.get_edges_count());
         return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
     }
 };

@@ -10,7 +10,8 @@ int main(int argc, char **argv)
         VGL_Graph graph;
         prepare_graph(graph, parser, UNDIRECTED_GRAPH);
         VerticesArray<int> components(graph, SCATTER);
-        auto run = [&]() { return parser.fused ? ConnectedComponents::hip_fused(graph, components)
+        const bool symmetric = parser.import_file.empty();      // generated UNDIRECTED_GRAPH inputs hold both directions of every edge
+        auto run = [&]() { return parser.fused ? ConnectedComponents::hip_fused(graph, components, symmetric)
                                                : ConnectedComponents::vgl_shiloach_vishkin(graph, components); };
         run();                                   // heat run
         report_performance(run());

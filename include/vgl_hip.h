@@ -196,6 +196,13 @@ typedef struct {
 } vgl_hip_cc_stats;
 /* vgl_shiloach_vishkin, shiloach_vishkin.hpp:7-88: labels = min id that reaches each vertex */
 int vgl_hip_cc_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc_stats *stats);
+/* Same labels for SYMMETRIC graphs only (every edge stored in both directions, as the reference's cc app builds its input,
+ * apps/cc/cc.cpp:24-36 UNDIRECTED_GRAPH): the fixed point of the hook/jump loop is then "smallest id of the connected component",
+ * which a min-id union-find reaches without sweeping all edges repeatedly -- two sampled neighbours per vertex, then only the
+ * rows outside the largest tree look at their edges.  The caller vouches for the symmetry; on a directed graph the labels
+ * are those of the weakly-connected components of the stored edges, NOT vgl_hip_cc_run's.  stats->hook_passes counts the
+ * link passes (sampling rounds + 1), algorithmic_bytes what those passes had to touch. */
+int vgl_hip_cc_run_symmetric(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc_stats *stats);
 
 /* ---- super-step pieces for the edge-cut multi-GPU path (one process per GPU; the exchange between steps is an
  *      RCCL collective issued by the host side, replacing common/mpi_exchange.hpp:110-150,222-271) ---- */

@@ -28,4 +28,6 @@ for ren in (None,'total'):
     dt,(c,st) = t(lambda: api.connected_components(g, raw=True), 2)
     n,ms = ctx.timing_get('cc_hook'); n2,ms2 = ctx.timing_get('cc_jump'); ctx.timing(False)
     print(f"CC rmat-24 sym renumber={ren}: {dt*1e3:.1f} ms, {st['hook_passes']} hook passes -> {E/dt/1e9:.1f} GTEPS; hook {ms/n:.2f} ms/launch -> {(8*E+12*V)/(ms/n*1e-3)/1e9:.0f} GB/s algorithmic; jump {ms2/max(n2,1):.2f} ms/launch; components {int(torch.unique(c).numel())}")
+    dt2,(c2,st2) = t(lambda: api.connected_components(g, raw=True, symmetric=True), 3)
+    print(f"CC rmat-24 sym renumber={ren} union-find path: {dt2*1e3:.2f} ms -> {E/dt2/1e9:.1f} GTEPS; same labels: {bool(torch.equal(c, c2))}")
     g.close(); del g

@@ -580,3 +580,35 @@ def test_pagerank_indegree_paths_and_hub_schedule(ctx, oracle):
     assert (a.cpu().numpy().view(np.int32) == want.view(np.int32)).all()
     assert (b.cpu().numpy().view(np.int32) == want.view(np.int32)).all()
     both.close(); out_only.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef,renumber", [("rmat", 14, 8, None), ("rmat", 14, 8, "total"), ("ru", 13, 1, None), ("ru", 12, 1, "out")])
+def test_symmetric_cc_matches_shiloach_vishkin(kind, scale, ef, renumber, ctx, oracle):
+    """on a symmetrised graph the union-find path returns exactly the hook/jump labels (smallest id of the component): against the
+    oracle's SV and sequential-BFS labelling, under identity and degree-sorted numbering, on graphs with one giant component (RMAT)
+    and with hundreds of small ones (sparse uniform)."""
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    V = 1 << scale
+    s, d = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, 31)
+    src, dst = torch.cat([s, d]), torch.cat([d, s])
+    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=False, renumber=renumber)
+    plain = api.Graph.from_coo(ctx, V, src, dst, with_incoming=False) if renumber else g
+    rowptr, adj = plain.out_rowptr.cpu().numpy(), plain.out_adj.cpu().numpy()
+    want = O.cc_sv(rowptr, adj)[0]
+    seq = O.cc_seq_bfs(rowptr, adj)                    # the reference checker's labelling (component counter): same partition,
+    mins = np.full(int(seq.max()) + 1, V, np.int64)    # and the SV label is the smallest id of each part
+    np.minimum.at(mins, seq, np.arange(V))
+    assert (mins[seq] == want).all()
+    fast, st = api.connected_components(g, symmetric=True)
+    slow, _ = api.connected_components(g)
+    assert (fast.cpu().numpy() == want).all()
+    assert (slow.cpu().numpy() == want).all()
+    assert st["hook_passes"] == 3
+    ncomp = len(np.unique(want))
+    assert ncomp > (100 if kind == "ru" else 1)
+    g.close()
+    if renumber:
+        plain.close()

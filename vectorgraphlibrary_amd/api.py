@@ -312,12 +312,15 @@ def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False):
     return (ranks if raw else graph.to_original(ranks)), _stats(st)
 
 
-def connected_components(graph, comp=None, raw=False):
-    """labels = smallest ORIGINAL vertex id that reaches each vertex (raw=True: smallest id in the graph's numbering)."""
+def connected_components(graph, comp=None, raw=False, symmetric=False):
+    """labels = smallest ORIGINAL vertex id that reaches each vertex (raw=True: smallest id in the graph's numbering).
+    symmetric=True: the caller vouches that every edge is stored in both directions; the same labels then come from a min-id
+    union-find (vgl_hip_cc_run_symmetric) instead of repeated sweeps over all edges."""
     ctx = graph.ctx
     comp = ctx.empty(graph.V, torch.int32) if comp is None else comp
     st = _l.CcStats()
-    _l.check(ctx.L.vgl_hip_cc_run(ctx.h, graph.h, _ptr(comp), C.byref(st)))
+    run = ctx.L.vgl_hip_cc_run_symmetric if symmetric else ctx.L.vgl_hip_cc_run
+    _l.check(run(ctx.h, graph.h, _ptr(comp), C.byref(st)))
     if raw or graph.fwd is None:
         return comp, _stats(st)
     out, scratch = ctx.empty(graph.V, torch.int32), ctx.empty(graph.V, torch.int32)

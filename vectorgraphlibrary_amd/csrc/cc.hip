@@ -67,6 +67,62 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_jump(int32_t V, int32_t *c
     }
 }
 
+// ---- symmetric graphs: min-id union-find (the same fixed point as the hook/jump loop when every edge has its reverse) ----
+// comp[] is a parent forest with comp[x] <= x at all times; a root is x with comp[x] == x.  link() hooks the larger of the two
+// roots under the smaller one with a CAS and climbs when it loses a race, so the root of a finished tree is its smallest id.
+__device__ __forceinline__ void vgl_cc_link(int32_t u, int32_t v, int32_t *comp)
+{
+    int32_t p1 = comp[u], p2 = comp[v];
+    while (p1 != p2) {
+        const int32_t high = max(p1, p2), low = min(p1, p2);
+        const int32_t ph = comp[high];
+        if (ph == low) break;
+        if (ph == high && atomicCAS(comp + high, high, low) == high) break;
+        p1 = comp[comp[high]];
+        p2 = comp[low];
+    }
+}
+
+// sampling round k: every owned row links with its k-th neighbour (V links instead of E)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_link_sample(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj,
+                                                                  int k, int32_t *comp)
+{
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK) {
+        const int64_t b = rowptr[r];
+        if (rowptr[r + 1] - b > k) vgl_cc_link(row_base + r, adj[b + k], comp);
+    }
+}
+
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_sample_labels(int32_t V, const int32_t *comp, int nsamples, int32_t *out)
+{
+    const int i = blockIdx.x * VGL_BLOCK + threadIdx.x;
+    if (i < nsamples) out[i] = comp[(int32_t)(((uint64_t)(uint32_t)i * 2654435761ull) % (uint64_t)V)];
+}
+
+// remaining edges, edge-balanced: rows already in the tree `giant` skip their edges without loading them (their edges towards
+// other trees are seen from the other endpoint -- the graph is symmetric); the first `skip` edges of a row were linked by the
+// sampling rounds.  A workgroup whose rows are all in `giant` touches no adjacency at all.
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_link_rest(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E,
+                                                                int32_t row_base, int32_t giant, int skip, int32_t *comp)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, E - e0);
+    const int r_first = tile_row[blockIdx.x];
+    const int r_last = tile_row[blockIdx.x + 1];
+    vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;
+        if (i < n) {
+            const int32_t r = r_first + s_map[i];
+            const int32_t u = row_base + r;
+            if (comp[u] != giant && e0 + i - rowptr[r] >= skip) vgl_cc_link(u, adj[e0 + i], comp);
+        }
+    }
+}
+
 static inline unsigned vgl_grid2(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, vgl_ceil_div(n, VGL_BLOCK))); }
 
 static int vgl_cc_hook_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *comp)
@@ -123,6 +179,55 @@ int vgl_hip_cc_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc
         VGL_TRY(vgl_hip_cc_jump(c, g->V, d_comp));
         st.algorithmic_bytes += 12 * (int64_t)g->V;
     }
+    if (stats) *stats = st;
+    return 0;
+}
+
+int vgl_hip_cc_run_symmetric(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc_stats *stats)
+{
+    if (!c || !g || !d_comp) VGL_FAIL("cc_run_symmetric: null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("cc_run_symmetric: graph handle must own all rows");
+    const int32_t V = g->V;
+    constexpr int ROUNDS = 2, NSAMPLES = 1024;
+    VGL_TRY(vgl_hip_cc_init(c, V, d_comp));
+    vgl_hip_cc_stats st = {0, 0};
+    for (int k = 0; k < ROUNDS; k++) {
+        {
+            vgl_timed_launch tl(c, "cc_hook");
+            hipLaunchKernelGGL(vgl_k_cc_link_sample, dim3(vgl_grid2(g->nrows)), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin,
+                               g->out.rowptr, g->out.adj, k, d_comp);
+        }
+        VGL_TRY(vgl_hip_cc_jump(c, V, d_comp));
+        st.hook_passes++;
+        st.algorithmic_bytes += (int64_t)V * (16 + 4 + 8) + 12 * (int64_t)V;      // row offsets, one neighbour, two labels; compress
+    }
+    // most frequent label among a fixed sample = the largest tree so far (any label is a correct choice; it only decides what is skipped)
+    int32_t giant = -1;
+    if (V > 0) {
+        int32_t *d_samples = reinterpret_cast<int32_t *>(g->iscratch);
+        const int ns = std::min<int64_t>(NSAMPLES, V);
+        hipLaunchKernelGGL(vgl_k_cc_sample_labels, dim3(vgl_ceil_div(ns, VGL_BLOCK)), dim3(VGL_BLOCK), 0, c->stream, V, d_comp, ns, d_samples);
+        VGL_HIP_TRY(hipGetLastError());
+        std::vector<int32_t> h((size_t)ns);
+        VGL_TRY(vgl_hip_memcpy_d2h(c, h.data(), d_samples, sizeof(int32_t) * (size_t)ns));
+        std::sort(h.begin(), h.end());
+        int best = 0;
+        for (int i = 0; i < ns;) {
+            int j = i;
+            while (j < ns && h[(size_t)j] == h[(size_t)i]) j++;
+            if (j - i > best) { best = j - i; giant = h[(size_t)i]; }
+            i = j;
+        }
+    }
+    if (g->out.ntiles > 0) {
+        vgl_timed_launch tl(c, "cc_hook");
+        hipLaunchKernelGGL(vgl_k_cc_link_rest, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj,
+                           g->out.tile_row, g->out.edges, g->row_begin, giant, ROUNDS, d_comp);
+        VGL_HIP_TRY(hipGetLastError());
+    }
+    VGL_TRY(vgl_hip_cc_jump(c, V, d_comp));
+    st.hook_passes++;
+    st.algorithmic_bytes += 12 * (int64_t)V + 12 * (int64_t)V;                    // row offsets + label per row (edges of skipped rows are not read); compress
     if (stats) *stats = st;
     return 0;
 }
