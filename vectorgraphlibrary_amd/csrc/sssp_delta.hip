@@ -426,21 +426,27 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
                            (long long)c->h_counters[C_TMP0]);
         return 0;
     };
-    // bucket width: delta, doubled through the sparse tail (fewer steps).  Narrower buckets in the dense core were measured
+    // bucket width: delta, multiplied by 16 after every bucket that relaxed fewer than E/16 edges (the sparse tail: fewer steps).  Narrower buckets in the dense core were measured
     // (W0 = 1/4 .. 1/16): 10 % fewer relaxed edges but 2-3x the steps, i.e. slower -- the per-step passes dominate.  The
     // light/heavy edge split always uses the plan's delta.  Any width is correct, it only changes the amount of re-relaxation.
     auto envf = [](const char *n, double dflt) { const char *v = getenv(n); return v ? atof(v) : dflt; };
     float width = (float)(p->delta * envf("VGL_DS_W0", 1.0));
     const int64_t rows_hi = (int64_t)envf("VGL_DS_HI", 1.0e18), rows_lo = (int64_t)envf("VGL_DS_LO", 4096.0);
     T = width;
-    int64_t bucket_rows = 0;
+    const int64_t edges_lo = (int64_t)envf("VGL_DS_ELO", std::max<double>(1.0e6, (double)g->out.edges / 16.0));
+    const double grow = envf("VGL_DS_GROW", 16.0);
+    int64_t bucket_rows = 0, bucket_edges = 0;
     for (;;) {
         VGL_TRY(step(1));
         bucket_rows += c->h_counters[C_FRONT];
-        bool near = c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0;
+        bucket_edges += c->h_counters[C_NEIGH];
+        // (leaving a bucket early once its light frontier is small and shrinking was measured: the tail reappears in the next
+        // bucket, 1-10 % slower)
+        const bool near = c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0;
         if (near) continue;                                             // the bucket received improvements: light edges again
         if (c->h_counters[C_TMP1] > 0) {                                // bucket settled: its heavy edges, once
             VGL_TRY(step(2));
+            bucket_edges += c->h_counters[C_NEIGH];
             if (c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0) continue;
         }
         const int bits = (int)c->h_counters[C_JUMP];                    // smallest pending distance after the last relax
@@ -448,10 +454,11 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
         memcpy(&min_far, &bits, sizeof(float));
         if (!(min_far < FLT_MAX)) break;                                // nothing pending anywhere: fixed point
         if (min_far < T) continue;                                      // (defensive) something below T is still pending
+        // a bucket that relaxed few edges was all per-step overhead (7 launches + a host read, ~0.1 ms): widen quickly
         if (bucket_rows > rows_hi && width > p->delta / 64.0f) width *= 0.5f;
-        else if (bucket_rows < rows_lo && width < 64.0f * p->delta) width *= 2.0f;
-        if (debug) fprintf(stderr, "ds bucket done: rows=%lld next width=%g\n", (long long)bucket_rows, width);
-        bucket_rows = 0;
+        else if ((bucket_edges < edges_lo || bucket_rows < rows_lo) && width < 4096.0f * p->delta) width *= (float)grow;
+        if (debug) fprintf(stderr, "ds bucket done: rows=%lld edges=%lld next width=%g\n", (long long)bucket_rows, (long long)bucket_edges, width);
+        bucket_rows = bucket_edges = 0;
         T = std::max(min_far + width, std::nextafter(min_far, FLT_MAX));
     }
     s.algorithmic_bytes = 12 * s.edges_relaxed + 5 * (int64_t)V * s.iterations;
