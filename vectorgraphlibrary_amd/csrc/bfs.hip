@@ -23,6 +23,20 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bfs_init(int32_t V, int32_t s
         levels[v] = (v == source) ? 1 : -1;      // FIRST_LEVEL_VERTEX / UNVISITED_VERTEX (change_state.h:21-23)
 }
 
+// start of a fused traversal: levels, the three bitmaps (visited = front = {source}, next = 0) and the tickets in one launch
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bfs_init_all(int32_t V, int32_t source, int32_t *levels, int64_t words, uint64_t *visited,
+                                                                uint64_t *front, uint64_t *next, uint32_t *tickets)
+{
+    for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK)
+        levels[v] = (v == source) ? 1 : -1;      // FIRST_LEVEL_VERTEX / UNVISITED_VERTEX (change_state.h:21-23)
+    for (int64_t w = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; w < words; w += (int64_t)gridDim.x * VGL_BLOCK) {
+        const uint64_t bit = (w == (source >> 6)) ? (1ULL << (source & 63)) : 0ULL;
+        visited[w] = bit; front[w] = bit; next[w] = 0;
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 3 * VGL_TICKET_WORDS; i += VGL_BLOCK) tickets[i] = 0;
+}
+
 // tile_first[t] = frontier position whose edge range contains edge t*VGL_TILE
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_first(int32_t F, const int64_t *offs, int32_t *tile_first)
 {
@@ -88,8 +102,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
 }
 
 // ---- frontier generation from the frontier BITMAP (small frontiers): one 64-bit word per thread, 256 words per workgroup ----
+// The last workgroup to finish also does what used to be two more launches: the exclusive scan of the per-workgroup counts
+// (<= a few thousand entries) and the hand-over of F and M to the host (counters + pinned mirror + sequence number).
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
-                                                                const int64_t *rowptr, int32_t *vt_cnt, int64_t *vt_deg)
+                                                                const int64_t *rowptr, int32_t *vt_cnt, int64_t *vt_deg,
+                                                                int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *offs, int64_t *counters,
+                                                                uint32_t *ticket, volatile int64_t *host, int64_t seq)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
@@ -108,11 +126,34 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
     }
     const int tc = vgl_block_reduce_add(cnt, s32);
     const int64_t td = vgl_block_reduce_add(deg, s64);
-    if (threadIdx.x == 0) { vt_cnt[blockIdx.x] = tc; vt_deg[blockIdx.x] = td; }
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) dep = vgl_put_agent(vt_cnt + blockIdx.x, tc) ^ vgl_put_agent(vt_deg + blockIdx.x, td);
+    if (!vgl_last_block(ticket, dep)) return;
+    const int nb = (int)gridDim.x;
+    const int per = (nb + VGL_BLOCK - 1) / VGL_BLOCK;
+    const int lo = min(nb, (int)threadIdx.x * per), hi = min(nb, lo + per);
+    int c = 0;
+    int64_t d = 0;
+    for (int t = lo; t < hi; t++) { c += vgl_load_agent(vt_cnt + t); d += vgl_load_agent(vt_deg + t); }
+    int ctot;
+    int64_t dtot;
+    int cpre = vgl_block_excl_add(c, s32, &ctot);
+    int64_t dpre = vgl_block_excl_add(d, s64, &dtot);
+    for (int t = lo; t < hi; t++) {
+        vt_cnt_off[t] = cpre; vt_deg_off[t] = dpre;
+        cpre += vgl_load_agent(vt_cnt + t);
+        dpre += vgl_load_agent(vt_deg + t);
+    }
+    if (threadIdx.x == 0) {
+        offs[ctot] = dtot;
+        vgl_publish2(counters, host, seq, C_FRONT, (int64_t)ctot, C_NEIGH, dtot);
+    }
 }
+// write pass; also fills tile_first (the frontier position that owns edge t*VGL_TILE, and, in entry [#tiles], the owner of the
+// last edge) -- every frontier vertex knows its own edge range, so the separate vgl_k_tile_first launch is not needed
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
                                                                 const int64_t *rowptr, const int32_t *vt_cnt_off, const int64_t *vt_deg_off,
-                                                                int32_t *ids, int64_t *offs)
+                                                                int32_t *ids, int64_t *offs, int32_t *tile_first, int64_t M)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
@@ -138,16 +179,18 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, 
         const int32_t v = (int32_t)(((word0 + wi) << 6) + b);
         const int64_t r = v - row_base;
         ids[pos] = v; offs[pos] = eoff;
-        eoff += rowptr[r + 1] - rowptr[r];
+        const int64_t eend = eoff + (rowptr[r + 1] - rowptr[r]);
+        for (int64_t t = (eoff + VGL_TILE - 1) / VGL_TILE; t < (eend + VGL_TILE - 1) / VGL_TILE; t++) tile_first[t] = pos;
+        if (eoff < eend && eend == M) tile_first[(M + VGL_TILE - 1) / VGL_TILE] = pos;
+        eoff = eend;
         pos++;
     }
 }
-__global__ void vgl_k_set_bit(int32_t v, uint64_t *a, uint64_t *b) { a[v >> 6] = 1ULL << (v & 63); b[v >> 6] = 1ULL << (v & 63); }
 
 // Bottom-up step.  No global atomics: a single same-address device atomic costs ~12 ns and serialises (65 536 blocks
 // adding to one counter took 1.5 ms per launch in the first version); instead a fixed grid of VGL_BU_BLOCKS persistent
 // workgroups each owns a contiguous vertex range, a private segment of the deferred-vertex list and a private slot of
-// partial counters, which vgl_k_bu_fold sums in a fixed order afterwards.
+// partial counters, which the last workgroup of the second pass sums in a fixed order.
 constexpr int VGL_BU_BLOCKS = 2048;
 
 // pass 1: one thread per owned vertex.  A vertex is a candidate when it is unvisited AND has incoming edges (in_nz
@@ -159,7 +202,8 @@ typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 1
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
                                                             const int32_t *in_adj, int64_t in_edges, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
-                                                            int32_t next_level, int32_t *heavy, int32_t *heavy_cnt, int64_t *partials)
+                                                            int32_t next_level, int32_t *heavy, int32_t *heavy_cnt, int64_t *partials,
+                                                            int32_t *heavy_off, uint32_t *ticket)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s_nheavy;
@@ -216,21 +260,19 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
     }
     found_cnt = vgl_block_reduce_add(found_cnt, s64);
     probes = vgl_block_reduce_add(probes, s64);
+    uint32_t dep = 0;
     if (threadIdx.x == 0) {
         partials[blockIdx.x * 4 + 0] = found_cnt;
         partials[blockIdx.x * 4 + 1] = probes;
-        heavy_cnt[blockIdx.x] = s_nheavy;
+        dep = vgl_put_agent(heavy_cnt + blockIdx.x, (int32_t)s_nheavy);
     }
-}
-
-// exclusive prefix of the per-workgroup deferred counts (one workgroup, VGL_BU_BLOCKS entries -> VGL_BU_BLOCKS+1 offsets)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy_offsets(const int32_t *heavy_cnt, int32_t *heavy_off)
-{
+    // last workgroup: exclusive prefix of the per-workgroup deferred counts (VGL_BU_BLOCKS entries -> VGL_BU_BLOCKS+1 offsets)
+    if (!vgl_last_block(ticket, dep)) return;
     __shared__ int s32[VGL_WAVES];
     constexpr int PER = VGL_BU_BLOCKS / VGL_BLOCK;
     int local[PER], sum = 0;
 #pragma unroll
-    for (int j = 0; j < PER; j++) { local[j] = heavy_cnt[threadIdx.x * PER + j]; sum += local[j]; }
+    for (int j = 0; j < PER; j++) { local[j] = vgl_load_agent(heavy_cnt + threadIdx.x * PER + j); sum += local[j]; }
     int total;
     int pre = vgl_block_excl_add(sum, s32, &total);
 #pragma unroll
@@ -244,7 +286,8 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy_offsets(const int32_
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
                                                             const int32_t *in_adj, const uint64_t *front, uint64_t *next,
                                                             int32_t *levels, int32_t next_level, const int32_t *heavy,
-                                                            const int32_t *heavy_off, int64_t *partials)
+                                                            const int32_t *heavy_off, int64_t *partials, int64_t *counters, uint32_t *ticket,
+                                                            volatile int64_t *host, int64_t seq)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s_off[VGL_BU_BLOCKS + 1];
@@ -275,32 +318,30 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, in
     }
     found_cnt = vgl_block_reduce_add(found_cnt, s64);
     probes = vgl_block_reduce_add(probes, s64);
-    if (threadIdx.x == 0) {
-        partials[blockIdx.x * 4 + 2] = found_cnt;
-        partials[blockIdx.x * 4 + 3] = probes;
-    }
-}
-
-// counters[C_BU_FOUND] / counters[C_BU_EDGES] = sums of the per-workgroup partials, in a fixed order
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_fold(const int64_t *partials, int64_t *counters)
-{
-    __shared__ int64_t s64[VGL_WAVES];
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) dep = vgl_put_agent(partials + blockIdx.x * 4 + 2, found_cnt) ^ vgl_put_agent(partials + blockIdx.x * 4 + 3, probes);
+    // last workgroup: counters[C_BU_FOUND] / [C_BU_EDGES] = sums of the per-workgroup partials of both passes in a fixed order,
+    // handed to the host (when it listens: host != nullptr)
+    if (!vgl_last_block(ticket, dep)) return;
     int64_t f = 0, p = 0;
     for (int b = threadIdx.x; b < VGL_BU_BLOCKS; b += VGL_BLOCK) {
-        f += partials[b * 4 + 0] + partials[b * 4 + 2];
-        p += partials[b * 4 + 1] + partials[b * 4 + 3];
+        f += partials[b * 4 + 0] + vgl_load_agent(partials + b * 4 + 2);
+        p += partials[b * 4 + 1] + vgl_load_agent(partials + b * 4 + 3);
     }
     f = vgl_block_reduce_add(f, s64);
     p = vgl_block_reduce_add(p, s64);
-    if (threadIdx.x == 0) { counters[C_BU_FOUND] = f; counters[C_BU_EDGES] = p; }
+    if (threadIdx.x == 0) {
+        if (host) vgl_publish2(counters, host, seq, C_BU_FOUND, f, C_BU_EDGES, p);
+        else { counters[C_BU_FOUND] = f; counters[C_BU_EDGES] = p; }
+    }
 }
 
-// visited |= next; front = next   (one word per thread)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_advance(int64_t words, uint64_t *visited, uint64_t *front, const uint64_t *next)
+// visited |= next; front = next; next = 0 (ready for the next emitting step without a memset)   (one word per thread)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_advance(int64_t words, uint64_t *visited, uint64_t *front, uint64_t *next)
 {
     for (int64_t w = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; w < words; w += (int64_t)gridDim.x * VGL_BLOCK) {
         const uint64_t n = next[w];
-        visited[w] |= n;
+        if (n) { visited[w] |= n; next[w] = 0; }
         front[w] = n;
     }
 }
@@ -380,10 +421,11 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_fold(int n, const int64
 static inline unsigned vgl_grid(int64_t n, int64_t cap = 8192) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
 
 // expand frontier (ids/offs with F vertices, M edges already produced by a frontier-generation write pass)
-static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_t M, int32_t *levels, int32_t next_level, bool emit)
+static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_t M, int32_t *levels, int32_t next_level, bool emit,
+                             bool have_tile_first)
 {
     if (F <= 0 || M <= 0) return 0;
-    hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, F, g->offs, g->tile_first);
+    if (!have_tile_first) hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, F, g->offs, g->tile_first);
     const int64_t nt = vgl_ceil_div(M, VGL_TILE);
     {
         vgl_timed_launch tl(c, "bfs_top_down");
@@ -398,51 +440,55 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
     return 0;
 }
 
-// frontier of the current level from bm_front (owned words): counts + totals (read back), optionally ids + edge offsets
-static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write)
+// frontier of the current level from a frontier bitmap (owned words).  count: per-workgroup counts, their scan and F / M in
+// h_counters[C_FRONT] / [C_NEIGH] (one launch, the host waits for it); write: ids + edge offsets + tile_first (needs the M of
+// the count pass)
+static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1)
 {
     const int64_t word0 = g->row_begin >> 6;
     const int64_t nwords = vgl_ceil_div(g->row_end, 64) - word0;
     const unsigned nb = (unsigned)vgl_ceil_div(nwords, VGL_BLOCK);
     if (count) {
+        const int64_t seq = vgl_next_seq(c);
         {
             vgl_timed_launch tl(c, "gnf");
             hipLaunchKernelGGL(vgl_k_bm_gnf_count, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, front,
-                               g->out.rowptr, g->vt_cnt, g->vt_deg);
+                               g->out.rowptr, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, g->offs, c->d_counters, g->tickets + 0 * VGL_TICKET_WORDS,
+                               (volatile int64_t *)c->h_counters, seq);
         }
-        hipLaunchKernelGGL(vgl_k_gnf_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, (int64_t)nb, g->vt_cnt, g->vt_deg, g->vt_cnt_off,
-                           g->vt_deg_off, c->d_counters, g->offs);
         VGL_HIP_TRY(hipGetLastError());
-        VGL_TRY(vgl_read_counters(c, false));
+        VGL_TRY(vgl_wait_counters(c, seq));
     }
     if (write) {
         vgl_timed_launch tl(c, "gnf");
         hipLaunchKernelGGL(vgl_k_bm_gnf_write, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, front,
-                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
+                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs, g->tile_first, M_known >= 0 ? M_known : c->h_counters[C_NEIGH]);
         VGL_HIP_TRY(hipGetLastError());
     }
     return 0;
 }
 
-// one bottom-up step over the owned rows: probe + balanced heavy pass + fold (counters C_BU_FOUND / C_BU_EDGES)
+// one bottom-up step over the owned rows: probe (+ deferred-list offsets) and the balanced heavy pass (+ fold of the counters
+// C_BU_FOUND / C_BU_EDGES, published to the host under sequence number *seq_out: vgl_wait_counters when they are needed)
 static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, int32_t next_level, const uint64_t *visited,
-                             const uint64_t *front, uint64_t *next)
+                             const uint64_t *front, uint64_t *next, int64_t *seq_out)
 {
     const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
     {
         vgl_timed_launch tl(c, "bfs_bottom_up");
         hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
                            g->in.rowptr, g->in.adj, g->in.edges, visited, g->bm_in_nz, front, next, levels, next_level,
-                           g->heavy, g->heavy_cnt, g->bu_partials);
+                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS);
     }
-    hipLaunchKernelGGL(vgl_k_bu_heavy_offsets, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->heavy_cnt, g->heavy_off);
+    const int64_t seq = vgl_next_seq(c);
     {
         vgl_timed_launch tl(c, "bfs_bottom_up_heavy");
         hipLaunchKernelGGL(vgl_k_bu_heavy, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,
-                           g->in.adj, front, next, levels, next_level, g->heavy, g->heavy_off, g->bu_partials);
+                           g->in.adj, front, next, levels, next_level, g->heavy, g->heavy_off, g->bu_partials, c->d_counters, g->tickets + 2 * VGL_TICKET_WORDS,
+                           (volatile int64_t *)c->h_counters, seq);
     }
-    hipLaunchKernelGGL(vgl_k_bu_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, g->bu_partials, c->d_counters);
     VGL_HIP_TRY(hipGetLastError());
+    if (seq_out) *seq_out = seq;
     return 0;
 }
 
@@ -466,10 +512,9 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     const int32_t V = g->V;
     const int64_t E = g->out.edges;
     const int64_t words = vgl_ceil_div(V, 64);
-    VGL_TRY(vgl_hip_bfs_init(c, V, source, d_levels));
-    VGL_HIP_TRY(hipMemsetAsync(g->bm_visited, 0, sizeof(uint64_t) * (size_t)words, c->stream));
-    VGL_HIP_TRY(hipMemsetAsync(g->bm_front, 0, sizeof(uint64_t) * (size_t)words, c->stream));
-    hipLaunchKernelGGL(vgl_k_set_bit, dim3(1), dim3(1), 0, c->stream, source, g->bm_visited, g->bm_front);
+    if (source < 0 || source >= V) VGL_FAIL("bfs_run: source vertex out of range");
+    hipLaunchKernelGGL(vgl_k_bfs_init_all, dim3(vgl_grid(V)), dim3(VGL_BLOCK), 0, c->stream, V, source, d_levels, words, g->bm_visited, g->bm_front,
+                       g->bm_next, g->tickets);
 
     vgl_hip_bfs_stats st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int32_t cur = 1;
@@ -512,16 +557,15 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         prevF = F;
         if (!bottom_up) {
             if (!counted) VGL_FAIL("bfs_run: internal error (frontier not counted)");
-            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, false, true));
+            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, false, true, M));
             else {
                 vgl_pred_equal_i32 pred{d_levels, cur};
                 vgl_timed_launch tl(c, "gnf");
                 hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_equal_i32>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred,
                                    g->nrows, g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
             }
-            const bool emit = M <= VGL_TD_EMIT_EDGES;
-            if (emit) VGL_HIP_TRY(hipMemsetAsync(g->bm_next, 0, sizeof(uint64_t) * (size_t)words, c->stream));
-            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit));
+            const bool emit = M <= VGL_TD_EMIT_EDGES;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
+            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap));
             if (emit)
                 hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
                                    g->bm_front, g->bm_next);
@@ -529,11 +573,12 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
         } else {
             if (!front_valid) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
-            VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next));
+            int64_t seq = 0;
+            VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next, &seq));
             hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
                                g->bm_front, g->bm_next);
             VGL_HIP_TRY(hipGetLastError());
-            VGL_TRY(vgl_read_counters(c, false));
+            VGL_TRY(vgl_wait_counters(c, seq));
             st.bu_steps++; st.edges_examined += c->h_counters[C_BU_EDGES];
             st.bu_edges += c->h_counters[C_BU_EDGES]; st.bu_found += c->h_counters[C_BU_FOUND];
             F = c->h_counters[C_BU_FOUND]; M = 0;      // next frontier; bitmaps now describe level cur+1
@@ -585,8 +630,7 @@ int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_
     const int64_t F = c->h_counters[C_FRONT], M = c->h_counters[C_NEIGH];
     if (local_frontier) *local_frontier = F;
     if (local_edges) *local_edges = M;
-    if (F > 0 && M > 0) {
-        hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, (int32_t)F, g->offs, g->tile_first);
+    if (F > 0 && M > 0) {                                        // tile_first came with the write pass
         vgl_timed_launch tl(c, "bfs_top_down");
         hipLaunchKernelGGL(vgl_k_td_expand<true>, dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
                            g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, d_visited_bits, d_levels, level + 1,
@@ -603,9 +647,10 @@ int vgl_hip_bfs_step_bottom_up(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_leve
     if (!g->in.rowptr) VGL_FAIL("bfs_step_bottom_up: the incoming CSR of the owned rows is required");
     // only the owned words of d_next_bits are written by the kernels: clear the rest so the buffer can be exchanged as is
     VGL_HIP_TRY(hipMemsetAsync(d_next_bits, 0, sizeof(uint64_t) * (size_t)vgl_ceil_div(g->V, 64), c->stream));
-    VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, level + 1, d_visited_bits, d_front_bits, d_next_bits));
+    int64_t seq = 0;
+    VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, level + 1, d_visited_bits, d_front_bits, d_next_bits, &seq));
     if (found || probed) {
-        VGL_TRY(vgl_read_counters(c, false));
+        VGL_TRY(vgl_wait_counters(c, seq));
         if (found) *found = c->h_counters[C_BU_FOUND];
         if (probed) *probed = c->h_counters[C_BU_EDGES];
     }

@@ -196,6 +196,11 @@ int vgl_read_counters(vgl_hip_ctx *c, bool fold_shards)
     const int64_t seq = ++c->publish_seq;
     hipLaunchKernelGGL(vgl_k_publish, dim3(1), dim3(64), 0, c->stream, c->d_counters, (volatile int64_t *)c->h_counters, seq);
     VGL_HIP_TRY(hipGetLastError());
+    return vgl_wait_counters(c, seq);
+}
+int64_t vgl_next_seq(vgl_hip_ctx *c) { return ++c->publish_seq; }
+int vgl_wait_counters(vgl_hip_ctx *c, int64_t seq)
+{
     volatile int64_t *flag = (volatile int64_t *)c->h_counters + C_NSLOTS;
     for (long spin = 0; *flag != seq; spin++) {
         if (spin > 2000000) {                          // ~1 s: fall back to a blocking wait (surfaces launch failures too)

@@ -185,6 +185,8 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_TRY(vgl_alloc(&g->heavy_cnt, (size_t)2048));
     VGL_TRY(vgl_alloc(&g->heavy_off, (size_t)2049));
     VGL_TRY(vgl_alloc(&g->bu_partials, (size_t)2048 * 4));
+    VGL_TRY(vgl_alloc(&g->tickets, (size_t)3 * VGL_TICKET_WORDS));
+    VGL_HIP_TRY(hipMemsetAsync(g->tickets, 0, 3 * VGL_TICKET_WORDS * sizeof(uint32_t), c->stream));
     VGL_TRY(vgl_alloc(&g->epoch, (size_t)V));
     VGL_TRY(vgl_alloc(&g->fscratch, (size_t)V));
     VGL_TRY(vgl_alloc(&g->fscratch2, (size_t)V));
@@ -209,7 +211,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     if (!g) return 0;
     if (c) hipStreamSynchronize(c->stream);
     void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->ids, g->offs, g->vt_cnt,
-                    g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->epoch, g->fscratch, g->fscratch2,
+                    g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->pr_hub_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete g;

@@ -82,6 +82,7 @@ struct vgl_hip_graph {
     int32_t *heavy_cnt = nullptr;    // one count per bottom-up workgroup
     int32_t *heavy_off = nullptr;    // exclusive prefix of heavy_cnt (+ total)
     int64_t *bu_partials = nullptr;  // 4 partial counters per bottom-up workgroup
+    uint32_t *tickets = nullptr;     // arrival counters of the "last workgroup finishes the job" kernels (reset by that workgroup)
     int32_t *epoch = nullptr;        // V (SSSP active filter)
     float *fscratch = nullptr;       // V (PR contrib)
     float *fscratch2 = nullptr;      // V (PR rdeg)
@@ -115,6 +116,10 @@ struct vgl_timed_launch {
 };
 
 int vgl_read_counters(vgl_hip_ctx *ctx, bool fold_shards = true);   // D2H all slots into h_counters, synchronises
+// kernels that publish their own results (last workgroup writes the slots it produced + `seq` into the pinned mirror):
+// seq = vgl_next_seq() is passed to the kernel, vgl_wait_counters(seq) spins until it shows up
+int64_t vgl_next_seq(vgl_hip_ctx *ctx);
+int vgl_wait_counters(vgl_hip_ctx *ctx, int64_t seq);
 int vgl_zero_counters(vgl_hip_ctx *ctx, int first, int count);
 int vgl_ensure_partials(vgl_hip_ctx *ctx, size_t n);
 
@@ -126,6 +131,59 @@ static inline int64_t vgl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / 
 #ifdef __HIPCC__
 __device__ __forceinline__ int vgl_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ int vgl_wave() { return threadIdx.x >> 6; }
+
+// true in exactly one workgroup per launch: the last one to get here.  Protocol (cheap on a multi-XCD part: a device-scope
+// release FENCE writes back the whole L2 of the XCD -- every workgroup doing that made a BFS 2.4x slower):
+//   * what the last workgroup must see is written by THREAD 0 with vgl_put_agent (device-scope atomic exchange) BEFORE the
+//     call, and the values the exchanges RETURN are folded into `dep`: the ticket increment is made data-dependent on them, so
+//     it cannot be issued before the exchanges have completed at the coherence point (no fence, no cache write-back);
+//   * the last workgroup reads those values with vgl_load_agent (device-scope atomic load).
+// Call from all threads of every workgroup (dep only matters in thread 0); the ticket is left at 0 for the next launch.
+__device__ __forceinline__ uint32_t vgl_put_agent(int32_t *p, int32_t v) { return (uint32_t)atomicExch(p, v); }
+__device__ __forceinline__ uint32_t vgl_put_agent(int64_t *p, int64_t v)
+{
+    return (uint32_t)atomicExch(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+template <class T> __device__ __forceinline__ void vgl_store_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ T vgl_load_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Tickets are two-level: same-address device atomics serialise (~12 ns each: 2048 workgroups on one counter cost 25 us, more than
+// the launches this saves), so workgroup b arrives at sub-counter b % 32 (its own cache line) and only the last arrival of a
+// sub-counter moves on to the top counter: ~64 + 32 serialised atomics instead of 2048.
+constexpr int VGL_TICKET_FAN = 32;
+constexpr int VGL_TICKET_STRIDE = 16;                                  // uint32 per counter: one 64-byte line each
+constexpr int VGL_TICKET_WORDS = (VGL_TICKET_FAN + 1) * VGL_TICKET_STRIDE;
+__device__ __forceinline__ bool vgl_last_block(uint32_t *ticket, uint32_t dep)
+{
+    __shared__ int s_is_last;
+    if (threadIdx.x == 0) {
+        uint32_t one = 1u;
+        asm volatile("" : "+v"(one) : "v"(dep));                     // `one` now depends on the returned values
+        const uint32_t nb = gridDim.x, sub = blockIdx.x % VGL_TICKET_FAN;
+        const uint32_t expect = (nb - sub + VGL_TICKET_FAN - 1) / VGL_TICKET_FAN;           // workgroups with this residue
+        uint32_t *sub_ticket = ticket + (1 + sub) * VGL_TICKET_STRIDE;
+        bool last = false;
+        if (__hip_atomic_fetch_add(sub_ticket, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1) {
+            vgl_store_agent(sub_ticket, 0u);
+            const uint32_t groups = nb < (uint32_t)VGL_TICKET_FAN ? nb : (uint32_t)VGL_TICKET_FAN;
+            if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
+                vgl_store_agent(ticket, 0u);
+                last = true;
+            }
+        }
+        s_is_last = last;
+    }
+    __syncthreads();
+    return s_is_last != 0;
+}
+// results of a last workgroup go to the device counters and straight into the pinned host mirror, then the sequence number
+__device__ __forceinline__ void vgl_publish2(int64_t *counters, volatile int64_t *host, int64_t seq, int slot_a, int64_t a, int slot_b, int64_t b)
+{
+    counters[slot_a] = a; counters[slot_b] = b;
+    host[slot_a] = a; host[slot_b] = b;
+    __threadfence_system();
+    host[C_NSLOTS] = seq;
+    __threadfence_system();
+}
 
 template <class T>
 __device__ __forceinline__ T vgl_wave_incl_add(T v)
