@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sssp", action="store_true")
+    ap.add_argument("--no-pr-cc", action="store_true", help="skip the PageRank (uniform-25) and CC (symmetrised RMAT-24x16) extras")
     ap.add_argument("--cpu-sources", type=int, default=3)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU super-step path even with one rank (debug)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -231,6 +232,53 @@ def main():
             cpu_baseline = {"value": round(n_cpu * E / dtc, 1), "unit": "edges/s", "cores": O.max_threads(), "kind": "port",
                             "sample": f"{n_cpu} top-down BFS traversals (oracle/vgl_oracle.c, OpenMP) of the same RMAT-{scale} graph"}
             del rp, adj
+
+        # ---- PageRank (BASELINE configs[3]: uniform-random scale 25) and CC (configs[4] stand-in on one GPU: symmetrised
+        #      RMAT-24 x16, 537 M stored edges); TEPS = iterations * E / time for PR (pr.hpp:147), E / time for CC ----
+        if not args.no_pr_cc and scale == 24:
+            g.close()
+            g.out_adj = g.in_adj = g.perm = None
+            torch.cuda.empty_cache()
+            iters = 10
+            for kind, pscale in (("uniform", 25), ("rmat", 24)):
+                pV, pE = 1 << pscale, (1 << pscale) * ef
+                ps, pd = (ctx.gen_uniform if kind == "uniform" else ctx.gen_rmat)(pscale, ef, seed)
+                pg = api.Graph.from_coo(ctx, pV, ps, pd, with_incoming=True, renumber=None if kind == "uniform" else renumber)
+                del ps, pd
+                api.page_rank(pg, 2, raw=True)
+                ctx.timing(True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, pst = api.page_rank(pg, iters, raw=True)
+                torch.cuda.synchronize()
+                dtp = time.perf_counter() - t1
+                n, ms = ctx.timing_get("pr_pull")
+                ctx.timing(False)
+                extra[f"pagerank_{kind}{pscale}"] = {
+                    "teps": round(iters * pE / dtp, 1), "ms_per_iteration": round(dtp / iters * 1e3, 3), "iterations": iters,
+                    "pull_kernel": {"launches": n, "ms_per_launch": round(ms / max(n, 1), 3),
+                                    "algorithmic_GBps": round((8 * pE + 28 * pV) / (ms / max(n, 1) * 1e-3) / 1e9, 1) if ms > 0 else None}}
+                pg.close()
+                del pg
+                torch.cuda.empty_cache()
+            cs, cd = ctx.gen_rmat(24, 16, seed)
+            cs, cd = torch.cat([cs, cd]), torch.cat([cd, cs])
+            cE = cs.numel()
+            cg = api.Graph.from_coo(ctx, 1 << 24, cs, cd, with_incoming=False, renumber=renumber)
+            del cs, cd
+            res = {}
+            for name, sym in (("shiloach_vishkin", False), ("union_find_symmetric", True)):
+                api.connected_components(cg, raw=True, symmetric=sym)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    _, cst = api.connected_components(cg, raw=True, symmetric=sym)
+                torch.cuda.synchronize()
+                dtc = (time.perf_counter() - t1) / 3
+                res[name] = {"teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "passes": cst["hook_passes"]}
+            extra["cc_rmat24x16_symmetrised"] = res
+            cg.close()
+            del cg
         workload = f"BFS direction-optimising on RMAT scale-{scale} (edge factor {ef}), 1xMI355X"
         scaling = "weak"
     else:
