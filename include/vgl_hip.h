@@ -164,6 +164,12 @@ typedef struct {
 #define VGL_HIP_SSSP_ACTIVE_TILES 1      /* same fixed point, skips edge tiles whose sources did not change */
 int vgl_hip_sssp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode,
                      float *d_dist, vgl_hip_sssp_stats *stats);
+/* SSWP::vgl_dijkstra, algorithms/sswp/widest_paths.hpp:5-76 (single-source widest paths): widths[source] = FLT_MAX, others 0;
+ * width[dst] = max(width[dst], min(width[src], capacity)) to the fixed point.  Same kernel and modes as vgl_hip_sssp_run with the
+ * (max, min) path algebra; only min / max of the inputs occur, so the result is bit-identical to the reference (and to its
+ * sequential checker, seq_widest_paths.hpp:5-64).  d_capacities is indexed like the outgoing CSR (global_edge_pos). */
+int vgl_hip_sswp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capacities, int32_t source, int mode,
+                     float *d_widths, vgl_hip_sssp_stats *stats);
 
 /* Same operators and bit-identical distances, bucketed schedule (delta-stepping with a light/heavy edge split): light
  * edges (w < delta) of a vertex are relaxed whenever it improves inside the current distance bucket, heavy edges once the

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE.  Run in the build container only (needs /root/reference):
     make -C oracle ref && python oracle/make_golden.py
 For every case the deterministic generator (oracle/vgl_oracle.c) produces the input edge list,
 the reference multicore build (vgl_compute_api/multicore via oracle/ref_driver.cpp) computes
-BFS levels / SSSP distances / PageRank / CC labels, and the outputs are stored as data:
+BFS levels / SSSP distances / SSWP widths / PageRank / CC labels, and the outputs are stored as data:
 full arrays for V <= 4096, FNV-1a-64 hashes + histograms above.  The script also asserts that
 the C restatement agrees with the reference before writing (so a drifting oracle cannot
 silently produce self-consistent goldens).
@@ -79,6 +79,15 @@ def main():
         my_dist, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
         assert (my_dist.view(np.int32) == dist.view(np.int32)).all(), "oracle SSSP != reference"
 
+        # --- SSWP (capacities = the same f32 edge values; reference vgl and its sequential checker must agree bit for bit) ---
+        run("sswp", g, "csr", o, source, wfile)
+        wd = np.fromfile(o, np.float32).reshape(2, V)
+        width = wd[0].copy()
+        assert (wd[1].view(np.int32) == width.view(np.int32)).all(), "reference SSWP vgl != seq"
+        my_width, _ = O.sswp_bellman_ford(rowptr, adj, w, source)
+        assert (my_width.view(np.int32) == width.view(np.int32)).all(), "oracle SSWP != reference"
+        assert (O.sswp_seq(rowptr, adj, w, source).view(np.int32) == width.view(np.int32)).all(), "oracle SSWP checker != reference"
+
         # --- PageRank ---
         run("pr", g, "csr", o, pr_iters)
         r = np.fromfile(o, np.float32).reshape(2, V)
@@ -111,6 +120,7 @@ def main():
             pin_src=np.uint64(O.fnv1a64(src)), pin_dst=np.uint64(O.fnv1a64(dst)), pin_w=np.uint64(O.fnv1a64(w_in)),
             pin_rowptr=np.uint64(O.fnv1a64(rowptr)), pin_adj=np.uint64(O.fnv1a64(adj)),
             bfs_fnv=np.uint64(O.fnv1a64(levels)), sssp_fnv=np.uint64(O.fnv1a64(dist)), cc_fnv=np.uint64(O.fnv1a64(comp_csr)),
+            sswp_fnv=np.uint64(O.fnv1a64(width)),
             bfs_level_hist=np.bincount(levels + 1),          # index 0 = unvisited (-1)
             bfs_edges_examined=st["edges_examined"], bfs_frontier_total=st["frontier_total"],
             cc_num_components=len(np.unique(comp_csr)),
@@ -119,11 +129,11 @@ def main():
             pr_ref_csr_vs_vcsr=relerr(pr_vgl_csr, pr_vgl_vcsr), pr_ref_vgl_vs_seq=relerr(pr_vgl_csr, pr_seq_csr),
         )
         if full:
-            rec.update(levels=levels, dist=dist, pr_vgl_csr=pr_vgl_csr, pr_vgl_vcsr=pr_vgl_vcsr,
+            rec.update(levels=levels, dist=dist, width=width, pr_vgl_csr=pr_vgl_csr, pr_vgl_vcsr=pr_vgl_vcsr,
                        pr_seq_csr=pr_seq_csr, comp_csr=comp_csr, comp_seq=comp_seq)
         else:                                   # sampled arrays + hashes keep the fixture small
             idx = np.arange(0, V, V // 1024, dtype=np.int64)
-            rec.update(sample_idx=idx, levels_s=levels[idx], dist_s=dist[idx], pr_vgl_csr_s=pr_vgl_csr[idx],
+            rec.update(sample_idx=idx, levels_s=levels[idx], dist_s=dist[idx], width_s=width[idx], pr_vgl_csr_s=pr_vgl_csr[idx],
                        pr_seq_csr_fnv=np.uint64(O.fnv1a64(pr_seq_csr)), comp_csr_s=comp_csr[idx])
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
         print(f"{name}: V={V} E={E} src={source} bfs_levels={st['levels']} "

@@ -55,6 +55,9 @@ def lib():
         L.vgo_sssp_bellman_ford.restype = i32
         L.vgo_sssp_bellman_ford.argtypes = [i32, p, p, p, i32, p, C.c_int]
         L.vgo_sssp_dijkstra.argtypes = [i32, p, p, p, i32, p]
+        L.vgo_sswp_bellman_ford.restype = i32
+        L.vgo_sswp_bellman_ford.argtypes = [i32, p, p, p, i32, p, C.c_int]
+        L.vgo_sswp_seq.argtypes = [i32, p, p, p, i32, p]
         L.vgo_indegree_noloops.argtypes = [i32, i64, p, p, p]
         L.vgo_pagerank.argtypes = [i32, p, p, p, C.c_int, C.c_int, p, C.c_int]
         L.vgo_cc_sv.restype = i32
@@ -144,6 +147,20 @@ def sssp_bellman_ford(rowptr, adj, w, source, parallel=False):
     dist = np.empty(V, np.float32)
     iters = lib().vgo_sssp_bellman_ford(V, _p(rowptr), _p(adj), _p(w), source, _p(dist), int(parallel))
     return dist, iters
+
+
+def sswp_bellman_ford(rowptr, adj, cap, source, parallel=False):
+    V = len(rowptr) - 1
+    width = np.empty(V, np.float32)
+    iters = lib().vgo_sswp_bellman_ford(V, _p(rowptr), _p(adj), _p(cap), source, _p(width), int(parallel))
+    return width, iters
+
+
+def sswp_seq(rowptr, adj, cap, source):
+    V = len(rowptr) - 1
+    width = np.empty(V, np.float32)
+    lib().vgo_sswp_seq(V, _p(rowptr), _p(adj), _p(cap), source, _p(width))
+    return width
 
 
 def sssp_dijkstra(rowptr, adj, w, source):

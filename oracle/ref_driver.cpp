@@ -8,15 +8,16 @@
  * from the reference is copied into this repository.  Built only by
  * `make -C oracle ref` into oracle/_ref/ (git-ignored) when /root/reference exists.
  *
- * One TU, compiled four times (-DAPP_BFS / -DAPP_SSSP / -DAPP_PR / -DAPP_CC) because
+ * One TU, compiled five times (-DAPP_BFS / -DAPP_SSSP / -DAPP_PR / -DAPP_CC / -DAPP_SSWP) because
  * the reference's degree-range thresholds are compile-time macros set per app
- * (apps/bfs/bfs.cpp:3-7, apps/sssp/sssp.cpp:3-12, apps/pr/pr.cpp:3-5, apps/cc/cc.cpp:3-5).
+ * (apps/bfs/bfs.cpp:3-7, apps/sssp/sssp.cpp:3-12, apps/pr/pr.cpp:3-5, apps/cc/cc.cpp:3-5, apps/sswp/sswp.cpp:3-5).
  *
  * usage: ref_driver_<app> <graph.el_container> <csr|vcsr> <out.bin> [app args]
  *   bfs : <source_original_id>                      -> int32 levels[V]
  *   sssp: <source_original_id> <weights.f32> <push|pull>  (csr only) -> f32 dist[V]
  *   pr  : <iterations>                              -> f32 ranks[V] (vgl) then f32 ranks[V] (seq)
  *   cc  : (none)                                    -> int32 comp[V] (vgl SV) then int32 comp[V] (seq bfs)
+ *   sswp: <source_original_id> <capacities.f32>     (csr only) -> f32 width[V] (vgl) then f32 width[V] (seq)
  */
 #if defined(APP_BFS)
 #define INT_ELEMENTS_PER_EDGE 4.0
@@ -35,8 +36,12 @@
 #define INT_ELEMENTS_PER_EDGE 5.0
 #define VECTOR_ENGINE_THRESHOLD_VALUE VECTOR_LENGTH*MAX_SX_AURORA_THREADS*128
 #define VECTOR_CORE_THRESHOLD_VALUE 5*VECTOR_LENGTH
+#elif defined(APP_SSWP)
+#define INT_ELEMENTS_PER_EDGE 5.0
+#define VECTOR_ENGINE_THRESHOLD_VALUE VECTOR_LENGTH*MAX_SX_AURORA_THREADS*128
+#define VECTOR_CORE_THRESHOLD_VALUE 3*VECTOR_LENGTH
 #else
-#error "define one of APP_BFS / APP_SSSP / APP_PR / APP_CC"
+#error "define one of APP_BFS / APP_SSSP / APP_PR / APP_CC / APP_SSWP"
 #endif
 
 #include "graph_library.h"
@@ -103,6 +108,24 @@ int main(int argc, char **argv)
         dump(out, comp);
         VerticesArray<int> check(graph, SCATTER);
         ConnectedComponents::seq_bfs_based(graph, check);
+        dump(out, check);
+#elif defined(APP_SSWP)
+        if (fmt != CSR_GRAPH) { fprintf(stderr, "sswp driver: csr only\n"); return 2; }
+        int source_orig = atoi(argv[4]);
+        long long E = graph.get_edges_count();
+        std::vector<float> w(E);
+        FILE *wf = fopen(argv[5], "rb");
+        if (!wf || fread(w.data(), sizeof(float), E, wf) != (size_t)E) { fprintf(stderr, "bad capacities file\n"); return 3; }
+        fclose(wf);
+        EdgesArray<float> capacities(graph);
+        float *wp = capacities.get_ptr();           /* CSR layout [out E ; in E] */
+        for (long long p = 0; p < E; p++) wp[p] = w[p];
+        graph.copy_outgoing_to_incoming_edges(wp, wp + E);
+        VerticesArray<float> widths(graph, SCATTER);
+        SSWP::vgl_dijkstra(graph, capacities, widths, source_orig);      /* takes the ORIGINAL id (widest_paths.hpp:13) */
+        dump(out, widths);
+        VerticesArray<float> check(graph, SCATTER);
+        SSWP::seq_dijkstra(graph, capacities, check, source_orig);
         dump(out, check);
 #endif
         fclose(out);

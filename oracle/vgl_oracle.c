@@ -261,6 +261,72 @@ int32_t vgo_sssp_bellman_ford(int32_t V, const int64_t *rowptr, const int32_t *a
     return iters;
 }
 
+/* ---- SSWP, single-source widest paths (algorithms/sswp/widest_paths.hpp:5-76): width[source] = inf_val, others 0; every
+ * super-step pushes new = min(width[src], capacity) along every edge and keeps the larger value, until nothing changes.
+ * Only min / max of the inputs: no rounding, the fixed point is unique. ---- */
+int32_t vgo_sswp_bellman_ford(int32_t V, const int64_t *rowptr, const int32_t *adj, const float *cap,
+                              int32_t source, float *width, int parallel)
+{
+    const float inf_val = FLT_MAX - 100.0f;                 /* numeric_limits<float>::max() - MAX_WEIGHT (== FLT_MAX in f32) */
+    float *prev = (float *)malloc(sizeof(float) * (size_t)(V > 0 ? V : 1));
+    #pragma omp parallel for schedule(static) if (parallel)
+    for (int32_t v = 0; v < V; v++) width[v] = 0.0f;
+    width[source] = inf_val;
+    int32_t iters = 0;
+    int64_t changes;
+    do {
+        iters++;
+        #pragma omp parallel for schedule(static) if (parallel)
+        for (int32_t v = 0; v < V; v++) prev[v] = width[v];
+        #pragma omp parallel for schedule(guided, 1024) if (parallel)
+        for (int32_t u = 0; u < V; u++) {
+            for (int64_t p = rowptr[u]; p < rowptr[u + 1]; p++) {
+                const float edge_width = cap[p];
+                const float src_width = width[u];
+                const float new_width = src_width < edge_width ? src_width : edge_width;
+                const int32_t v = adj[p];
+                if (width[v] < new_width) width[v] = new_width;
+            }
+        }
+        changes = 0;
+        #pragma omp parallel for schedule(static) reduction(+ : changes) if (parallel)
+        for (int32_t v = 0; v < V; v++) changes += (prev[v] != width[v]);
+    } while (changes);
+    free(prev);
+    return iters;
+}
+
+/* checker in the spirit of seq_widest_paths.hpp:5-64 (label-correcting with a priority queue): here a plain FIFO worklist --
+ * the result is the same unique fixed point, computed in a different order from the function above */
+void vgo_sswp_seq(int32_t V, const int64_t *rowptr, const int32_t *adj, const float *cap, int32_t source, float *width)
+{
+    for (int32_t v = 0; v < V; v++) width[v] = 0.0f;
+    width[source] = FLT_MAX;
+    size_t qcap = 1024, head = 0, tail = 0, count = 0;
+    int32_t *q = (int32_t *)malloc(qcap * sizeof(int32_t));
+    uint8_t *inq = (uint8_t *)calloc((size_t)(V > 0 ? V : 1), 1);
+    q[tail] = source; tail = (tail + 1) % qcap; count++; inq[source] = 1;
+    while (count > 0) {
+        const int32_t u = q[head]; head = (head + 1) % qcap; count--; inq[u] = 0;
+        for (int64_t p = rowptr[u]; p < rowptr[u + 1]; p++) {
+            const int32_t v = adj[p];
+            const float nw = width[u] < cap[p] ? width[u] : cap[p];
+            if (nw > width[v]) {
+                width[v] = nw;
+                if (!inq[v]) {
+                    if (count == qcap) {                     /* grow the ring */
+                        int32_t *nq = (int32_t *)malloc(2 * qcap * sizeof(int32_t));
+                        for (size_t i = 0; i < count; i++) nq[i] = q[(head + i) % qcap];
+                        free(q); q = nq; head = 0; tail = count; qcap *= 2;
+                    }
+                    q[tail] = v; tail = (tail + 1) % qcap; count++; inq[v] = 1;
+                }
+            }
+        }
+    }
+    free(q); free(inq);
+}
+
 /* seq_shortest_paths.hpp:9-68: lazy-deletion binary-heap Dijkstra keyed by (distance, vertex) */
 typedef struct { float d; int32_t v; } vgo_hitem;
 static inline int vgo_hless(vgo_hitem a, vgo_hitem b) { return (a.d < b.d) || (a.d == b.d && a.v < b.v); }

@@ -77,6 +77,19 @@ def test_algorithms_match_oracle_and_golden(path, ctx, oracle):
     if full:
         assert (dv.view(np.int32) == z["dist"].view(np.int32)).all()
 
+    # ---- SSWP (f1 widening): widest paths on the same capacities, both schedules, bit-exact (only min / max of the inputs) ----
+    ref_width, _ = O.sswp_bellman_ford(rowptr, adj, w, source)
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+        width, st = api.sswp(g, w_d, source, mode)
+        wv = width.cpu().numpy()
+        assert (wv.view(np.int32) == ref_width.view(np.int32)).all(), f"SSWP mode {mode}: widths differ from the oracle"
+        assert O.fnv1a64(wv) == int(z["sswp_fnv"]), "SSWP widths differ from the reference golden"
+    assert wv[source] == np.float32(3.4028234663852886e38) and (wv[ref_levels < 0] == 0).all()      # FLT_MAX at the source, 0 where unreachable
+    if full:
+        assert (wv.view(np.int32) == z["width"].view(np.int32)).all()
+    else:
+        assert (wv[z["sample_idx"]].view(np.int32) == z["width_s"].view(np.int32)).all()
+
     # ---- PageRank ----
     it = int(z["pr_iters"])
     ranks, st = api.page_rank(g, it)
@@ -414,6 +427,7 @@ def test_degree_renumbered_graph(kind, case, ctx, oracle):
     w = ctx.gather_u32(g.perm, ctx.gen_weights(len(hs), seed))
     for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
         assert (api.sssp(g, w, source, mode)[0].cpu().numpy().view(np.int32) == z["dist"].view(np.int32)).all()
+    assert (api.sswp(g, w, source)[0].cpu().numpy().view(np.int32) == z["width"].view(np.int32)).all()
     rk = api.page_rank(g, int(z["pr_iters"]))[0].cpu().numpy()
     ref = O.pagerank(*O.coo_to_csr(V, hs, hd)[:2], int(z["pr_iters"]), 1)
     assert relerr(rk, ref) <= PR_RTOL
@@ -446,6 +460,9 @@ def test_degenerate_graphs(V, edges, ctx, oracle):
         for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
             d, _ = api.sssp(g, w_d, source, mode, delta=0.5)
             assert (d.cpu().numpy().view(np.int32) == dref.view(np.int32)).all()
+        wref, _ = O.sswp_bellman_ford(rowptr, adj, w, source)
+        for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+            assert (api.sswp(g, w_d, source, mode)[0].cpu().numpy().view(np.int32) == wref.view(np.int32)).all()
     assert (api.connected_components(g)[0].cpu().numpy() == O.cc_sv(rowptr, adj)[0]).all()
     rk = api.page_rank(g, 3)[0].cpu().numpy()
     assert (rk.view(np.int32) == O.pagerank(rowptr, adj, 3, 1).view(np.int32)).all()

@@ -303,6 +303,17 @@ def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False, d
     return (dist if raw else graph.to_original(dist)), _stats(st)
 
 
+def sswp(graph, capacities, source, mode=SSSP_ACTIVE_TILES, widths=None, raw=False):
+    """single-source widest paths (SSWP::vgl_dijkstra): widths[source] = FLT_MAX, unreachable vertices 0; capacities in the
+    order of the outgoing CSR.  source / result in ORIGINAL numbering unless raw=True."""
+    ctx = graph.ctx
+    widths = ctx.empty(graph.V, torch.float32) if widths is None else widths
+    st = _l.SsspStats()
+    src = int(source) if raw else graph.vertex_id(source)
+    _l.check(ctx.L.vgl_hip_sswp_run(ctx.h, graph.h, _ptr(capacities), src, int(mode), _ptr(widths), C.byref(st)))
+    return (widths if raw else graph.to_original(widths)), _stats(st)
+
+
 def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False):
     """indeg_noloops (optional) is indexed in the graph's own numbering."""
     ctx = graph.ctx

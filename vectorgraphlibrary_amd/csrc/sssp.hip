@@ -11,18 +11,45 @@
 // VGL_HIP_SSSP_ACTIVE_TILES additionally keeps epoch[v] = last super-step in which d[v] decreased and skips a whole
 // tile (no adjacency / weight traffic) when none of its rows changed in the current or previous super-step.
 // Algorithmic bytes per streamed edge: 4 (adj) + 4 (weight) + 4 (dist[dst]) = 12; per vertex and super-step 28.
+//
+// The same kernel runs single-source WIDEST paths (SSWP::vgl_dijkstra, algorithms/sswp/widest_paths.hpp:5-76): the path algebra
+// is a template parameter -- (min, +) with "smaller is better" for SSSP, (max, min) with "larger is better" for SSWP.  Widths
+// are non-negative too, so the integer atomic-max on the f32 bits is exact; only min / max of inputs occur (no rounding).
 #include "vgl_hip_internal.h"
 #include <cfloat>
+#include <string>
 
+struct vgl_path_shortest {                        // shortest_paths.hpp:99-133
+    static __device__ __forceinline__ float source_value() { return 0.0f; }
+    static __device__ __forceinline__ float other_value() { return FLT_MAX; }     // inf_val = FLT_MAX - MAX_WEIGHT == FLT_MAX in f32
+    static __device__ __forceinline__ bool live(float d) { return d < FLT_MAX; }
+    static __device__ __forceinline__ float dead_value() { return FLT_MAX; }
+    static __device__ __forceinline__ float extend(float d, float w) { return __fadd_rn(d, w); }      // src_weight + weight
+    static __device__ __forceinline__ bool better(float cand, float old) { return old > cand; }
+    static __device__ __forceinline__ int update(float *p, float cand) { return atomicMin(reinterpret_cast<int *>(p), __float_as_int(cand)); }
+    static __device__ __forceinline__ bool improved(int before, float cand) { return before > __float_as_int(cand); }
+};
+struct vgl_path_widest {                          // widest_paths.hpp:22-55
+    static __device__ __forceinline__ float source_value() { return FLT_MAX; }    // numeric_limits<float>::max() - MAX_WEIGHT == FLT_MAX
+    static __device__ __forceinline__ float other_value() { return 0.0f; }
+    static __device__ __forceinline__ bool live(float d) { return d > 0.0f; }     // min(0, capacity) = 0 never beats a width >= 0
+    static __device__ __forceinline__ float dead_value() { return 0.0f; }
+    static __device__ __forceinline__ float extend(float d, float w) { return fminf(d, w); }          // vect_min(widths[src], edge_width)
+    static __device__ __forceinline__ bool better(float cand, float old) { return old < cand; }
+    static __device__ __forceinline__ int update(float *p, float cand) { return atomicMax(reinterpret_cast<int *>(p), __float_as_int(cand)); }
+    static __device__ __forceinline__ bool improved(int before, float cand) { return before < __float_as_int(cand); }
+};
+
+template <class Path>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_init(int32_t V, int32_t source, float *dist, int32_t *epoch)
 {
     for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK) {
-        dist[v] = (v == source) ? 0.0f : FLT_MAX;     // inf_val = FLT_MAX - MAX_WEIGHT == FLT_MAX in f32 (shortest_paths.hpp:102)
+        dist[v] = (v == source) ? Path::source_value() : Path::other_value();
         if (epoch) epoch[v] = (v == source) ? 0 : -4;
     }
 }
 
-template <bool ACTIVE_FILTER>
+template <bool ACTIVE_FILTER, class Path>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax(const int64_t *rowptr, const int32_t *adj, const float *w,
                                                               const int32_t *tile_row, int64_t E, int32_t row_base,
                                                               float *dist, int32_t *epoch, int32_t iter, int64_t *counters, int64_t *shards)
@@ -75,20 +102,20 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax(const int64_t *row
                 prev_row = rows[j];
                 const int32_t u = row_base + r_first + rows[j];
                 d = dist[u];
-                live = d < FLT_MAX;
+                live = Path::live(d);
                 if (ACTIVE_FILTER) live = live && (epoch[u] >= iter - 1);
             }
             const bool ok = live && (i0 + j < n);
-            dsrc[j] = ok ? d : FLT_MAX;
+            dsrc[j] = ok ? d : Path::dead_value();
             olds[j] = ok ? dist[dsts[j]] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < VGL_EPT; j++) {
-            if (dsrc[j] < FLT_MAX) {
-                const float nd = __fadd_rn(dsrc[j], ws[j]);          // src_weight + weight (shortest_paths.hpp:126-130)
-                if (olds[j] > nd) {
-                    const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nd));
-                    if (before > __float_as_int(nd)) {
+            if (Path::live(dsrc[j])) {
+                const float nd = Path::extend(dsrc[j], ws[j]);       // shortest_paths.hpp:126-130 / widest_paths.hpp:45-50
+                if (Path::better(nd, olds[j])) {
+                    const int before = Path::update(dist + dsts[j], nd);
+                    if (Path::improved(before, nd)) {
                         changed = 1;
                         if (ACTIVE_FILTER) epoch[dsts[j]] = iter;
                     }
@@ -105,17 +132,45 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax(const int64_t *row
 
 static inline unsigned vgl_grid1(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, vgl_ceil_div(n, VGL_BLOCK))); }
 
+template <class Path>
 static int vgl_sssp_launch(vgl_hip_ctx *c, vgl_hip_graph *g, const float *w, float *dist, bool filter, int32_t iter)
 {
     if (g->out.ntiles == 0) return 0;
     vgl_timed_launch tl(c, "sssp_relax");
     if (filter)
-        hipLaunchKernelGGL(vgl_k_sssp_relax<true>, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
+        hipLaunchKernelGGL((vgl_k_sssp_relax<true, Path>), dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
                            g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters, c->d_shards);
     else
-        hipLaunchKernelGGL(vgl_k_sssp_relax<false>, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
+        hipLaunchKernelGGL((vgl_k_sssp_relax<false, Path>), dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj, w,
                            g->out.tile_row, g->out.edges, g->row_begin, dist, g->epoch, iter, c->d_counters, c->d_shards);
     VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// shared driver of vgl_hip_sssp_run / vgl_hip_sswp_run: super-steps until a pass changes nothing
+template <class Path>
+static int vgl_path_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode, float *d_dist, vgl_hip_sssp_stats *stats,
+                        const char *who)
+{
+    auto fail = [&](const char *what) { return vgl_set_error(__FILE__, __LINE__, (std::string(who) + ": " + what).c_str()); };
+    if (!c || !g || !d_weights || !d_dist) return fail("null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) return fail("graph handle must own all rows (use the *_relax_owned step for shards)");
+    if (source < 0 || source >= g->V) return fail("source vertex out of range");
+    if (mode != VGL_HIP_SSSP_ALL_ACTIVE && mode != VGL_HIP_SSSP_ACTIVE_TILES) return fail("unknown mode");
+    const bool filter = mode == VGL_HIP_SSSP_ACTIVE_TILES;
+    hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, g->epoch);
+    VGL_TRY(vgl_zero_counters(c, C_EDGES, 1));
+    vgl_hip_sssp_stats st = {0, 0, 0};
+    for (int32_t iter = 1;; iter++) {
+        VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
+        VGL_TRY(vgl_sssp_launch<Path>(c, g, d_weights, d_dist, filter, iter));
+        VGL_TRY(vgl_read_counters(c));
+        st.iterations = iter;
+        if (!c->h_counters[C_CHANGED]) break;      // do { ... } while(changes)  (shortest_paths.hpp:112-154, widest_paths.hpp:34-64)
+    }
+    st.edges_relaxed = c->h_counters[C_EDGES];
+    st.algorithmic_bytes = 12 * st.edges_relaxed + 28 * (int64_t)g->V * st.iterations;
+    if (stats) *stats = st;
     return 0;
 }
 
@@ -125,7 +180,7 @@ int vgl_hip_sssp_init(vgl_hip_ctx *c, int32_t V, int32_t source, float *d_dist)
 {
     if (!c || !d_dist) VGL_FAIL("sssp_init: null argument");
     if (source < 0 || source >= V) VGL_FAIL("sssp_init: source vertex out of range");
-    hipLaunchKernelGGL(vgl_k_sssp_init, dim3(vgl_grid1(V)), dim3(VGL_BLOCK), 0, c->stream, V, source, d_dist, (int32_t *)nullptr);
+    hipLaunchKernelGGL(vgl_k_sssp_init<vgl_path_shortest>, dim3(vgl_grid1(V)), dim3(VGL_BLOCK), 0, c->stream, V, source, d_dist, (int32_t *)nullptr);
     VGL_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -133,32 +188,20 @@ int vgl_hip_sssp_init(vgl_hip_ctx *c, int32_t V, int32_t source, float *d_dist)
 int vgl_hip_sssp_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode, float *d_dist,
                      vgl_hip_sssp_stats *stats)
 {
-    if (!c || !g || !d_weights || !d_dist) VGL_FAIL("sssp_run: null argument");
-    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("sssp_run: graph handle must own all rows (use vgl_hip_sssp_relax_owned for shards)");
-    if (source < 0 || source >= g->V) VGL_FAIL("sssp_run: source vertex out of range");
-    if (mode != VGL_HIP_SSSP_ALL_ACTIVE && mode != VGL_HIP_SSSP_ACTIVE_TILES) VGL_FAIL("sssp_run: unknown mode");
-    const bool filter = mode == VGL_HIP_SSSP_ACTIVE_TILES;
-    hipLaunchKernelGGL(vgl_k_sssp_init, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, g->epoch);
-    VGL_TRY(vgl_zero_counters(c, C_EDGES, 1));
-    vgl_hip_sssp_stats st = {0, 0, 0};
-    for (int32_t iter = 1;; iter++) {
-        VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
-        VGL_TRY(vgl_sssp_launch(c, g, d_weights, d_dist, filter, iter));
-        VGL_TRY(vgl_read_counters(c));
-        st.iterations = iter;
-        if (!c->h_counters[C_CHANGED]) break;      // do { ... } while(changes)  (shortest_paths.hpp:112-154)
-    }
-    st.edges_relaxed = c->h_counters[C_EDGES];
-    st.algorithmic_bytes = 12 * st.edges_relaxed + 28 * (int64_t)g->V * st.iterations;
-    if (stats) *stats = st;
-    return 0;
+    return vgl_path_run<vgl_path_shortest>(c, g, d_weights, source, mode, d_dist, stats, "sssp_run");
+}
+
+int vgl_hip_sswp_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_capacities, int32_t source, int mode, float *d_widths,
+                     vgl_hip_sssp_stats *stats)
+{
+    return vgl_path_run<vgl_path_widest>(c, g, d_capacities, source, mode, d_widths, stats, "sswp_run");
 }
 
 int vgl_hip_sssp_relax_owned(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, float *d_dist, int *changed)
 {
     if (!c || !g || !d_weights || !d_dist) VGL_FAIL("sssp_relax_owned: null argument");
     VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
-    VGL_TRY(vgl_sssp_launch(c, g, d_weights, d_dist, false, 1));
+    VGL_TRY(vgl_sssp_launch<vgl_path_shortest>(c, g, d_weights, d_dist, false, 1));
     VGL_TRY(vgl_read_counters(c));
     if (changed) *changed = (int)c->h_counters[C_CHANGED];
     return 0;

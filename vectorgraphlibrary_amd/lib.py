@@ -79,6 +79,7 @@ _SIGNATURES = {
     "vgl_hip_count_not_equal_u32": [_p, _i32, _p, _p, C.POINTER(_i64)],
     "vgl_hip_bfs_run": [_p, _p, _i32, _int, _p, C.POINTER(BfsStats)],
     "vgl_hip_sssp_run": [_p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
+    "vgl_hip_sswp_run": [_p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
     "vgl_hip_sssp_run_delta": [_p, _p, _p, _i32, C.c_float, _p, C.POINTER(SsspStats)],
     "vgl_hip_sssp_plan_create": [_p, _p, _p, C.c_float, _pp],
     "vgl_hip_sssp_plan_destroy": [_p, _p],
