@@ -124,6 +124,23 @@ inline std::vector<float> seq_dijkstra(const HostCSR &g, const std::vector<float
     }
     return d;
 }
+// in the spirit of SSWP::seq_dijkstra (seq_widest_paths.hpp:5-64): label-correcting with a max-priority queue
+inline std::vector<float> seq_widest_paths(const HostCSR &g, const std::vector<float> &cap, int source)
+{
+    std::vector<float> wd((size_t)g.V, 0.0f);
+    typedef std::pair<float, int> item;
+    std::priority_queue<item> pq;
+    wd[source] = std::numeric_limits<float>::max(); pq.push({wd[source], source});
+    while (!pq.empty()) {
+        const int u = pq.top().second; pq.pop();
+        for (long long p = g.rowptr[u]; p < g.rowptr[u + 1]; p++) {
+            const int v = g.adj[p];
+            const float nw = std::min(wd[u], cap[p]);
+            if (nw > wd[v]) { wd[v] = nw; pq.push({nw, v}); }
+        }
+    }
+    return wd;
+}
 inline std::vector<float> seq_page_rank(const HostCSR &g, int iterations)
 {
     const int V = g.V;

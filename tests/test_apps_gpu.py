@@ -56,6 +56,19 @@ def test_sssp_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
     assert (np.fromfile(dump, np.float32).view(np.int32) == ref.view(np.int32)).all()
 
 
+@pytest.mark.parametrize("mode", [[], ["-fused"]], ids=["operator_api", "fused"])
+@pytest.mark.parametrize("kind,scale,ef,seed", CASES)
+def test_sswp_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
+    """widest paths (f1 widening): the lambda version on the generic operator path and the fused kernel, both bit-exact"""
+    O = oracle
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
+    source = O.pick_source(rowptr, seed)
+    out, dump = run_app("sswp", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-source", source, "-check"] + mode, tmp_path)
+    assert "error count: 0" in out
+    ref, _ = O.sswp_bellman_ford(rowptr, adj, O.gen_weights(len(src), seed)[perm], source)
+    assert (np.fromfile(dump, np.float32).view(np.int32) == ref.view(np.int32)).all()
+
+
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)
 def test_pr_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
     O = oracle
