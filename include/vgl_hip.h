@@ -200,6 +200,12 @@ typedef struct {
     int32_t hook_passes;
     int64_t algorithmic_bytes; /* (8*E + 12*V) per hook pass + 12*V per jump pass */
 } vgl_hip_cc_stats;
+/* HITS::vgl_hits, algorithms/hits/hits.hpp:5-100 (f64, apps/hits/hits.cpp:13): auth = hub = 1, then `steps` times
+ *   auth[v] = sum of hub over the in-neighbours, auth /= ||auth||_2, hub[v] = sum of auth over the out-neighbours, hub /= ||hub||_2.
+ * Per-vertex sums run in adjacency order (the sequential checker's order, hits.hpp:117-160); norms are folded in a fixed order.
+ * Needs the incoming CSR.  Deterministic; agrees with seq_hits to ~1e-15 relative. */
+int vgl_hip_hits_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int steps, double *d_auth, double *d_hub);
+
 /* vgl_shiloach_vishkin, shiloach_vishkin.hpp:7-88: labels = min id that reaches each vertex */
 int vgl_hip_cc_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc_stats *stats);
 /* Same labels for SYMMETRIC graphs only (every edge stored in both directions, as the reference's cc app builds its input,

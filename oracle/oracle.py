@@ -58,6 +58,7 @@ def lib():
         L.vgo_sswp_bellman_ford.restype = i32
         L.vgo_sswp_bellman_ford.argtypes = [i32, p, p, p, i32, p, C.c_int]
         L.vgo_sswp_seq.argtypes = [i32, p, p, p, i32, p]
+        L.vgo_hits.argtypes = [i32, p, p, p, p, i32, p, p]
         L.vgo_indegree_noloops.argtypes = [i32, i64, p, p, p]
         L.vgo_pagerank.argtypes = [i32, p, p, p, C.c_int, C.c_int, p, C.c_int]
         L.vgo_cc_sv.restype = i32
@@ -147,6 +148,22 @@ def sssp_bellman_ford(rowptr, adj, w, source, parallel=False):
     dist = np.empty(V, np.float32)
     iters = lib().vgo_sssp_bellman_ford(V, _p(rowptr), _p(adj), _p(w), source, _p(dist), int(parallel))
     return dist, iters
+
+
+def transpose_csr(rowptr, adj):
+    """incoming CSR the way VGL_Graph::import builds it (vgl_graph.hpp:57-68): the OUT-CSR-ordered edge list, transposed, stable"""
+    V = len(rowptr) - 1
+    csr_src = np.repeat(np.arange(V, dtype=np.int32), np.diff(rowptr))
+    in_rowptr, in_adj, _ = coo_to_csr(V, adj, csr_src, want_perm=False)
+    return in_rowptr, in_adj
+
+
+def hits(rowptr, adj, steps):
+    V = len(rowptr) - 1
+    in_rowptr, in_adj = transpose_csr(rowptr, adj)
+    auth, hub = np.empty(V, np.float64), np.empty(V, np.float64)
+    lib().vgo_hits(V, _p(rowptr), _p(adj), _p(in_rowptr), _p(in_adj), int(steps), _p(auth), _p(hub))
+    return auth, hub
 
 
 def sswp_bellman_ford(rowptr, adj, cap, source, parallel=False):

@@ -8,7 +8,7 @@
  * from the reference is copied into this repository.  Built only by
  * `make -C oracle ref` into oracle/_ref/ (git-ignored) when /root/reference exists.
  *
- * One TU, compiled five times (-DAPP_BFS / -DAPP_SSSP / -DAPP_PR / -DAPP_CC / -DAPP_SSWP) because
+ * One TU, compiled six times (-DAPP_BFS / -DAPP_SSSP / -DAPP_PR / -DAPP_CC / -DAPP_SSWP / -DAPP_HITS) because
  * the reference's degree-range thresholds are compile-time macros set per app
  * (apps/bfs/bfs.cpp:3-7, apps/sssp/sssp.cpp:3-12, apps/pr/pr.cpp:3-5, apps/cc/cc.cpp:3-5, apps/sswp/sswp.cpp:3-5).
  *
@@ -18,6 +18,7 @@
  *   pr  : <iterations>                              -> f32 ranks[V] (vgl) then f32 ranks[V] (seq)
  *   cc  : (none)                                    -> int32 comp[V] (vgl SV) then int32 comp[V] (seq bfs)
  *   sswp: <source_original_id> <capacities.f32>     (csr only) -> f32 width[V] (vgl) then f32 width[V] (seq)
+ *   hits: <steps>                                   -> f64 auth[V], hub[V] (vgl) then f64 auth[V], hub[V] (seq)
  */
 #if defined(APP_BFS)
 #define INT_ELEMENTS_PER_EDGE 4.0
@@ -40,8 +41,12 @@
 #define INT_ELEMENTS_PER_EDGE 5.0
 #define VECTOR_ENGINE_THRESHOLD_VALUE VECTOR_LENGTH*MAX_SX_AURORA_THREADS*128
 #define VECTOR_CORE_THRESHOLD_VALUE 3*VECTOR_LENGTH
+#elif defined(APP_HITS)
+#define INT_ELEMENTS_PER_EDGE 5.0
+#define VECTOR_ENGINE_THRESHOLD_VALUE 2147483646
+#define VECTOR_CORE_THRESHOLD_VALUE 5*VECTOR_LENGTH
 #else
-#error "define one of APP_BFS / APP_SSSP / APP_PR / APP_CC / APP_SSWP"
+#error "define one of APP_BFS / APP_SSSP / APP_PR / APP_CC / APP_SSWP / APP_HITS"
 #endif
 
 #include "graph_library.h"
@@ -127,6 +132,16 @@ int main(int argc, char **argv)
         VerticesArray<float> check(graph, SCATTER);
         SSWP::seq_dijkstra(graph, capacities, check, source_orig);
         dump(out, check);
+#elif defined(APP_HITS)
+        int steps = atoi(argv[4]);
+        VerticesArray<double> auth(graph), hub(graph);
+        HITS::vgl_hits(graph, auth, hub, steps);
+        dump(out, auth);
+        dump(out, hub);
+        VerticesArray<double> check_auth(graph), check_hub(graph);
+        HITS::seq_hits(graph, check_auth, check_hub, steps);
+        dump(out, check_auth);
+        dump(out, check_hub);
 #endif
         fclose(out);
         VGL_RUNTIME::finalize_library();

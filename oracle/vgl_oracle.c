@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <math.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -259,6 +260,36 @@ int32_t vgo_sssp_bellman_ford(int32_t V, const int64_t *rowptr, const int32_t *a
     } while (changes);
     free(prev);
     return iters;
+}
+
+/* ---- HITS (algorithms/hits/hits.hpp:103-173 seq_hits, the reference's own checker; f64 like apps/hits/hits.cpp:13):
+ * auth = hub = 1; per step auth[v] = sum of hub over the incoming neighbours (adjacency order), normalised by the 2-norm,
+ * then hub[v] = sum of auth over the outgoing neighbours, normalised.  Sequential `+=` chains, norm accumulated in vertex
+ * order exactly like the reference loop. ---- */
+void vgo_hits(int32_t V, const int64_t *out_rowptr, const int32_t *out_adj, const int64_t *in_rowptr, const int32_t *in_adj,
+              int32_t steps, double *auth, double *hub)
+{
+    for (int32_t v = 0; v < V; v++) { auth[v] = 1; hub[v] = 1; }
+    for (int32_t step = 0; step < steps; step++) {
+        double norm = 0.0;
+        for (int32_t v = 0; v < V; v++) {
+            double p_auth = 0.0;
+            for (int64_t p = in_rowptr[v]; p < in_rowptr[v + 1]; p++) p_auth += hub[in_adj[p]];
+            auth[v] = p_auth;
+            norm += p_auth * p_auth;
+        }
+        norm = sqrt(norm);
+        for (int32_t v = 0; v < V; v++) auth[v] /= norm;
+        norm = 0.0;
+        for (int32_t v = 0; v < V; v++) {
+            double p_hub = 0.0;
+            for (int64_t p = out_rowptr[v]; p < out_rowptr[v + 1]; p++) p_hub += auth[out_adj[p]];
+            hub[v] = p_hub;
+            norm += p_hub * p_hub;
+        }
+        norm = sqrt(norm);
+        for (int32_t v = 0; v < V; v++) hub[v] /= norm;
+    }
 }
 
 /* ---- SSWP, single-source widest paths (algorithms/sswp/widest_paths.hpp:5-76): width[source] = inf_val, others 0; every

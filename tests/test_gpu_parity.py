@@ -9,7 +9,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith("hits_"))
+HITS_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hits_*.npz")))
 PR_RTOL = 1e-6
 
 
@@ -629,3 +630,51 @@ def test_symmetric_cc_matches_shiloach_vishkin(kind, scale, ef, renumber, ctx, o
     g.close()
     if renumber:
         plain.close()
+
+
+HITS_RTOL = 1e-12          # f64; per-vertex sums keep the reference's order, only the norm's summation order differs (~1e-16)
+
+
+def _relerr64(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", HITS_GOLDEN, ids=[os.path.basename(p)[:-4] for p in HITS_GOLDEN])
+def test_hits_matches_oracle_and_golden(path, ctx, oracle):
+    """HITS (f1 widening) through vgl_hip_hits_run against the oracle and the reference's fixtures, identity and degree-sorted ids"""
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    z = np.load(path)
+    kind, scale, ef, seed, steps = str(z["kind"]), int(z["scale"]), int(z["edge_factor"]), int(z["seed"]), int(z["steps"])
+    V = 1 << scale
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    for renumber in (None, "total"):
+        g = api.Graph.from_coo(ctx, V, src, dst, renumber=renumber)
+        auth, hub = api.hits(g, steps)
+        a, h = auth.cpu().numpy(), hub.cpu().numpy()
+        assert _relerr64(a, z["auth_seq"]) <= HITS_RTOL and _relerr64(h, z["hub_seq"]) <= HITS_RTOL
+        assert _relerr64(a, z["auth_vgl_csr"]) <= HITS_RTOL and _relerr64(h, z["hub_vgl_csr"]) <= HITS_RTOL
+        a2, h2 = api.hits(g, steps)                                    # deterministic: fixed-order norms, sequential chains
+        assert torch.equal(a2, auth) and torch.equal(h2, hub)
+        g.close()
+
+
+@pytest.mark.gpu
+def test_hits_hub_rows_and_zero_steps(ctx, oracle):
+    """rows above the hub threshold in BOTH directions (RMAT-14x32), and steps = 0 leaves the initial all-ones vectors"""
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    scale, ef, seed = 14, 32, 9
+    V = 1 << scale
+    src, dst = ctx.gen_rmat(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst)
+    rowptr, adj = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy()
+    assert int(np.diff(rowptr).max()) >= 2048 and int(np.diff(g.in_rowptr.cpu().numpy()).max()) >= 2048
+    wa, wh = O.hits(rowptr, adj, 3)
+    a, h = api.hits(g, 3)
+    assert _relerr64(a.cpu().numpy(), wa) <= HITS_RTOL and _relerr64(h.cpu().numpy(), wh) <= HITS_RTOL
+    a0, h0 = api.hits(g, 0)
+    assert float(a0.min()) == 1.0 == float(a0.max()) and float(h0.min()) == 1.0 == float(h0.max())
+    g.close()

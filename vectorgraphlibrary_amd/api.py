@@ -323,6 +323,17 @@ def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False):
     return (ranks if raw else graph.to_original(ranks)), _stats(st)
 
 
+def hits(graph, steps, raw=False):
+    """HITS authorities and hubs (f64) after `steps` steps; needs the incoming CSR.  ORIGINAL numbering unless raw=True."""
+    ctx = graph.ctx
+    auth, hub = ctx.empty(graph.V, torch.float64), ctx.empty(graph.V, torch.float64)
+    _l.check(ctx.L.vgl_hip_hits_run(ctx.h, graph.h, int(steps), _ptr(auth), _ptr(hub)))
+    if raw or graph.fwd is None:
+        return auth, hub
+    idx = graph.fwd.long()
+    return auth[idx], hub[idx]
+
+
 def connected_components(graph, comp=None, raw=False, symmetric=False):
     """labels = smallest ORIGINAL vertex id that reaches each vertex (raw=True: smallest id in the graph's numbering).
     symmetric=True: the caller vouches that every edge is stored in both directions; the same labels then come from a min-id

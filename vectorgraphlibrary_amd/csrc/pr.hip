@@ -7,11 +7,10 @@
 //             to f32 once (the reference's f32 OpenMP reduction is thread-order dependent)
 //   pull    : rank[src] = k + d * (sum_{src->dst, dst != src} contrib[dst] + dangling), the sum taken IN ADJACENCY ORDER
 //             in f32 exactly like the reference's `+=` chain, so the result is bit-identical to seq_page_rank's
-//             evaluation order (seq_pr.hpp:81-96).  Workgroup = 256 consecutive rows, one thread per row; the rows' edges are
-//             staged through LDS in tiles of 2048 (coalesced adjacency read + contrib gather by all threads), then every
-//             thread adds its own row's slice sequentially from LDS.
+//             evaluation order (seq_pr.hpp:81-96): vgl_k_pull_sum<float, skip self loops> of vgl_pull.h (256 rows per workgroup,
+//             edges staged through LDS; rows with >= 512 edges go through the hub schedule of the same launch).
 // Algorithmic bytes per iteration: 8*E + 28*V.
-#include "vgl_hip_internal.h"
+#include "vgl_pull.h"
 #include <queue>
 
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pr_sum_partial(int32_t V, const float *ranks, double *partials)
@@ -58,25 +57,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pr_dangling(int nparts, const
     if (threadIdx.x == 0) *dangling_out = (float)acc;
 }
 
-// Rows with at least VGL_PR_HUB_DEGREE edges are "hubs": their strictly sequential f32 sum (deg dependent adds) would stall a
-// whole 256-row workgroup (a 7*10^5-edge RMAT hub took 1.7 s per iteration that way).  They are listed once per graph, largest
-// first, and summed by the first `hub_blocks` workgroups of the pull kernel (one workgroup per CU, i.e. one wavefront per SIMD,
-// raised issue priority) while the remaining workgroups pull the ordinary rows on the same CUs (a separate kernel on a side
-// stream overlapped worse: 5.0 vs 4.2 ms per RMAT-24 iteration): a wavefront takes its hubs
-// from a precomputed longest-first schedule, gathers 512 values per batch (the next batch's gathers and the adjacency of the one after in flight; 1024-value batches cost
-// 112 VGPRs and the ordinary rows' occupancy), parks them in LDS and folds them IN
-// ADJACENCY ORDER with one dependent v_add per value (all lanes compute the same chain; broadcast LDS reads).  The critical
-// path of an iteration is the chain of the largest hub (~10 cycles per edge measured), not the sum over hubs.
-constexpr int VGL_PR_HUB_DEGREE = 512;
-constexpr int VGL_PR_HUB_BATCH = 512;
-constexpr int VGL_PR_HUB_BLOCKS = 256;      // one per CU
-
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pr_find_hubs(int32_t nrows, const int64_t *rowptr, int32_t *hub_rows, int32_t *hub_deg,
-                                                                int32_t *hub_count)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_find_hubs(int32_t nrows, const int64_t *rowptr, int32_t *hub_rows, int32_t *hub_deg,
+                                                                  int32_t *hub_count)
 {
     for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK) {
         const int64_t dg = rowptr[r + 1] - rowptr[r];
-        if (dg >= VGL_PR_HUB_DEGREE) {                       // few thousand rows, once per graph
+        if (dg >= VGL_PULL_HUB_DEGREE) {                     // few thousand rows, once per graph
             const int slot = atomicAdd(hub_count, 1);
             hub_rows[slot] = r;
             hub_deg[slot] = (int32_t)min(dg, (int64_t)INT32_MAX);
@@ -84,120 +70,15 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pr_find_hubs(int32_t nrows, c
     }
 }
 
-__device__ __forceinline__ void vgl_pr_hub_waves(float *s_buf, const int32_t *hub_rows, const int32_t *hub_off, int32_t row_base,
-                                                 const int64_t *rowptr, const int32_t *adj, const float *contrib, const float *dangling_ptr,
-                                                 float k, float d, float *ranks_out)
-{
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = vgl_lane();
-    float *cur = s_buf + vgl_wave() * VGL_PR_HUB_BATCH;                  // this wavefront's batch (consumed before the next is parked)
-    constexpr int U = VGL_PR_HUB_BATCH / 64;
-    constexpr int B = VGL_PR_HUB_BATCH;
-    // No lane-dependent control flow anywhere below: the LDS hand-over relies on the wavefront staying converged (a ticket fetched
-    // under `if (lane == 0)` let the compiler unswitch the loop on the lane id and the lanes ran apart).  Each wavefront owns a
-    // precomputed list of hubs (longest-processing-time schedule built on the host, vgl_pr_find_hubs).
-    const int32_t w = __builtin_amdgcn_readfirstlane((int32_t)blockIdx.x * VGL_WAVES + vgl_wave());    // scalar: loops are uniform
-    const int32_t h_end = hub_off[w + 1];
-    for (int32_t h = hub_off[w]; h < h_end; h++) {
-        const int32_t r = hub_rows[h];
-        const int64_t b = rowptr[r];
-        const uint32_t n = (uint32_t)(rowptr[r + 1] - b);               // a row has fewer than 2^31 edges
-        const int32_t *adj_h = adj + b;                                  // scalar base + 32-bit lane offsets
-        const int32_t self = row_base + r;
-        float acc = 0.0f;
-        float val[U];
-        int32_t dst[U];
-        auto load_adj = [&](uint32_t base) {
-#pragma unroll
-            for (int u = 0; u < U; u++) { const uint32_t q = base + u * 64 + lane; dst[u] = q < n ? adj_h[q] : self; }
-        };
-        auto gather = [&]() {
-#pragma unroll
-            for (int u = 0; u < U; u++) val[u] = (dst[u] != self) ? contrib[(uint32_t)dst[u]] : 0.0f;   // x + 0.0f == x: exact no-op
-        };
-        // three batches in flight: fold(i) from LDS | gathers of batch i+1 | adjacency of batch i+2
-        load_adj(0);
-        gather();
-        if (B < n) load_adj(B);
-        for (uint32_t base = 0; base < n; base += B) {
-#pragma unroll
-            for (int u = 0; u < U; u++) cur[u * 64 + lane] = val[u];
-            if (base + B < n) {
-                gather();
-                if (base + 2 * B < n) load_adj(base + 2 * B);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int n4 = (int)min((uint32_t)(B / 4), (n - base + 3) / 4);   // the tail of the batch is zero-filled
-            const float4 *p = reinterpret_cast<const float4 *>(cur);
-#pragma unroll 8
-            for (int i = 0; i < n4; i++) {
-                const float4 v = p[i];                                  // same address in every lane: LDS broadcast
-                acc = __fadd_rn(acc, v.x);
-                acc = __fadd_rn(acc, v.y);
-                acc = __fadd_rn(acc, v.z);
-                acc = __fadd_rn(acc, v.w);
-            }
-        }
-        ranks_out[self] = __fadd_rn(k, __fmul_rn(d, __fadd_rn(acc, *dangling_ptr)));     // all lanes: same value, same address
+struct vgl_pr_epilogue {                                     // k + d * (rank + dangling)  (pr.hpp:121)
+    const float *dangling;
+    float k, d;
+    float *ranks_out;
+    __device__ __forceinline__ void operator()(int32_t v, float acc) const
+    {
+        ranks_out[v] = __fadd_rn(k, __fmul_rn(d, __fadd_rn(acc, *dangling)));
     }
-}
-
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pr_pull(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj,
-                                                           const float *contrib, const float *dangling_ptr, float k, float d,
-                                                           float *ranks_out, int hub_blocks, const int32_t *hub_rows, const int32_t *hub_off)
-{
-    __shared__ float s_buf[2 * VGL_TILE];               // pull: values | destinations; hub wavefronts: 4 x 512 values
-    __shared__ int64_t s_jump;
-    if ((int)blockIdx.x < hub_blocks) {                 // dispatched first: one workgroup per CU runs the hub schedule
-        vgl_pr_hub_waves(s_buf, hub_rows, hub_off, row_base, rowptr, adj, contrib, dangling_ptr, k, d, ranks_out);
-        return;
-    }
-    float *s_val = s_buf;
-    int32_t *s_dst = reinterpret_cast<int32_t *>(s_buf + VGL_TILE);
-    const int32_t blk = (int32_t)blockIdx.x - hub_blocks;
-    const int32_t r = blk * VGL_BLOCK + threadIdx.x;
-    const int32_t r_lo = blk * VGL_BLOCK;
-    const int32_t r_hi = min(nrows, r_lo + VGL_BLOCK);
-    const int64_t E0 = rowptr[r_lo], E1 = rowptr[r_hi];
-    int64_t seg_b = 0, seg_e = 0;
-    if (r < nrows) { seg_b = rowptr[r]; seg_e = rowptr[r + 1]; }
-    const bool hub = (seg_e - seg_b) >= VGL_PR_HUB_DEGREE;      // summed by the hub wavefronts
-    const int32_t self = row_base + r;
-    float acc = 0.0f;
-    int64_t base = E0;
-    while (base < E1) {
-        // a tile that starts inside a hub's edge range is skipped wholesale: jump to the end of that range
-        if (threadIdx.x == 0) s_jump = -1;
-        __syncthreads();
-        if (hub && seg_b <= base && base < seg_e) s_jump = seg_e;      // at most one row contains `base`
-        __syncthreads();
-        const int64_t jump = s_jump;
-        __syncthreads();                               // everyone has read s_jump before thread 0 resets it
-        if (jump >= 0) { base = jump; continue; }
-        const int n = (int)min((int64_t)VGL_TILE, E1 - base);
-#pragma unroll
-        for (int j = 0; j < VGL_EPT; j++) {
-            const int i = threadIdx.x + j * VGL_BLOCK;
-            if (i < n) {
-                const int32_t dst = adj[base + i];
-                s_dst[i] = dst;
-                s_val[i] = contrib[dst];
-            }
-        }
-        __syncthreads();
-        if (!hub) {
-            const int lo = (int)(max(seg_b, base) - base);
-            const int hi = (int)(min(seg_e, base + n) - base);
-            for (int i = lo; i < hi; i++)
-                if (s_dst[i] != self) acc = __fadd_rn(acc, s_val[i]);     // if(src_id != dst_id) rank += ... (pr.hpp:115-116)
-        }
-        base += n;
-    }
-    if (r < nrows && !hub)
-        ranks_out[self] = __fadd_rn(k, __fmul_rn(d, __fadd_rn(acc, *dangling_ptr)));   // k + d * (rank + dangling) (pr.hpp:121)
-}
+};
 
 // indegree without self loops from an out-CSR shard (pr.hpp:31-65 computes it from the incoming graph; same numbers)
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_indeg_noloops(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row,
@@ -249,24 +130,24 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_indeg_sub_loops(const int64_t
 
 static inline unsigned vgl_grid3(int64_t n, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
 
-static int vgl_pr_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g)
+int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
 {
-    if (g->pr_hub_rows) return 0;
+    if (dir.hub_rows) return 0;
     int32_t *d_rows = nullptr, *d_deg = nullptr, *d_count = nullptr;
     const size_t cap = (size_t)std::max<int32_t>(g->nrows, 1);
     VGL_HIP_TRY(hipMalloc((void **)&d_rows, sizeof(int32_t) * cap));
     VGL_HIP_TRY(hipMalloc((void **)&d_deg, sizeof(int32_t) * cap));
     VGL_HIP_TRY(hipMalloc((void **)&d_count, sizeof(int32_t)));
     VGL_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL(vgl_k_pr_find_hubs, dim3(vgl_grid3(g->nrows, 4096)), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->out.rowptr, d_rows,
+    hipLaunchKernelGGL(vgl_k_pull_find_hubs, dim3(vgl_grid3(g->nrows, 4096)), dim3(VGL_BLOCK), 0, c->stream, g->nrows, dir.rowptr, d_rows,
                        d_deg, d_count);
     VGL_HIP_TRY(hipGetLastError());
-    VGL_TRY(vgl_hip_memcpy_d2h(c, &g->pr_nhubs, d_count, sizeof(int32_t)));
-    const size_t n = (size_t)g->pr_nhubs;
-    g->pr_hub_blocks = n ? (int)std::min<int64_t>(VGL_PR_HUB_BLOCKS, vgl_ceil_div((int64_t)n, VGL_WAVES)) : 0;
-    const int W = g->pr_hub_blocks * VGL_WAVES;
+    VGL_TRY(vgl_hip_memcpy_d2h(c, &dir.nhubs, d_count, sizeof(int32_t)));
+    const size_t n = (size_t)dir.nhubs;
+    dir.hub_blocks = n ? (int)std::min<int64_t>(VGL_PULL_HUB_BLOCKS, vgl_ceil_div((int64_t)n, VGL_WAVES)) : 0;
+    const int W = dir.hub_blocks * VGL_WAVES;
     // device layout: [n hub rows grouped by wavefront][W+1 offsets]
-    VGL_HIP_TRY(hipMalloc((void **)&g->pr_hub_rows, sizeof(int32_t) * (n + (size_t)W + 1)));
+    VGL_HIP_TRY(hipMalloc((void **)&dir.hub_rows, sizeof(int32_t) * (n + (size_t)W + 1)));
     if (n > 0) {
         std::vector<int32_t> rows(n), deg(n), order(n);
         VGL_TRY(vgl_hip_memcpy_d2h(c, rows.data(), d_rows, sizeof(int32_t) * n));
@@ -292,7 +173,7 @@ static int vgl_pr_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g)
             for (int32_t r : lists[(size_t)wv]) packed[pos++] = r;
         }
         packed[n + (size_t)W] = (int32_t)pos;
-        VGL_TRY(vgl_hip_memcpy_h2d(c, g->pr_hub_rows, packed.data(), sizeof(int32_t) * packed.size()));
+        VGL_TRY(vgl_hip_memcpy_h2d(c, dir.hub_rows, packed.data(), sizeof(int32_t) * packed.size()));
     }
     VGL_HIP_TRY(hipFree(d_rows));
     VGL_HIP_TRY(hipFree(d_deg));
@@ -308,16 +189,18 @@ static int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *ind
     const float k = (float)((1.0 - (double)d) / (double)((float)V));       // pr.hpp:37-38
     const int npart = (int)vgl_grid3(V, 1024);
     const unsigned nblk = (unsigned)vgl_ceil_div(g->nrows, VGL_BLOCK);
-    VGL_TRY(vgl_pr_find_hubs(c, g));
+    VGL_TRY(vgl_pull_find_hubs(c, g, g->out));
     VGL_TRY(vgl_ensure_partials(c, (size_t)npart + 8));
     float *dangling = reinterpret_cast<float *>(c->d_partials + npart);    // one slot after the prepare partials
     hipLaunchKernelGGL(vgl_k_pr_prepare, dim3(npart), dim3(VGL_BLOCK), 0, c->stream, V, indeg, rdeg, ranks, contrib, c->d_partials);
     hipLaunchKernelGGL(vgl_k_pr_dangling, dim3(1), dim3(VGL_BLOCK), 0, c->stream, npart, c->d_partials, dangling);
-    const int hub_blocks = g->pr_hub_blocks;
+    const int hub_blocks = g->out.hub_blocks;
     {
         vgl_timed_launch tl(c, "pr_pull");
-        hipLaunchKernelGGL(vgl_k_pr_pull, dim3(nblk + hub_blocks), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, g->out.rowptr,
-                           g->out.adj, contrib, dangling, k, d, ranks_out, hub_blocks, g->pr_hub_rows, g->pr_hub_rows + g->pr_nhubs);
+        const vgl_pr_epilogue epi{dangling, k, d, ranks_out};
+        hipLaunchKernelGGL((vgl_k_pull_sum<float, true, false, vgl_pr_epilogue>), dim3(nblk + hub_blocks), dim3(VGL_BLOCK), 0, c->stream, g->nrows,
+                           g->row_begin, g->out.rowptr, g->out.adj, (const float *)contrib, epi, hub_blocks, (const int32_t *)g->out.hub_rows,
+                           (const int32_t *)(g->out.hub_rows + g->out.nhubs), (double *)nullptr);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;

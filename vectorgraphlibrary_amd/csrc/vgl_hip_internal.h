@@ -64,6 +64,9 @@ struct vgl_dir_csr {                 // one direction of the graph (borrowed) + 
     int64_t edges = 0;
     int32_t *tile_row = nullptr;     // ntiles+1: local row that contains edge t*VGL_TILE
     int64_t ntiles = 0;
+    int32_t *hub_rows = nullptr;     // pull sums (PageRank, HITS): rows with >= 512 edges grouped per wavefront + offsets (lazy)
+    int32_t nhubs = 0;
+    int hub_blocks = 0;              // workgroups of the pull kernel that run the hub schedule
 };
 
 struct vgl_hip_graph {
@@ -88,9 +91,6 @@ struct vgl_hip_graph {
     float *fscratch2 = nullptr;      // V (PR rdeg)
     float *fscratch3 = nullptr;      // V (PR new ranks)
     int32_t *iscratch = nullptr;     // V (PR indeg when not supplied)
-    int32_t *pr_hub_rows = nullptr;      // PageRank: rows with >= 512 edges grouped per wavefront + offsets (lazy)
-    int32_t pr_nhubs = 0;
-    int pr_hub_blocks = 0;               // workgroups of the pull kernel that run the hub schedule
     uint8_t *ds_tile_active = nullptr;   // delta-stepping SSSP: one byte per out-edge tile (lazy)
     int64_t *ds_partials = nullptr;
 };

@@ -1,0 +1,161 @@
+// vgl_pull.h -- out[v] = epilogue( sum over the adjacency of row v, IN ADJACENCY ORDER, of x[adj] ) for one CSR direction.
+// Shared by PageRank (f32, self loops skipped, pr.hpp:105-124) and HITS (f64, both directions, hits.hpp:43-78): both reference
+// loops are a strictly sequential `+=` chain per vertex, and keeping that order makes the sums bit-identical to the reference's
+// sequential checkers (seq_pr.hpp:81-96, hits.hpp:117-160).
+//
+// Workgroup = 256 consecutive rows, one thread per row; the rows' edges are staged through LDS in tiles of 2048 (coalesced
+// adjacency read + gather by all threads), then every thread adds its own row's slice sequentially from LDS.
+// Rows with at least VGL_PULL_HUB_DEGREE edges are "hubs": their chain (deg dependent adds) would stall a whole 256-row workgroup
+// (a 7*10^5-edge RMAT hub took 1.7 s per PageRank iteration that way).  They are listed once per graph and direction, dealt to
+// 1024 wavefronts by a longest-processing-time schedule (vgl_pull_find_hubs), and summed by the first `hub_blocks` workgroups of
+// the same launch (one workgroup per CU, i.e. one wavefront per SIMD, raised issue priority) while the remaining workgroups pull
+// the ordinary rows on the same CUs (a separate kernel on a side stream overlapped worse: 5.0 vs 4.2 ms per RMAT-24 PageRank
+// iteration): a wavefront gathers 512 values per batch (the next batch's gathers and the adjacency of the one after in flight;
+// 1024-value batches cost 112 VGPRs and the ordinary rows' occupancy), parks them in LDS and folds them with one dependent add
+// per value (all lanes compute the same chain; broadcast LDS reads).  The critical path of a launch is the chain of the largest
+// hub (~10 cycles per edge measured), not the sum over hubs.
+#pragma once
+#include "vgl_hip_internal.h"
+
+constexpr int VGL_PULL_HUB_DEGREE = 512;
+constexpr int VGL_PULL_HUB_BATCH = 512;
+constexpr int VGL_PULL_HUB_BLOCKS = 256;      // one per CU
+
+// lists the hubs of direction `d` (rows with >= VGL_PULL_HUB_DEGREE edges) grouped per wavefront; lazy, once per graph + direction
+int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &d);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float vgl_add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double vgl_add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+// Epi: struct with  __device__ void operator()(int32_t v, T sum) const  (writes the result of vertex v)
+template <class T, bool SKIP_SELF, bool SUMSQ, class Epi>
+__device__ __forceinline__ void vgl_pull_hub_waves(T *s_vals, const int32_t *hub_rows, const int32_t *hub_off, int32_t row_base,
+                                                   const int64_t *rowptr, const int32_t *adj, const T *x, Epi epi, double &sumsq)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = vgl_lane();
+    T *cur = s_vals + vgl_wave() * VGL_PULL_HUB_BATCH;                   // this wavefront's batch (consumed before the next is parked)
+    constexpr int U = VGL_PULL_HUB_BATCH / 64;
+    constexpr int B = VGL_PULL_HUB_BATCH;
+    // No lane-dependent control flow anywhere below: the LDS hand-over relies on the wavefront staying converged (a ticket fetched
+    // under `if (lane == 0)` let the compiler unswitch the loop on the lane id and the lanes ran apart).  Each wavefront owns a
+    // precomputed list of hubs.
+    const int32_t w = __builtin_amdgcn_readfirstlane((int32_t)blockIdx.x * VGL_WAVES + vgl_wave());    // scalar: loops are uniform
+    const int32_t h_end = hub_off[w + 1];
+    for (int32_t h = hub_off[w]; h < h_end; h++) {
+        const int32_t r = hub_rows[h];
+        const int64_t b = rowptr[r];
+        const uint32_t n = (uint32_t)(rowptr[r + 1] - b);               // a row has fewer than 2^31 edges
+        const int32_t *adj_h = adj + b;                                  // scalar base + 32-bit lane offsets
+        const int32_t self = row_base + r;
+        T acc = (T)0;
+        T val[U];
+        int32_t dst[U];
+        // entries past the end of the row (and self loops when they are skipped) are marked with -1 and contribute +0: exact no-op
+        auto load_adj = [&](uint32_t base) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t q = base + u * 64 + lane;
+                int32_t t = q < n ? adj_h[q] : -1;
+                if (SKIP_SELF && t == self) t = -1;
+                dst[u] = t;
+            }
+        };
+        auto gather = [&]() {
+#pragma unroll
+            for (int u = 0; u < U; u++) val[u] = dst[u] >= 0 ? x[(uint32_t)dst[u]] : (T)0;
+        };
+        // three batches in flight: fold(i) from LDS | gathers of batch i+1 | adjacency of batch i+2
+        load_adj(0);
+        gather();
+        if (B < n) load_adj(B);
+        for (uint32_t base = 0; base < n; base += B) {
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u * 64 + lane] = val[u];
+            if (base + B < n) {
+                gather();
+                if (base + 2 * B < n) load_adj(base + 2 * B);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int n4 = (int)min((uint32_t)(B / 4), (n - base + 3) / 4);   // the tail of the batch is zero-filled
+#pragma unroll 8
+            for (int i = 0; i < n4; i++) {                              // same addresses in every lane: LDS broadcast
+                const T v0 = cur[4 * i], v1 = cur[4 * i + 1], v2 = cur[4 * i + 2], v3 = cur[4 * i + 3];
+                acc = vgl_add_rn(acc, v0);
+                acc = vgl_add_rn(acc, v1);
+                acc = vgl_add_rn(acc, v2);
+                acc = vgl_add_rn(acc, v3);
+            }
+        }
+        epi(self, acc);                                                  // all lanes: same value, same address
+        if (SUMSQ && lane == 0) sumsq += (double)acc * (double)acc;
+    }
+}
+
+// grid = hub_blocks + ceil(nrows / 256) workgroups.  SUMSQ: sumsq_partials[blockIdx.x] = sum over this workgroup's rows of sum^2 (f64)
+template <class T, bool SKIP_SELF, bool SUMSQ, class Epi>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj,
+                                                            const T *x, Epi epi, int hub_blocks, const int32_t *hub_rows,
+                                                            const int32_t *hub_off, double *sumsq_partials)
+{
+    __shared__ T s_val[VGL_TILE];                       // ordinary rows: staged values; hub wavefronts: 4 x 512 values
+    __shared__ int32_t s_dst[VGL_TILE];
+    __shared__ int64_t s_jump;
+    __shared__ double s_sq[VGL_WAVES];
+    double sumsq = 0.0;
+    if ((int)blockIdx.x < hub_blocks) {                 // dispatched first: one workgroup per CU runs the hub schedule
+        vgl_pull_hub_waves<T, SKIP_SELF, SUMSQ>(s_val, hub_rows, hub_off, row_base, rowptr, adj, x, epi, sumsq);
+    } else {
+        const int32_t blk = (int32_t)blockIdx.x - hub_blocks;
+        const int32_t r = blk * VGL_BLOCK + threadIdx.x;
+        const int32_t r_lo = blk * VGL_BLOCK;
+        const int32_t r_hi = min(nrows, r_lo + VGL_BLOCK);
+        const int64_t E0 = rowptr[r_lo], E1 = rowptr[r_hi];
+        int64_t seg_b = 0, seg_e = 0;
+        if (r < nrows) { seg_b = rowptr[r]; seg_e = rowptr[r + 1]; }
+        const bool hub = (seg_e - seg_b) >= VGL_PULL_HUB_DEGREE;      // summed by the hub wavefronts
+        const int32_t self = row_base + r;
+        T acc = (T)0;
+        int64_t base = E0;
+        while (base < E1) {
+            // a tile that starts inside a hub's edge range is skipped wholesale: jump to the end of that range
+            if (threadIdx.x == 0) s_jump = -1;
+            __syncthreads();
+            if (hub && seg_b <= base && base < seg_e) s_jump = seg_e;      // at most one row contains `base`
+            __syncthreads();
+            const int64_t jump = s_jump;
+            __syncthreads();                               // everyone has read s_jump before thread 0 resets it
+            if (jump >= 0) { base = jump; continue; }
+            const int n = (int)min((int64_t)VGL_TILE, E1 - base);
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) {
+                const int i = threadIdx.x + j * VGL_BLOCK;
+                if (i < n) {
+                    const int32_t dst = adj[base + i];
+                    s_dst[i] = dst;
+                    s_val[i] = x[dst];
+                }
+            }
+            __syncthreads();
+            if (!hub) {
+                const int lo = (int)(max(seg_b, base) - base);
+                const int hi = (int)(min(seg_e, base + n) - base);
+                for (int i = lo; i < hi; i++)
+                    if (!SKIP_SELF || s_dst[i] != self) acc = vgl_add_rn(acc, s_val[i]);     // if(src_id != dst_id) rank += ... (pr.hpp:115-116)
+            }
+            base += n;
+        }
+        if (r < nrows && !hub) {
+            epi(self, acc);
+            if (SUMSQ) sumsq = (double)acc * (double)acc;
+        }
+    }
+    if (SUMSQ) {
+        const double tot = vgl_block_reduce_add(sumsq, s_sq);
+        if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = tot;
+    }
+}
+#endif
