@@ -124,6 +124,30 @@ inline std::vector<float> seq_dijkstra(const HostCSR &g, const std::vector<float
     }
     return d;
 }
+// HITS::seq_hits (hits.hpp:103-173): authorities from the incoming lists, hubs from the outgoing lists, 2-norm after each half step
+inline void seq_hits(const HostCSR &out, const HostCSR &in, int steps, std::vector<double> &auth, std::vector<double> &hub)
+{
+    const int V = out.V;
+    auth.assign((size_t)V, 1.0); hub.assign((size_t)V, 1.0);
+    for (int step = 0; step < steps; step++) {
+        double norm = 0;
+        for (int v = 0; v < V; v++) {
+            double acc = 0;
+            for (long long p = in.rowptr[v]; p < in.rowptr[v + 1]; p++) acc += hub[in.adj[p]];
+            auth[v] = acc; norm += acc * acc;
+        }
+        norm = std::sqrt(norm);
+        for (int v = 0; v < V; v++) auth[v] /= norm;
+        norm = 0;
+        for (int v = 0; v < V; v++) {
+            double acc = 0;
+            for (long long p = out.rowptr[v]; p < out.rowptr[v + 1]; p++) acc += auth[out.adj[p]];
+            hub[v] = acc; norm += acc * acc;
+        }
+        norm = std::sqrt(norm);
+        for (int v = 0; v < V; v++) hub[v] /= norm;
+    }
+}
 // in the spirit of SSWP::seq_dijkstra (seq_widest_paths.hpp:5-64): label-correcting with a max-priority queue
 inline std::vector<float> seq_widest_paths(const HostCSR &g, const std::vector<float> &cap, int source)
 {

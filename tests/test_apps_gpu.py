@@ -69,6 +69,22 @@ def test_sswp_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
     assert (np.fromfile(dump, np.float32).view(np.int32) == ref.view(np.int32)).all()
 
 
+@pytest.mark.parametrize("mode", [[], ["-fused"]], ids=["operator_api", "fused"])
+@pytest.mark.parametrize("kind,scale,ef,seed", CASES)
+def test_hits_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
+    """HITS (f1 widening, f64): gather/scatter with vertex pre-ops + reduce<double> on the operator path, and the fused kernel"""
+    O = oracle
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
+    out, dump = run_app("hits", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 4, "-check"] + mode, tmp_path)
+    assert "error count: 0" in out
+    auth, hub = O.hits(rowptr, adj, 4)
+    got = np.fromfile(dump, np.float64)
+    V = len(rowptr) - 1
+    tol = 1e-12 if mode else 1e-9          # the lambda version accumulates with f64 atomics (order-dependent last bits)
+    assert np.max(np.abs(got[:V] - auth) / np.maximum(np.abs(auth), 1e-300)) <= tol
+    assert np.max(np.abs(got[V:] - hub) / np.maximum(np.abs(hub), 1e-300)) <= tol
+
+
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)
 def test_pr_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
     O = oracle
