@@ -125,7 +125,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_plan_tile_first(int32_t F, co
     }
 }
 
-static int vgl_build_dir(vgl_hip_ctx *c, vgl_dir_csr &d, int32_t nrows)
+int vgl_build_tile_rows(vgl_hip_ctx *c, vgl_dir_csr &d, int32_t nrows)
 {
     d.ntiles = vgl_ceil_div(d.edges, VGL_TILE);
     VGL_HIP_TRY(hipMalloc((void **)&d.tile_row, sizeof(int32_t) * ((size_t)d.ntiles + 2)));
@@ -163,10 +163,10 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     vgl_hip_graph *g = new vgl_hip_graph();
     g->V = V; g->row_begin = row_begin; g->row_end = row_end; g->nrows = row_end - row_begin;
     g->out.rowptr = d_out_rowptr; g->out.adj = d_out_adj; g->out.edges = out_edges;
-    VGL_TRY(vgl_build_dir(c, g->out, g->nrows));
+    VGL_TRY(vgl_build_tile_rows(c, g->out, g->nrows));
     if (d_in_rowptr) {
         g->in.rowptr = d_in_rowptr; g->in.adj = d_in_adj; g->in.edges = in_edges;
-        VGL_TRY(vgl_build_dir(c, g->in, g->nrows));
+        VGL_TRY(vgl_build_tile_rows(c, g->in, g->nrows));
     }
     const size_t words = (size_t)vgl_ceil_div(V, 64) + 1;
     VGL_TRY(vgl_alloc(&g->bm_visited, words));

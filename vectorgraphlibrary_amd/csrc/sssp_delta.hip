@@ -32,9 +32,13 @@ constexpr int VGL_DS_SCAN_THREADS = 1024;
 
 struct vgl_hip_sssp_plan {
     float delta = 0.0f;
-    int32_t *adj_p = nullptr;     // E: every row light edges first (w < delta), then heavy, both in original relative order
-    float *w_p = nullptr;         // E
-    int32_t *light_cnt = nullptr; // nrows
+    // the edges split into two CSRs over the same rows, both in original relative order: [0] light (w < delta), [1] heavy.
+    // Own row offsets / adjacency / weights / tile table each, so a step can either walk a compacted frontier's segments or
+    // sweep the whole part as static tiles.
+    vgl_dir_csr part[2];
+    int64_t *prow[2] = {nullptr, nullptr};
+    int32_t *padj[2] = {nullptr, nullptr};
+    float *pw[2] = {nullptr, nullptr};
     uint8_t *state = nullptr;     // V: bit0 light edges pending, bit1 heavy edges pending
     int32_t *vt_aux = nullptr;    // per vertex tile: rows with heavy pending below T
     int64_t *partials = nullptr;  // min-pending reduction (1024) followed by the relax kernel's near-improvement flags
@@ -48,35 +52,25 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_light_flags(int64_t E, con
     for (int64_t e = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; e < E; e += (int64_t)gridDim.x * VGL_BLOCK) flags[e] = w[e] < delta;
     if (blockIdx.x == 0 && threadIdx.x == 0) flags[E] = 0;
 }
-// S = exclusive scan of the light flags (E+1 entries).  Stable partition inside every row.
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_partition(const int64_t *rowptr, const int32_t *adj, const float *w, const int32_t *tile_row,
-                                                                int64_t E, const uint32_t *S, float delta, int32_t *adj_p, float *w_p)
+// S = exclusive scan of the light flags (E+1 entries): light edge e goes to position S[e] of the light part, heavy edge e to
+// position e - S[e] of the heavy part (stable, rows stay contiguous in both parts)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_partition(int64_t E, const int32_t *adj, const float *w, const uint32_t *S, float delta,
+                                                                int32_t *adj_l, float *w_l, int32_t *adj_h, float *w_h)
 {
-    __shared__ int s_map[VGL_TILE];
-    __shared__ int s_w[VGL_WAVES];
-    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
-    const int n = (int)min((int64_t)VGL_TILE, E - e0);
-    const int r_first = tile_row[blockIdx.x], r_last = tile_row[blockIdx.x + 1];
-    vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
-#pragma unroll
-    for (int j = 0; j < VGL_EPT; j++) {
-        const int i = threadIdx.x + j * VGL_BLOCK;
-        if (i < n) {
-            const int64_t e = e0 + i;
-            const int r = r_first + s_map[i];
-            const int64_t rb = rowptr[r], re = rowptr[r + 1];
-            const uint32_t lb = S[e] - S[rb];                       // light edges of this row before e
-            const float we = w[e];
-            const int64_t pos = (we < delta) ? rb + lb : rb + (S[re] - S[rb]) + (e - rb - lb);
-            adj_p[pos] = adj[e];
-            w_p[pos] = we;
-        }
+    for (int64_t e = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; e < E; e += (int64_t)gridDim.x * VGL_BLOCK) {
+        const float we = w[e];
+        const int64_t l = S[e];
+        if (we < delta) { adj_l[l] = adj[e]; w_l[l] = we; }
+        else { adj_h[e - l] = adj[e]; w_h[e - l] = we; }
     }
 }
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_light_counts(int32_t nrows, const int64_t *rowptr, const uint32_t *S, int32_t *light_cnt)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_split_rows(int32_t nrows, const int64_t *rowptr, const uint32_t *S, int64_t *row_l, int64_t *row_h)
 {
-    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK)
-        light_cnt[r] = (int32_t)(S[rowptr[r + 1]] - S[rowptr[r]]);
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r <= nrows; r += gridDim.x * VGL_BLOCK) {
+        const int64_t e = rowptr[r], l = S[e];
+        row_l[r] = l;
+        row_h[r] = e - l;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -112,12 +106,9 @@ __device__ __forceinline__ uint32_t vgl_ds_bits8(const uint8_t *state, const flo
     *aux = hv; *st_out = st8;
     return act;
 }
-__device__ __forceinline__ int64_t vgl_ds_degree(const int64_t *rowptr, const int32_t *light_cnt, int32_t r, uint8_t bit)
-{
-    return bit == 1 ? (int64_t)light_cnt[r] : (rowptr[r + 1] - rowptr[r]) - (int64_t)light_cnt[r];
-}
+__device__ __forceinline__ int64_t vgl_ds_degree(const int64_t *prow, int32_t r) { return prow[r + 1] - prow[r]; }
 
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_count(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *light_cnt,
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_count(int32_t nrows, int32_t row_base, const int64_t *prow,
                                                             const uint8_t *state, const float *dist, uint8_t bit, float T,
                                                             int32_t *vt_cnt, int64_t *vt_deg, int32_t *vt_aux)
 {
@@ -133,7 +124,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_count(int32_t nrows, int32
         cnt = __popc(bits); aux_cnt = __popc(aux);
         if (bits)
             for (int j = 0; j < nvalid; j++)
-                if ((bits >> j) & 1) deg += vgl_ds_degree(rowptr, light_cnt, r0 + j, bit);
+                if ((bits >> j) & 1) deg += vgl_ds_degree(prow, r0 + j);
     }
     const int tc = vgl_block_reduce_add(cnt, s32);
     const int ta = vgl_block_reduce_add(aux_cnt, s32);
@@ -172,7 +163,7 @@ __global__ __launch_bounds__(VGL_DS_SCAN_THREADS) void vgl_k_ds_scan(int64_t nti
 }
 
 // ids / offs of the scheduled rows (ascending) and the scheduled bit is cleared (each row is owned by exactly one thread)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_write(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *light_cnt,
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_write(int32_t nrows, int32_t row_base, const int64_t *prow,
                                                             uint8_t *state, const float *dist, uint8_t bit, float T,
                                                             const int32_t *vt_cnt_off, const int64_t *vt_deg_off, int32_t *ids, int64_t *offs)
 {
@@ -191,7 +182,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_write(int32_t nrows, int32
 #pragma unroll
             for (int j = 0; j < VGL_EPT; j++) {
                 degs[j] = 0;
-                if (j < nvalid && ((bits >> j) & 1)) { degs[j] = vgl_ds_degree(rowptr, light_cnt, r0 + j, bit); deg += degs[j]; }
+                if (j < nvalid && ((bits >> j) & 1)) { degs[j] = vgl_ds_degree(prow, r0 + j); deg += degs[j]; }
             }
         }
     }
@@ -228,10 +219,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_tile_first(const int64_t *
     }
 }
 
-// persistent relax over the frontier's edge tiles.  HEAVY selects which segment of every scheduled row is walked.
-template <bool HEAVY>
+// persistent relax over the frontier's edge tiles; prow / adj_p / w_p are the part (light or heavy) the step walks
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *counters, const int32_t *ids, const int64_t *offs, const int32_t *tile_first,
-                                                            const int64_t *rowptr, const int32_t *light_cnt, const int32_t *adj_p, const float *w_p,
+                                                            const int64_t *prow, const int32_t *adj_p, const float *w_p,
                                                             int32_t row_base, float T, float *dist, uint8_t *state, int64_t *near_partials, int hotskip)
 {
     constexpr int STAGE = 1024;                             // rows staged per tile: 8 + 8 + 4 KB of LDS => 8 workgroups per CU
@@ -255,7 +245,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *count
                 const int p = p_first + k;
                 const int32_t u = ids[p];
                 const int32_t r = u - row_base;
-                s_base[k] = rowptr[r] + (HEAVY ? (int64_t)light_cnt[r] : 0) - offs[p];
+                s_base[k] = prow[r] - offs[p];
                 s_dsrc[k] = dist[u];
             }
         vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);
@@ -272,7 +262,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *count
                 if (staged) { base = s_base[k]; d = s_dsrc[k]; }
                 else {
                     const int p = p_first + k; const int32_t u = ids[p]; const int32_t r = u - row_base;
-                    base = rowptr[r] + (HEAVY ? (int64_t)light_cnt[r] : 0) - offs[p];
+                    base = prow[r] - offs[p];
                     d = dist[u];
                 }
                 const int64_t e = base + e0 + i;
@@ -347,9 +337,6 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     hipStream_t st = c->stream;
     vgl_hip_sssp_plan *p = new vgl_hip_sssp_plan();
     p->delta = delta;
-    VGL_HIP_TRY(hipMalloc((void **)&p->adj_p, sizeof(int32_t) * (size_t)std::max<int64_t>(E, 1)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->w_p, sizeof(float) * (size_t)std::max<int64_t>(E, 1)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->light_cnt, sizeof(int32_t) * (size_t)g->nrows));
     VGL_HIP_TRY(hipMalloc((void **)&p->state, (size_t)g->V + 8));
     VGL_HIP_TRY(hipMalloc((void **)&p->vt_aux, sizeof(int32_t) * (size_t)std::max<int64_t>(g->nvtiles, 1)));
     VGL_HIP_TRY(hipMalloc((void **)&p->partials, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS)));
@@ -362,11 +349,24 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     VGL_HIP_TRY(rocprim::exclusive_scan(nullptr, need, flags, S, 0u, (size_t)E + 1, rocprim::plus<uint32_t>(), st));
     VGL_HIP_TRY(hipMalloc(&temp, need ? need : 16));
     VGL_HIP_TRY(rocprim::exclusive_scan(temp, need, flags, S, 0u, (size_t)E + 1, rocprim::plus<uint32_t>(), st));
-    if (g->out.ntiles > 0)
-        hipLaunchKernelGGL(vgl_k_ds_partition, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, st, g->out.rowptr, g->out.adj, d_weights,
-                           g->out.tile_row, E, S, delta, p->adj_p, p->w_p);
-    hipLaunchKernelGGL(vgl_k_ds_light_counts, dim3(vgl_ds_grid(g->nrows, 8192)), dim3(VGL_BLOCK), 0, st, g->nrows, g->out.rowptr, S, p->light_cnt);
+    uint32_t n_light = 0;                                   // S[E] = number of light edges: sizes of the two parts
+    VGL_TRY(vgl_hip_memcpy_d2h(c, &n_light, S + E, sizeof(uint32_t)));
+    const int64_t part_edges[2] = {(int64_t)n_light, E - (int64_t)n_light};
+    for (int k = 0; k < 2; k++) {
+        VGL_HIP_TRY(hipMalloc((void **)&p->prow[k], sizeof(int64_t) * ((size_t)g->nrows + 1)));
+        VGL_HIP_TRY(hipMalloc((void **)&p->padj[k], sizeof(int32_t) * (size_t)std::max<int64_t>(part_edges[k], 1)));
+        VGL_HIP_TRY(hipMalloc((void **)&p->pw[k], sizeof(float) * (size_t)std::max<int64_t>(part_edges[k], 1)));
+    }
+    if (E > 0)
+        hipLaunchKernelGGL(vgl_k_ds_partition, dim3(vgl_ds_grid(E, 16384)), dim3(VGL_BLOCK), 0, st, E, g->out.adj, d_weights, S, delta, p->padj[0],
+                           p->pw[0], p->padj[1], p->pw[1]);
+    hipLaunchKernelGGL(vgl_k_ds_split_rows, dim3(vgl_ds_grid((int64_t)g->nrows + 1, 8192)), dim3(VGL_BLOCK), 0, st, g->nrows, g->out.rowptr, S, p->prow[0],
+                       p->prow[1]);
     VGL_HIP_TRY(hipGetLastError());
+    for (int k = 0; k < 2; k++) {
+        p->part[k].rowptr = p->prow[k]; p->part[k].adj = p->padj[k]; p->part[k].edges = part_edges[k];
+        VGL_TRY(vgl_build_tile_rows(c, p->part[k], g->nrows));
+    }
     VGL_HIP_TRY(hipStreamSynchronize(st));
     hipFree(temp); hipFree(flags); hipFree(S);
     *out = p;
@@ -377,7 +377,8 @@ int vgl_hip_sssp_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_plan *p)
 {
     if (!p) return 0;
     if (c) hipStreamSynchronize(c->stream);
-    hipFree(p->adj_p); hipFree(p->w_p); hipFree(p->light_cnt); hipFree(p->state); hipFree(p->vt_aux); hipFree(p->partials);
+    for (int k = 0; k < 2; k++) { hipFree(p->prow[k]); hipFree(p->padj[k]); hipFree(p->pw[k]); hipFree(p->part[k].tile_row); }
+    hipFree(p->state); hipFree(p->vt_aux); hipFree(p->partials);
     delete p;
     return 0;
 }
@@ -400,21 +401,18 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     // everything the host needs for the next decision in ONE read: F, M, heavy-pending-below-T (before the relax), whether
     // the relax produced improvements below T, and the smallest pending distance after the relax.
     auto step = [&](uint8_t bit) -> int {
-        hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, g->out.rowptr, p->light_cnt, p->state, d_dist,
+        const int k = bit == 1 ? 0 : 1;                     // which part this step walks
+        hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
                            bit, T, g->vt_cnt, g->vt_deg, p->vt_aux);
         hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
                            g->vt_deg_off, c->d_counters, g->offs);
-        hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, g->out.rowptr, p->light_cnt, p->state, d_dist,
+        hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
                            bit, T, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
         hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
         {
             vgl_timed_launch tl(c, "sssp_relax");
-            if (bit == 1)
-                hipLaunchKernelGGL(vgl_k_ds_relax<false>, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
-                                   g->out.rowptr, p->light_cnt, p->adj_p, p->w_p, g->row_begin, T, d_dist, p->state, near_partials, hotskip);
-            else
-                hipLaunchKernelGGL(vgl_k_ds_relax<true>, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
-                                   g->out.rowptr, p->light_cnt, p->adj_p, p->w_p, g->row_begin, T, d_dist, p->state, near_partials, hotskip);
+            hipLaunchKernelGGL(vgl_k_ds_relax, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
+                               p->prow[k], p->padj[k], p->pw[k], g->row_begin, T, d_dist, p->state, near_partials, hotskip);
         }
         hipLaunchKernelGGL(vgl_k_ds_min_pending, dim3(1024), dim3(VGL_BLOCK), 0, st, V, p->state, d_dist, p->partials);
         hipLaunchKernelGGL(vgl_k_ds_min_fold, dim3(1), dim3(VGL_BLOCK), 0, st, 1024, p->partials, near_partials, c->d_counters);
