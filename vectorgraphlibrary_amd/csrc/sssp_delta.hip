@@ -23,12 +23,12 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <rocprim/rocprim.hpp>
 
 constexpr int VGL_DS_BLOCKS = 2048;       // persistent grid of the relax kernel
-constexpr int VGL_DS_SCAN_THREADS = 1024;
 
 struct vgl_hip_sssp_plan {
     float delta = 0.0f;
@@ -39,9 +39,12 @@ struct vgl_hip_sssp_plan {
     int64_t *prow[2] = {nullptr, nullptr};
     int32_t *padj[2] = {nullptr, nullptr};
     float *pw[2] = {nullptr, nullptr};
+    int64_t rows_nonempty[2] = {0, 0};   // rows that have edges in the part (what "most of the part is scheduled" is measured against)
     uint8_t *state = nullptr;     // V: bit0 light edges pending, bit1 heavy edges pending
+    uint8_t *active = nullptr;    // V: rows scheduled by the current DENSE step (static sweep over a whole part)
     int32_t *vt_aux = nullptr;    // per vertex tile: rows with heavy pending below T
-    int64_t *partials = nullptr;  // min-pending reduction (1024) followed by the relax kernel's near-improvement flags
+    int64_t *partials = nullptr;  // min-pending reduction (1024) followed by the relax kernels' near-improvement counts (+ 1 flag word)
+    uint32_t *tickets = nullptr;  // arrival counters of the min_pending kernel ([1]; [0] unused)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -63,6 +66,14 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_partition(int64_t E, const
         if (we < delta) { adj_l[l] = adj[e]; w_l[l] = we; }
         else { adj_h[e - l] = adj[e]; w_h[e - l] = we; }
     }
+}
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_count_nonempty(int32_t nrows, const int64_t *prow, unsigned long long *out)
+{
+    __shared__ int s32[VGL_WAVES];
+    int cnt = 0;
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK) cnt += prow[r + 1] > prow[r];
+    cnt = vgl_block_reduce_add(cnt, s32);
+    if (threadIdx.x == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);      // once per plan, <= 1024 workgroups
 }
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_split_rows(int32_t nrows, const int64_t *rowptr, const uint32_t *S, int64_t *row_l, int64_t *row_h)
 {
@@ -133,27 +144,26 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_count(int32_t nrows, int32
 }
 
 // exclusive offsets per vertex tile; counters[C_FRONT] = F, [C_NEIGH] = M, [C_TMP1] = rows with heavy pending below T; offs[F] = M
-__global__ __launch_bounds__(VGL_DS_SCAN_THREADS) void vgl_k_ds_scan(int64_t ntiles, const int32_t *vt_cnt, const int64_t *vt_deg, const int32_t *vt_aux,
-                                                                     int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *counters, int64_t *offs)
+// one workgroup: exclusive offsets of the per-tile counts, totals into counters[C_FRONT] = F, [C_NEIGH] = M, [C_TMP1] = rows with
+// heavy pending below T, and offs[F] = M.  (Doing this in the last workgroup of the count kernel was tried: with 8192 small
+// workgroups the per-workgroup arrival atomics cost more than this launch.)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_scan(int ntiles, const int32_t *vt_cnt, const int64_t *vt_deg, const int32_t *vt_aux,
+                                                           int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *counters, int64_t *offs)
 {
-    __shared__ int64_t s_c[VGL_DS_SCAN_THREADS / 64], s_d[VGL_DS_SCAN_THREADS / 64], s_a[VGL_DS_SCAN_THREADS / 64];
-    const int64_t per = (ntiles + VGL_DS_SCAN_THREADS - 1) / VGL_DS_SCAN_THREADS;
-    const int64_t lo = min(ntiles, (int64_t)threadIdx.x * per), hi = min(ntiles, lo + per);
-    int64_t c = 0, d = 0, a = 0;
-    for (int64_t t = lo; t < hi; t++) { c += vt_cnt[t]; d += vt_deg[t]; a += vt_aux[t]; }
-    const int64_t ci = vgl_wave_incl_add(c), di = vgl_wave_incl_add(d), ai = vgl_wave_reduce_add(a);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) { s_c[w] = ci; s_d[w] = di; s_a[w] = ai; }
-    __syncthreads();
-    int64_t cb = 0, db = 0, ctot = 0, dtot = 0, atot = 0;
-#pragma unroll
-    for (int i = 0; i < VGL_DS_SCAN_THREADS / 64; i++) {
-        if (i < w) { cb += s_c[i]; db += s_d[i]; }
-        ctot += s_c[i]; dtot += s_d[i]; atot += s_a[i];
-    }
-    int64_t cpre = cb + ci - c, dpre = db + di - d;
-    for (int64_t t = lo; t < hi; t++) {
-        vt_cnt_off[t] = (int32_t)cpre; vt_deg_off[t] = dpre;
+    __shared__ int s32[VGL_WAVES];
+    __shared__ int64_t s64[VGL_WAVES];
+    const int per = (ntiles + VGL_BLOCK - 1) / VGL_BLOCK;
+    const int lo = min(ntiles, (int)threadIdx.x * per), hi = min(ntiles, lo + per);
+    int c = 0, a = 0;
+    int64_t d = 0;
+    for (int t = lo; t < hi; t++) { c += vt_cnt[t]; d += vt_deg[t]; a += vt_aux[t]; }
+    int ctot, atot;
+    int64_t dtot;
+    int cpre = vgl_block_excl_add(c, s32, &ctot);
+    int64_t dpre = vgl_block_excl_add(d, s64, &dtot);
+    (void)vgl_block_excl_add(a, s32, &atot);
+    for (int t = lo; t < hi; t++) {
+        vt_cnt_off[t] = cpre; vt_deg_off[t] = dpre;
         cpre += vt_cnt[t]; dpre += vt_deg[t];
     }
     if (threadIdx.x == 0) {
@@ -278,50 +288,180 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *count
                 const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
                 if (before > __float_as_int(nds[j])) {
                     state[dsts[j]] = 3;                         // light and heavy edges pending again
-                    near |= nds[j] < T;
+                    near += nds[j] < T;
                 }
             }
         }
     }
-    const int any_near = __syncthreads_or(near);
-    if (threadIdx.x == 0) near_partials[blockIdx.x] = any_near;
+    __shared__ int s_near[VGL_WAVES];
+    const int n_near = vgl_block_reduce_add(near, s_near);  // improvements that fall inside the current bucket (>= rows of the next light step)
+    if (threadIdx.x == 0) { near_partials[blockIdx.x] = n_near; if (n_near) near_partials[VGL_DS_BLOCKS] = 1; }   // flag: same value from everyone
+}
+
+// DENSE step, pass 1: what count + write do for a compacted frontier, without the compaction -- every scheduled row gets
+// active[v] = 1 and its pending bit cleared; per-vertex-tile counts feed the same scan kernel (totals for the host)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_mark(int32_t nrows, int32_t row_base, const int64_t *prow, uint8_t *state, const float *dist,
+                                                           uint8_t bit, float T, uint8_t *active, int32_t *vt_cnt, int64_t *vt_deg, int32_t *vt_aux)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    __shared__ int s32[VGL_WAVES];
+    const int32_t r0 = blockIdx.x * VGL_TILE + threadIdx.x * VGL_EPT;
+    int cnt = 0, aux_cnt = 0;
+    int64_t deg = 0;
+    if (r0 < nrows) {
+        const int nvalid = min(VGL_EPT, nrows - r0);
+        uint32_t aux; uint64_t st8;
+        const uint32_t bits = vgl_ds_bits8(state, dist, row_base + r0, nvalid, bit, T, &aux, &st8);
+        cnt = __popc(bits); aux_cnt = __popc(aux);
+        uint64_t act8 = 0, st_new = st8;
+        if (bits)
+            for (int j = 0; j < nvalid; j++)
+                if ((bits >> j) & 1) {
+                    deg += vgl_ds_degree(prow, r0 + j);
+                    act8 |= 1ULL << (8 * j);
+                    st_new &= ~((uint64_t)bit << (8 * j));
+                }
+        const int32_t v0 = row_base + r0;
+        if (nvalid == 8) {
+            *reinterpret_cast<uint64_t *>(active + v0) = act8;
+            if (bits) *reinterpret_cast<uint64_t *>(state + v0) = st_new;
+        } else {
+            for (int j = 0; j < nvalid; j++) { active[v0 + j] = (uint8_t)(act8 >> (8 * j)); if (bits) state[v0 + j] = (uint8_t)(st_new >> (8 * j)); }
+        }
+    }
+    const int tc = vgl_block_reduce_add(cnt, s32);
+    const int ta = vgl_block_reduce_add(aux_cnt, s32);
+    const int64_t td = vgl_block_reduce_add(deg, s64);
+    if (threadIdx.x == 0) { vt_cnt[blockIdx.x] = tc; vt_deg[blockIdx.x] = td; vt_aux[blockIdx.x] = ta; }
+}
+
+// DENSE step, pass 2: static sweep over ALL edge tiles of the part (the all-edges kernel of sssp.hip: thread = 8 consecutive
+// edges, two 16-byte loads of adjacency and of weights); rows that are not scheduled contribute nothing, tiles without a
+// scheduled row are skipped before any edge data is read.  Worth it when most of the part is scheduled anyway: 158 G edges/s
+// against ~65 G/s for the compacted walk (strided slots, staged row bases).
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax_static(const int64_t *prow, const int32_t *adj_p, const float *w_p, const int32_t *tile_row,
+                                                                   int64_t E, int32_t row_base, const uint8_t *active, float T, float *dist,
+                                                                   uint8_t *state, int64_t *near_partials)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    __shared__ int s_near[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, E - e0);
+    const int r_first = tile_row[blockIdx.x];
+    const int r_last = tile_row[blockIdx.x + 1];
+    int any = 0;
+    for (int r = r_first + threadIdx.x; r <= r_last; r += VGL_BLOCK) any |= active[row_base + r];
+    if (!__syncthreads_or(any)) return;
+    vgl_tile_row_map(s_map, s_w, prow, e0, r_first, r_last);
+    const int i0 = threadIdx.x * VGL_EPT;
+    int near = 0;
+    if (i0 < n) {
+        int32_t dsts[VGL_EPT];
+        float ws[VGL_EPT];
+        if (i0 + VGL_EPT <= n && ((e0 + i0) & 3) == 0) {
+            const int4 a0 = *reinterpret_cast<const int4 *>(adj_p + e0 + i0);
+            const int4 a1 = *reinterpret_cast<const int4 *>(adj_p + e0 + i0 + 4);
+            const float4 w0 = *reinterpret_cast<const float4 *>(w_p + e0 + i0);
+            const float4 w1 = *reinterpret_cast<const float4 *>(w_p + e0 + i0 + 4);
+            dsts[0] = a0.x; dsts[1] = a0.y; dsts[2] = a0.z; dsts[3] = a0.w; dsts[4] = a1.x; dsts[5] = a1.y; dsts[6] = a1.z; dsts[7] = a1.w;
+            ws[0] = w0.x; ws[1] = w0.y; ws[2] = w0.z; ws[3] = w0.w; ws[4] = w1.x; ws[5] = w1.y; ws[6] = w1.z; ws[7] = w1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) {
+                const bool ok = i0 + j < n;
+                dsts[j] = ok ? adj_p[e0 + i0 + j] : 0;
+                ws[j] = ok ? w_p[e0 + i0 + j] : 0.0f;
+            }
+        }
+        float olds[VGL_EPT], nds[VGL_EPT];
+        bool ok[VGL_EPT];
+        int prev_row = -1;
+        float d = 0.0f;
+        bool live = false;
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            const int row = s_map[i0 + j];
+            if (row != prev_row) {
+                prev_row = row;
+                const int32_t u = row_base + r_first + row;
+                live = active[u] != 0;
+                d = live ? dist[u] : 0.0f;
+            }
+            ok[j] = live && (i0 + j < n);
+            nds[j] = __fadd_rn(d, ws[j]);                      // src_weight + weight (shortest_paths.hpp:126-130)
+            olds[j] = ok[j] ? dist[dsts[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            if (ok[j] && olds[j] > nds[j]) {
+                const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
+                if (before > __float_as_int(nds[j])) {
+                    state[dsts[j]] = 3;
+                    near += nds[j] < T;
+                }
+            }
+        }
+    }
+    const int n_near = vgl_block_reduce_add(near, s_near);
+    if (threadIdx.x == 0 && n_near) {
+        atomicAdd((unsigned long long *)&near_partials[blockIdx.x & (VGL_DS_BLOCKS - 1)], (unsigned long long)n_near);
+        near_partials[VGL_DS_BLOCKS] = 1;
+    }
 }
 
 // min distance over all vertices with a pending bit (needed only when a bucket is exhausted)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_min_pending(int32_t V, const uint8_t *state, const float *dist, int64_t *partials)
+// End of a step, one launch: (1) the smallest distance among vertices with a pending bit -- only when the host will need it:
+// if the relax produced improvements below T the bucket continues, and after a light step with heavy edges pending below T the
+// heavy step comes next, so the scan of state / dist is skipped; (2) the LAST workgroup folds the partial minima and the
+// near-improvement counts, resets them, and hands the five numbers the host decides on straight to the pinned mirror.
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_min_pending(int32_t V, const uint8_t *state, const float *dist, int64_t *partials,
+                                                                  int64_t *near_partials, int light_step, int64_t *counters, uint32_t *ticket,
+                                                                  volatile int64_t *host, int64_t seq)
 {
     __shared__ int s32[VGL_WAVES];
+    __shared__ int64_t s64[VGL_WAVES];
+    const bool skip = near_partials[VGL_DS_BLOCKS] != 0 || (light_step && counters[C_TMP1] > 0);
     int m = __float_as_int(FLT_MAX);
-    const int32_t ngroups = V >> 3;                          // state has 8 bytes of slack; the tail is handled below
-    for (int32_t gi = blockIdx.x * VGL_BLOCK + threadIdx.x; gi < ngroups; gi += gridDim.x * VGL_BLOCK) {
-        const uint64_t st8 = *reinterpret_cast<const uint64_t *>(state + ((int64_t)gi << 3));
-        if (st8) {
+    if (!skip) {
+        const int32_t ngroups = V >> 3;                          // state has 8 bytes of slack; the tail is handled below
+        for (int32_t gi = blockIdx.x * VGL_BLOCK + threadIdx.x; gi < ngroups; gi += gridDim.x * VGL_BLOCK) {
+            const uint64_t st8 = *reinterpret_cast<const uint64_t *>(state + ((int64_t)gi << 3));
+            if (st8) {
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if ((st8 >> (8 * j)) & 0xff) m = min(m, __float_as_int(dist[(gi << 3) + j]));
+                for (int j = 0; j < 8; j++)
+                    if ((st8 >> (8 * j)) & 0xff) m = min(m, __float_as_int(dist[(gi << 3) + j]));
+            }
         }
+        if (blockIdx.x == 0 && threadIdx.x < (V & 7)) { const int32_t v = (V & ~7) + threadIdx.x; if (state[v]) m = min(m, __float_as_int(dist[v])); }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (V & 7)) { const int32_t v = (V & ~7) + threadIdx.x; if (state[v]) m = min(m, __float_as_int(dist[v])); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
     if (vgl_lane() == 0) s32[vgl_wave()] = m;
     __syncthreads();
-    if (threadIdx.x == 0) { for (int w = 1; w < VGL_WAVES; w++) m = min(m, s32[w]); partials[blockIdx.x] = min(m, s32[0]); }
-}
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_min_fold(int n, const int64_t *partials, const int64_t *near_partials, int64_t *counters)
-{
-    __shared__ int s32[VGL_WAVES];
-    int m = __float_as_int(FLT_MAX);
-    int near = 0;
-    for (int i = threadIdx.x; i < VGL_DS_BLOCKS; i += VGL_BLOCK) near |= (int)near_partials[i];
-    near = __syncthreads_or(near);
-    if (threadIdx.x == 0) counters[C_TMP0] = near;
-    for (int i = threadIdx.x; i < n; i += VGL_BLOCK) m = min(m, (int)partials[i]);
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) { for (int w = 1; w < VGL_WAVES; w++) m = min(m, s32[w]); dep = vgl_put_agent(partials + blockIdx.x, (int64_t)min(m, s32[0])); }
+    if (!vgl_last_block(ticket, dep)) return;
+    int64_t near = 0;
+    for (int i = threadIdx.x; i < VGL_DS_BLOCKS; i += VGL_BLOCK) { near += near_partials[i]; near_partials[i] = 0; }
+    near = vgl_block_reduce_add(near, s64);
+    int mm = __float_as_int(FLT_MAX);
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += VGL_BLOCK) mm = min(mm, (int)vgl_load_agent(partials + i));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
-    if (vgl_lane() == 0) s32[vgl_wave()] = m;
+    for (int o = 32; o > 0; o >>= 1) mm = min(mm, __shfl_xor(mm, o));
     __syncthreads();
-    if (threadIdx.x == 0) { for (int w = 1; w < VGL_WAVES; w++) m = min(m, s32[w]); counters[C_JUMP] = min(m, s32[0]); }
+    if (vgl_lane() == 0) s32[vgl_wave()] = mm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < VGL_WAVES; w++) mm = min(mm, s32[w]);
+        near_partials[VGL_DS_BLOCKS] = 0;
+        counters[C_TMP0] = near; counters[C_JUMP] = mm;
+        host[C_FRONT] = counters[C_FRONT]; host[C_NEIGH] = counters[C_NEIGH]; host[C_TMP1] = counters[C_TMP1];
+        host[C_TMP0] = near; host[C_JUMP] = mm;
+        __threadfence_system();
+        host[C_NSLOTS] = seq;
+        __threadfence_system();
+    }
 }
 
 static inline unsigned vgl_ds_grid(int64_t n, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
@@ -338,8 +478,13 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     vgl_hip_sssp_plan *p = new vgl_hip_sssp_plan();
     p->delta = delta;
     VGL_HIP_TRY(hipMalloc((void **)&p->state, (size_t)g->V + 8));
+    VGL_HIP_TRY(hipMalloc((void **)&p->active, (size_t)g->V + 8));
+    VGL_HIP_TRY(hipMemsetAsync(p->active, 0, (size_t)g->V + 8, st));
     VGL_HIP_TRY(hipMalloc((void **)&p->vt_aux, sizeof(int32_t) * (size_t)std::max<int64_t>(g->nvtiles, 1)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->partials, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->partials, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS + 1)));
+    VGL_HIP_TRY(hipMemsetAsync(p->partials, 0, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS + 1), st));
+    VGL_HIP_TRY(hipMalloc((void **)&p->tickets, sizeof(uint32_t) * 2 * VGL_TICKET_WORDS));
+    VGL_HIP_TRY(hipMemsetAsync(p->tickets, 0, sizeof(uint32_t) * 2 * VGL_TICKET_WORDS, st));
     uint32_t *flags = nullptr, *S = nullptr;
     void *temp = nullptr;
     size_t need = 0;
@@ -363,10 +508,15 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     hipLaunchKernelGGL(vgl_k_ds_split_rows, dim3(vgl_ds_grid((int64_t)g->nrows + 1, 8192)), dim3(VGL_BLOCK), 0, st, g->nrows, g->out.rowptr, S, p->prow[0],
                        p->prow[1]);
     VGL_HIP_TRY(hipGetLastError());
+    VGL_HIP_TRY(hipMemsetAsync(p->partials, 0, 2 * sizeof(int64_t), st));
     for (int k = 0; k < 2; k++) {
         p->part[k].rowptr = p->prow[k]; p->part[k].adj = p->padj[k]; p->part[k].edges = part_edges[k];
         VGL_TRY(vgl_build_tile_rows(c, p->part[k], g->nrows));
+        hipLaunchKernelGGL(vgl_k_ds_count_nonempty, dim3(vgl_ds_grid(g->nrows, 1024)), dim3(VGL_BLOCK), 0, st, g->nrows, p->prow[k],
+                           reinterpret_cast<unsigned long long *>(p->partials + k));
     }
+    VGL_TRY(vgl_hip_memcpy_d2h(c, p->rows_nonempty, p->partials, 2 * sizeof(int64_t)));
+    VGL_HIP_TRY(hipMemsetAsync(p->partials, 0, 2 * sizeof(int64_t), st));
     VGL_HIP_TRY(hipStreamSynchronize(st));
     hipFree(temp); hipFree(flags); hipFree(S);
     *out = p;
@@ -378,7 +528,7 @@ int vgl_hip_sssp_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_plan *p)
     if (!p) return 0;
     if (c) hipStreamSynchronize(c->stream);
     for (int k = 0; k < 2; k++) { hipFree(p->prow[k]); hipFree(p->padj[k]); hipFree(p->pw[k]); hipFree(p->part[k].tile_row); }
-    hipFree(p->state); hipFree(p->vt_aux); hipFree(p->partials);
+    hipFree(p->state); hipFree(p->active); hipFree(p->vt_aux); hipFree(p->partials); hipFree(p->tickets);
     delete p;
     return 0;
 }
@@ -400,26 +550,39 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     // one step: schedule rows with (state & bit) && dist < T, relax their light (bit 1) or heavy (bit 2) segment, then gather
     // everything the host needs for the next decision in ONE read: F, M, heavy-pending-below-T (before the relax), whether
     // the relax produced improvements below T, and the smallest pending distance after the relax.
-    auto step = [&](uint8_t bit) -> int {
+    // dense = sweep the whole part as static tiles (rows marked in p->active) instead of walking a compacted frontier: chosen by
+    // the caller from a PREDICTION of the step's size, so a wrong guess only costs time
+    auto step = [&](uint8_t bit, bool dense) -> int {
         const int k = bit == 1 ? 0 : 1;                     // which part this step walks
-        hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
-                           bit, T, g->vt_cnt, g->vt_deg, p->vt_aux);
-        hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
-                           g->vt_deg_off, c->d_counters, g->offs);
-        hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
-                           bit, T, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
-        hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
-        {
+        if (dense && p->part[k].ntiles > 0) {
+            hipLaunchKernelGGL(vgl_k_ds_mark, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist, bit, T,
+                               p->active, g->vt_cnt, g->vt_deg, p->vt_aux);
+            hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_BLOCK), 0, st, (int)g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
+                               g->vt_deg_off, c->d_counters, g->offs);
+            vgl_timed_launch tl(c, "sssp_relax");
+            hipLaunchKernelGGL(vgl_k_ds_relax_static, dim3((unsigned)p->part[k].ntiles), dim3(VGL_BLOCK), 0, st, p->prow[k], p->padj[k], p->pw[k],
+                               p->part[k].tile_row, p->part[k].edges, g->row_begin, p->active, T, d_dist, p->state, near_partials);
+        } else {
+            hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
+                               bit, T, g->vt_cnt, g->vt_deg, p->vt_aux);
+            hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_BLOCK), 0, st, (int)g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
+                               g->vt_deg_off, c->d_counters, g->offs);
+            hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
+                               bit, T, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
+            hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
             vgl_timed_launch tl(c, "sssp_relax");
             hipLaunchKernelGGL(vgl_k_ds_relax, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
                                p->prow[k], p->padj[k], p->pw[k], g->row_begin, T, d_dist, p->state, near_partials, hotskip);
         }
-        hipLaunchKernelGGL(vgl_k_ds_min_pending, dim3(1024), dim3(VGL_BLOCK), 0, st, V, p->state, d_dist, p->partials);
-        hipLaunchKernelGGL(vgl_k_ds_min_fold, dim3(1), dim3(VGL_BLOCK), 0, st, 1024, p->partials, near_partials, c->d_counters);
+        const int64_t seq = vgl_next_seq(c);
+        hipLaunchKernelGGL(vgl_k_ds_min_pending, dim3(1024), dim3(VGL_BLOCK), 0, st, V, p->state, d_dist, p->partials, near_partials, (int)(bit == 1),
+                           c->d_counters, p->tickets + VGL_TICKET_WORDS, (volatile int64_t *)c->h_counters, seq);
         VGL_HIP_TRY(hipGetLastError());
-        VGL_TRY(vgl_read_counters(c, false));
+        VGL_TRY(vgl_wait_counters(c, seq));
         if (c->h_counters[C_FRONT] > 0) { s.iterations++; s.edges_relaxed += c->h_counters[C_NEIGH]; }
-        if (debug) fprintf(stderr, "ds %s T=%g rows=%lld edges=%lld heavy_pending_below_T=%lld near_improved=%lld\n", bit == 1 ? "light" : "heavy", T,
+        if (debug) { static double t_last = 0; timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); const double t_now = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+                     fprintf(stderr, "[%7.0f us] ", t_now - t_last); t_last = t_now; }
+        if (debug) fprintf(stderr, "ds %s%s T=%g rows=%lld edges=%lld heavy_pending_below_T=%lld near_improved=%lld\n", bit == 1 ? "light" : "heavy", dense ? " (dense)" : "", T,
                            (long long)c->h_counters[C_FRONT], (long long)c->h_counters[C_NEIGH], (long long)c->h_counters[C_TMP1],
                            (long long)c->h_counters[C_TMP0]);
         return 0;
@@ -433,9 +596,12 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     T = width;
     const int64_t edges_lo = (int64_t)envf("VGL_DS_ELO", std::max<double>(1.0e6, (double)g->out.edges / 16.0));
     const double grow = envf("VGL_DS_GROW", 16.0);
+    const double dense_frac = envf("VGL_DS_DENSE", 0.4);    // dense when the predicted rows exceed this share of the part's non-empty rows
     int64_t bucket_rows = 0, bucket_edges = 0;
+    int64_t pred_light_rows = 0;                             // improvements below T seen by the last relax: the next light frontier, roughly
     for (;;) {
-        VGL_TRY(step(1));
+        VGL_TRY(step(1, (double)pred_light_rows > dense_frac * (double)p->rows_nonempty[0]));
+        pred_light_rows = c->h_counters[C_TMP0];
         bucket_rows += c->h_counters[C_FRONT];
         bucket_edges += c->h_counters[C_NEIGH];
         // (leaving a bucket early once its light frontier is small and shrinking was measured: the tail reappears in the next
@@ -443,7 +609,8 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
         const bool near = c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0;
         if (near) continue;                                             // the bucket received improvements: light edges again
         if (c->h_counters[C_TMP1] > 0) {                                // bucket settled: its heavy edges, once
-            VGL_TRY(step(2));
+            VGL_TRY(step(2, (double)c->h_counters[C_TMP1] > dense_frac * (double)p->rows_nonempty[1]));
+            pred_light_rows = c->h_counters[C_TMP0];
             bucket_edges += c->h_counters[C_NEIGH];
             if (c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0) continue;
         }
