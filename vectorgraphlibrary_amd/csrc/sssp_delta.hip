@@ -9,16 +9,21 @@
 //   * vertices are processed in distance buckets [.., T), T advancing by delta from the nearest pending vertex;
 //   * a vertex's LIGHT edges (w < delta) are relaxed whenever it improves inside the bucket, its HEAVY edges once, after the
 //     bucket has settled  (~1.3-1.6 E gathers in total);
-//   * each step works on a compacted, ascending-id FRONTIER of scheduled rows and only on the light (or heavy) SEGMENT of their
-//     adjacency: a per-(graph, weights, delta) plan stores every row's edges stably partitioned light-first, so a step
-//     streams exactly the edges it relaxes (the tile-granular first version re-streamed ~9 E per run).
+//   * a per-(graph, weights, delta) plan stores the light and the heavy edges as two CSRs over the same rows (stable split), so a
+//     step streams exactly the kind of edges it relaxes (the tile-granular first version re-streamed ~9 E per run);
+//   * a SPARSE step works on a compacted, ascending-id FRONTIER of scheduled rows and walks only their segments of the part;
+//     a DENSE step (most of the part is scheduled anyway: the light rounds at the peak of the first bucket, its heavy step)
+//     marks the scheduled rows and sweeps the whole part as static tiles with the all-edges kernel.  The choice is made from a
+//     prediction (improvements below T seen by the previous relax / rows with heavy edges pending), so it only affects speed.
 //
 // Robustness rule (no reliance on bucket theory for correctness): EVERY improvement of d[v] sets both pending bits of
 // state[v]; a bit is cleared only when the row is scheduled, so every improvement is eventually followed by a relaxation of
 // all out-edges => the loop ends exactly at the fixed point.
 //
-// One step = count / scan / write (frontier ids + exclusive edge offsets, 8 rows per thread like the GNF) -> tile_first ->
-// persistent relax over the frontier's edge tiles; all sized from DEVICE counters, one host read per step.
+// Sparse step = count / scan / write (frontier ids + exclusive edge offsets, 8 rows per thread like the GNF) -> tile_first ->
+// persistent relax over the frontier's edge tiles; dense step = mark / scan -> static relax.  Both end with vgl_k_ds_min_pending,
+// whose last workgroup folds the partials and hands F, M, heavy-pending, near-improvements and the smallest pending distance
+// to the host (one wait per step); everything else is sized from DEVICE counters.
 #include "vgl_hip_internal.h"
 #include <cfloat>
 #include <cmath>
