@@ -200,6 +200,17 @@ typedef struct {
     int32_t hook_passes;
     int64_t algorithmic_bytes; /* (8*E + 12*V) per hook pass + 12*V per jump pass */
 } vgl_hip_cc_stats;
+/* SCC::vgl_forward_backward, algorithms/scc/scc.hpp (checker SCC::seq_tarjan, seq_scc.hpp): strongly connected components of a
+ * directed graph.  d_comp[v] = smallest vertex id of v's component: the canonical form of the partition (the reference's labels are
+ * arbitrary counters and its test compares partitions, verify_results.h equal_components).  Needs the incoming CSR. */
+typedef struct {
+    int32_t trim_rounds;             /* vertex passes that removed trivial components */
+    int32_t forward_backward_steps;  /* pivot reach steps (0 or 1: the big component) */
+    int32_t colour_rounds;           /* colour-class rounds for the remaining components */
+    int32_t edge_passes;             /* all-edges passes of those rounds (inactive tiles skipped) */
+} vgl_hip_scc_stats;
+int vgl_hip_scc_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_scc_stats *stats);
+
 /* HITS::vgl_hits, algorithms/hits/hits.hpp:5-100 (f64, apps/hits/hits.cpp:13): auth = hub = 1, then `steps` times
  *   auth[v] = sum of hub over the in-neighbours, auth /= ||auth||_2, hub[v] = sum of auth over the out-neighbours, hub /= ||hub||_2.
  * Per-vertex sums run in adjacency order (the sequential checker's order, hits.hpp:117-160); norms are folded in a fixed order.

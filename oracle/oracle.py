@@ -59,6 +59,7 @@ def lib():
         L.vgo_sswp_bellman_ford.argtypes = [i32, p, p, p, i32, p, C.c_int]
         L.vgo_sswp_seq.argtypes = [i32, p, p, p, i32, p]
         L.vgo_hits.argtypes = [i32, p, p, p, p, i32, p, p]
+        L.vgo_scc_tarjan.argtypes = [i32, p, p, p]
         L.vgo_indegree_noloops.argtypes = [i32, i64, p, p, p]
         L.vgo_pagerank.argtypes = [i32, p, p, p, C.c_int, C.c_int, p, C.c_int]
         L.vgo_cc_sv.restype = i32
@@ -156,6 +157,23 @@ def transpose_csr(rowptr, adj):
     csr_src = np.repeat(np.arange(V, dtype=np.int32), np.diff(rowptr))
     in_rowptr, in_adj, _ = coo_to_csr(V, adj, csr_src, want_perm=False)
     return in_rowptr, in_adj
+
+
+def scc_tarjan(rowptr, adj):
+    """canonical SCC labels: comp[v] = smallest vertex id of v's strongly connected component"""
+    V = len(rowptr) - 1
+    comp = np.empty(V, np.int32)
+    lib().vgo_scc_tarjan(V, _p(rowptr), _p(adj), _p(comp))
+    return comp
+
+
+def canonical_labels(labels):
+    """any labelling of a partition -> the smallest member id of each part (what scc_tarjan / cc_sv return)"""
+    labels = np.asarray(labels)
+    _, inv = np.unique(labels, return_inverse=True)
+    mins = np.full(inv.max() + 1, len(labels), np.int64)
+    np.minimum.at(mins, inv, np.arange(len(labels)))
+    return mins[inv].astype(np.int32)
 
 
 def hits(rowptr, adj, steps):

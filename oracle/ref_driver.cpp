@@ -8,7 +8,7 @@
  * from the reference is copied into this repository.  Built only by
  * `make -C oracle ref` into oracle/_ref/ (git-ignored) when /root/reference exists.
  *
- * One TU, compiled six times (-DAPP_BFS / -DAPP_SSSP / -DAPP_PR / -DAPP_CC / -DAPP_SSWP / -DAPP_HITS) because
+ * One TU, compiled seven times (-DAPP_BFS / -DAPP_SSSP / -DAPP_PR / -DAPP_CC / -DAPP_SSWP / -DAPP_HITS / -DAPP_SCC) because
  * the reference's degree-range thresholds are compile-time macros set per app
  * (apps/bfs/bfs.cpp:3-7, apps/sssp/sssp.cpp:3-12, apps/pr/pr.cpp:3-5, apps/cc/cc.cpp:3-5, apps/sswp/sswp.cpp:3-5).
  *
@@ -19,6 +19,7 @@
  *   cc  : (none)                                    -> int32 comp[V] (vgl SV) then int32 comp[V] (seq bfs)
  *   sswp: <source_original_id> <capacities.f32>     (csr only) -> f32 width[V] (vgl) then f32 width[V] (seq)
  *   hits: <steps>                                   -> f64 auth[V], hub[V] (vgl) then f64 auth[V], hub[V] (seq)
+ *   scc : (none)                                    -> int32 comp[V] (vgl forward-backward) then int32 comp[V] (seq Tarjan)
  */
 #if defined(APP_BFS)
 #define INT_ELEMENTS_PER_EDGE 4.0
@@ -45,8 +46,13 @@
 #define INT_ELEMENTS_PER_EDGE 5.0
 #define VECTOR_ENGINE_THRESHOLD_VALUE 2147483646
 #define VECTOR_CORE_THRESHOLD_VALUE 5*VECTOR_LENGTH
+#elif defined(APP_SCC)
+#define INT_ELEMENTS_PER_EDGE 4.0
+#define NEC_VECTOR_ENGINE_THRESHOLD_VALUE  VECTOR_LENGTH * MAX_SX_AURORA_THREADS * 128
+#define VECTOR_CORE_THRESHOLD_VALUE VECTOR_LENGTH
+#define COLLECTIVE_FRONTIER_TYPE_CHANGE_THRESHOLD 0.35
 #else
-#error "define one of APP_BFS / APP_SSSP / APP_PR / APP_CC / APP_SSWP / APP_HITS"
+#error "define one of APP_BFS / APP_SSSP / APP_PR / APP_CC / APP_SSWP / APP_HITS / APP_SCC"
 #endif
 
 #include "graph_library.h"
@@ -142,6 +148,13 @@ int main(int argc, char **argv)
         HITS::seq_hits(graph, check_auth, check_hub, steps);
         dump(out, check_auth);
         dump(out, check_hub);
+#elif defined(APP_SCC)
+        VerticesArray<int> comp(graph, SCATTER);
+        SCC::vgl_forward_backward(graph, comp);
+        dump(out, comp);
+        VerticesArray<int> check(graph, SCATTER);
+        SCC::seq_tarjan(graph, check);
+        dump(out, check);
 #endif
         fclose(out);
         VGL_RUNTIME::finalize_library();

@@ -262,6 +262,47 @@ int32_t vgo_sssp_bellman_ford(int32_t V, const int64_t *rowptr, const int32_t *a
     return iters;
 }
 
+/* ---- SCC (checker of the reference: SCC::seq_tarjan, algorithms/scc/seq_scc.hpp): iterative Tarjan with an explicit stack.
+ * The reference's labels are arbitrary counters (its test compares PARTITIONS, verify_results.h equal_components); the oracle
+ * returns the canonical labelling comp[v] = smallest vertex id of v's strongly connected component. ---- */
+void vgo_scc_tarjan(int32_t V, const int64_t *rowptr, const int32_t *adj, int32_t *comp)
+{
+    int32_t *disc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V > 0 ? V : 1));
+    int32_t *low = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V > 0 ? V : 1));
+    int32_t *stk = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V > 0 ? V : 1));     /* Tarjan stack */
+    int32_t *call_v = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V > 0 ? V : 1));  /* DFS call stack: vertex */
+    int64_t *call_p = (int64_t *)malloc(sizeof(int64_t) * (size_t)(V > 0 ? V : 1));  /* DFS call stack: next edge position */
+    uint8_t *onstk = (uint8_t *)calloc((size_t)(V > 0 ? V : 1), 1);
+    for (int32_t v = 0; v < V; v++) { disc[v] = -1; comp[v] = -1; }
+    int32_t timer = 0, sp = 0;
+    for (int32_t root = 0; root < V; root++) {
+        if (disc[root] != -1) continue;
+        int32_t cs = 0;
+        call_v[cs] = root; call_p[cs] = rowptr[root]; cs++;
+        disc[root] = low[root] = timer++; stk[sp++] = root; onstk[root] = 1;
+        while (cs > 0) {
+            const int32_t u = call_v[cs - 1];
+            if (call_p[cs - 1] < rowptr[u + 1]) {
+                const int32_t w = adj[call_p[cs - 1]++];
+                if (disc[w] == -1) {
+                    disc[w] = low[w] = timer++; stk[sp++] = w; onstk[w] = 1;
+                    call_v[cs] = w; call_p[cs] = rowptr[w]; cs++;
+                } else if (onstk[w] && disc[w] < low[u]) low[u] = disc[w];
+            } else {
+                cs--;
+                if (cs > 0) { const int32_t parent = call_v[cs - 1]; if (low[u] < low[parent]) low[parent] = low[u]; }
+                if (low[u] == disc[u]) {                       /* u is the root of an SCC: pop it, label with the smallest id */
+                    int32_t first = sp, mn = u;
+                    do { first--; if (stk[first] < mn) mn = stk[first]; } while (stk[first] != u);
+                    for (int32_t i = first; i < sp; i++) { comp[stk[i]] = mn; onstk[stk[i]] = 0; }
+                    sp = first;
+                }
+            }
+        }
+    }
+    free(disc); free(low); free(stk); free(call_v); free(call_p); free(onstk);
+}
+
 /* ---- HITS (algorithms/hits/hits.hpp:103-173 seq_hits, the reference's own checker; f64 like apps/hits/hits.cpp:13):
  * auth = hub = 1; per step auth[v] = sum of hub over the incoming neighbours (adjacency order), normalised by the 2-norm,
  * then hub[v] = sum of auth over the outgoing neighbours, normalised.  Sequential `+=` chains, norm accumulated in vertex

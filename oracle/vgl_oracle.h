@@ -60,6 +60,8 @@ void vgo_bfs_seq(int32_t V, const int64_t *rowptr, const int32_t *adj, int32_t s
  *      checker algorithms/sssp/seq_shortest_paths.hpp:9-68) ---- */
 int32_t vgo_sssp_bellman_ford(int32_t V, const int64_t *rowptr, const int32_t *adj, const float *w,
                               int32_t source, float *dist, int parallel); /* returns iterations */
+/* ---- SCC (algorithms/scc/scc.hpp forward-backward; checker seq_tarjan, seq_scc.hpp): canonical labels = smallest id of the SCC ---- */
+void vgo_scc_tarjan(int32_t V, const int64_t *rowptr, const int32_t *adj, int32_t *comp);
 /* ---- HITS (algorithms/hits/hits.hpp:5-100; checker seq_hits, hits.hpp:103-173), f64 ---- */
 void vgo_hits(int32_t V, const int64_t *out_rowptr, const int32_t *out_adj, const int64_t *in_rowptr, const int32_t *in_adj,
               int32_t steps, double *auth, double *hub);

@@ -9,8 +9,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith("hits_"))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("hits_", "scc_")))
 HITS_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "hits_*.npz")))
+SCC_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "scc_*.npz")))
 PR_RTOL = 1e-6
 
 
@@ -678,3 +679,45 @@ def test_hits_hub_rows_and_zero_steps(ctx, oracle):
     a0, h0 = api.hits(g, 0)
     assert float(a0.min()) == 1.0 == float(a0.max()) and float(h0.min()) == 1.0 == float(h0.max())
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SCC_GOLDEN, ids=[os.path.basename(p)[:-4] for p in SCC_GOLDEN])
+def test_scc_matches_oracle_and_golden(path, ctx, oracle):
+    """SCC (f1 widening): vgl_hip_scc_run returns exactly the canonical labels of the reference's Tarjan partition, under identity
+    and degree-sorted numbering (including the sparse input on which the reference's own forward-backward code is wrong)"""
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    z = np.load(path)
+    kind, scale, ef, seed = str(z["kind"]), int(z["scale"]), int(z["edge_factor"]), int(z["seed"])
+    V = 1 << scale
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    for renumber in (None, "total"):
+        g = api.Graph.from_coo(ctx, V, src, dst, renumber=renumber)
+        comp, st = api.strongly_connected_components(g)
+        assert (comp.cpu().numpy() == z["comp"]).all(), f"SCC labels differ (renumber={renumber}, stats={st})"
+        g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef", [("rmat", 16, 16), ("ru", 16, 1), ("ru", 15, 2)])
+def test_scc_larger_graphs_match_oracle(kind, scale, ef, ctx, oracle):
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    V = 1 << scale
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, 41)
+    g = api.Graph.from_coo(ctx, V, src, dst)
+    want = O.scc_tarjan(g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy())
+    comp, st = api.strongly_connected_components(g)
+    assert (comp.cpu().numpy() == want).all(), st
+    g.close()
+    # degenerate: no edges at all, and a single vertex with a self loop
+    e = torch.zeros(0, dtype=torch.int32, device=ctx.device)
+    g0 = api.Graph.from_coo(ctx, 5, e, e)
+    assert (api.strongly_connected_components(g0)[0].cpu().numpy() == np.arange(5)).all()
+    g0.close()
+    one = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    g1 = api.Graph.from_coo(ctx, 1, one, one)
+    assert (api.strongly_connected_components(g1)[0].cpu().numpy() == [0]).all()
+    g1.close()

@@ -323,6 +323,19 @@ def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False):
     return (ranks if raw else graph.to_original(ranks)), _stats(st)
 
 
+def strongly_connected_components(graph, raw=False):
+    """labels = smallest ORIGINAL vertex id of each strongly connected component (raw=True: smallest id in the graph's numbering)"""
+    ctx = graph.ctx
+    comp = ctx.empty(graph.V, torch.int32)
+    st = _l.SccStats()
+    _l.check(ctx.L.vgl_hip_scc_run(ctx.h, graph.h, _ptr(comp), C.byref(st)))
+    if raw or graph.fwd is None:
+        return comp, _stats(st)
+    out, scratch = ctx.empty(graph.V, torch.int32), ctx.empty(graph.V, torch.int32)
+    _l.check(ctx.L.vgl_hip_cc_labels_to_original(ctx.h, graph.V, _ptr(comp), _ptr(graph.fwd), _ptr(graph.bwd), _ptr(scratch), _ptr(out)))
+    return out, _stats(st)
+
+
 def hits(graph, steps, raw=False):
     """HITS authorities and hubs (f64) after `steps` steps; needs the incoming CSR.  ORIGINAL numbering unless raw=True."""
     ctx = graph.ctx

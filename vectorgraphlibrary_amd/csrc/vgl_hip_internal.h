@@ -92,6 +92,7 @@ struct vgl_hip_graph {
     float *fscratch3 = nullptr;      // V (PR new ranks)
     int32_t *iscratch = nullptr;     // V (PR indeg when not supplied)
     uint8_t *ds_tile_active = nullptr;   // delta-stepping SSSP: one byte per out-edge tile (lazy)
+    vgl_hip_graph *transposed = nullptr; // SCC: handle with the two directions swapped (backward reach = BFS on it), lazy, owned
     int64_t *ds_partials = nullptr;
 };
 

@@ -30,6 +30,10 @@ class PrStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("ranks_sum", C.c_double), ("algorithmic_bytes", C.c_int64)]
 
 
+class SccStats(C.Structure):
+    _fields_ = [("trim_rounds", C.c_int32), ("forward_backward_steps", C.c_int32), ("colour_rounds", C.c_int32), ("edge_passes", C.c_int32)]
+
+
 class CcStats(C.Structure):
     _fields_ = [("hook_passes", C.c_int32), ("algorithmic_bytes", C.c_int64)]
 
@@ -86,6 +90,7 @@ _SIGNATURES = {
     "vgl_hip_sssp_run_plan": [_p, _p, _p, _i32, _p, C.POINTER(SsspStats)],
     "vgl_hip_pr_run": [_p, _p, _p, _int, _p, C.POINTER(PrStats)],
     "vgl_hip_hits_run": [_p, _p, _int, _p, _p],
+    "vgl_hip_scc_run": [_p, _p, _p, C.POINTER(SccStats)],
     "vgl_hip_cc_run": [_p, _p, _p, C.POINTER(CcStats)],
     "vgl_hip_cc_run_symmetric": [_p, _p, _p, C.POINTER(CcStats)],
     "vgl_hip_bfs_init": [_p, _i32, _i32, _p],
