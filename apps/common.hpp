@@ -124,6 +124,36 @@ inline std::vector<float> seq_dijkstra(const HostCSR &g, const std::vector<float
     }
     return d;
 }
+// SCC::seq_tarjan (seq_scc.hpp): iterative Tarjan; labels are component counters (equal_components compares partitions)
+inline std::vector<int> seq_tarjan(const HostCSR &g)
+{
+    const int V = g.V;
+    std::vector<int> disc((size_t)V, -1), low((size_t)V, 0), comp((size_t)V, -1), stk, call_v;
+    std::vector<long long> call_p;
+    std::vector<char> onstk((size_t)V, 0);
+    int timer = 0, ncomp = 0;
+    for (int root = 0; root < V; root++) {
+        if (disc[root] != -1) continue;
+        call_v.push_back(root); call_p.push_back(g.rowptr[root]);
+        disc[root] = low[root] = timer++; stk.push_back(root); onstk[root] = 1;
+        while (!call_v.empty()) {
+            const int u = call_v.back();
+            if (call_p.back() < g.rowptr[u + 1]) {
+                const int w = g.adj[call_p.back()++];
+                if (disc[w] == -1) { disc[w] = low[w] = timer++; stk.push_back(w); onstk[w] = 1; call_v.push_back(w); call_p.push_back(g.rowptr[w]); }
+                else if (onstk[w]) low[u] = std::min(low[u], disc[w]);
+            } else {
+                call_v.pop_back(); call_p.pop_back();
+                if (!call_v.empty()) low[call_v.back()] = std::min(low[call_v.back()], low[u]);
+                if (low[u] == disc[u]) {
+                    for (;;) { const int x = stk.back(); stk.pop_back(); onstk[x] = 0; comp[x] = ncomp; if (x == u) break; }
+                    ncomp++;
+                }
+            }
+        }
+    }
+    return comp;
+}
 // HITS::seq_hits (hits.hpp:103-173): authorities from the incoming lists, hubs from the outgoing lists, 2-norm after each half step
 inline void seq_hits(const HostCSR &out, const HostCSR &in, int steps, std::vector<double> &auth, std::vector<double> &hub)
 {

@@ -1,0 +1,24 @@
+// scc app: counterpart of apps/scc/scc.cpp:11-52 (directed input; -check against a sequential Tarjan, partitions compared).
+#include "common.hpp"
+#include "algorithms/scc.hpp"
+int main(int argc, char **argv)
+{
+    try {
+        VGL_RUNTIME::init_library(argc, argv);
+        Parser parser;
+        parser.parse_args(argc, argv);
+        VGL_Graph graph;
+        prepare_graph(graph, parser, DIRECTED_GRAPH);
+        VerticesArray<int> components(graph, SCATTER);
+        SCC::vgl_forward_backward(graph, components);            // heat run
+        report_performance(SCC::vgl_forward_backward(graph, components));
+        if (parser.get_check_flag()) {
+            HostCSR h(graph);
+            equal_components(components.to_host(), seq_tarjan(h));
+        }
+        dump_array(parser.dump, components.to_host());
+        VGL_RUNTIME::finalize_library();
+    } catch (std::string error) { std::cout << error << std::endl; return 1; }
+    catch (const char *error) { std::cout << error << std::endl; return 1; }
+    return 0;
+}

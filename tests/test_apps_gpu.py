@@ -85,6 +85,16 @@ def test_hits_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
     assert np.max(np.abs(got[V:] - hub) / np.maximum(np.abs(hub), 1e-300)) <= tol
 
 
+@pytest.mark.parametrize("kind,scale,ef,seed", CASES + [("ru", 12, 1, 8)])
+def test_scc_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
+    """SCC app (f1 widening): canonical labels equal the oracle's Tarjan partition; the app's own -check (partition equality) agrees"""
+    O = oracle
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
+    out, dump = run_app("scc", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-check"], tmp_path)
+    assert "error count: 0" in out
+    assert (np.fromfile(dump, np.int32) == O.scc_tarjan(rowptr, adj)).all()
+
+
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)
 def test_pr_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
     O = oracle

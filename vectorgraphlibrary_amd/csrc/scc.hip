@@ -26,7 +26,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_scc_init(int32_t V, int32_t *
     for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK) { act[v] = 1; comp[v] = -1; }
 }
 
-// cnt[r] = number of ACTIVE neighbours x != r of every active row r of one CSR direction (out: successors, in: predecessors)
+// cnt[r] = number of ACTIVE neighbours x != r of every active row r of one CSR direction (out: successors, in: predecessors).
+// ALL: everything is active (first count of a run): no gather of act[x], the pass is a pure adjacency stream
+template <bool ALL>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_scc_count_active(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E,
                                                                     const int32_t *act, int32_t *cnt)
 {
@@ -35,9 +37,11 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_scc_count_active(const int64_
     const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
     const int n = (int)min((int64_t)VGL_TILE, E - e0);
     const int r_first = tile_row[blockIdx.x], r_last = tile_row[blockIdx.x + 1];
-    int any = 0;
-    for (int r = r_first + threadIdx.x; r <= r_last; r += VGL_BLOCK) any |= act[r];
-    if (!__syncthreads_or(any)) return;
+    if (!ALL) {
+        int any = 0;
+        for (int r = r_first + threadIdx.x; r <= r_last; r += VGL_BLOCK) any |= act[r];
+        if (!__syncthreads_or(any)) return;
+    }
     vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
     const int i0 = threadIdx.x * VGL_EPT;
     int prev_row = -1, run = 0;
@@ -47,9 +51,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_scc_count_active(const int64_
         if (row != prev_row) {
             if (run) atomicAdd(cnt + r_first + prev_row, run);
             prev_row = row; run = 0;
-            live = act[r_first + row] != 0;
+            live = ALL || act[r_first + row] != 0;
         }
-        if (live) { const int32_t x = adj[e0 + i0 + j]; run += (x != r_first + row) && act[x]; }
+        if (live) { const int32_t x = adj[e0 + i0 + j]; run += (x != r_first + row) && (ALL || act[x]); }
     }
     if (run) atomicAdd(cnt + r_first + prev_row, run);
 }
@@ -191,14 +195,15 @@ int vgl_hip_scc_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_s
     int rc = 0;
     auto fail = [&](int code) { hipStreamSynchronize(st); hipFree(buf); return code; };
 #define SCC_TRY(expr) do { rc = (expr); if (rc != 0) return fail(rc); } while (0)
-    auto recount = [&]() -> int {
+    auto recount = [&](bool all) -> int {
         hipLaunchKernelGGL(vgl_k_scc_colour_init, dim3(scc_grid(V)), dim3(VGL_BLOCK), 0, st, V, act, colour, od, id);      // zeroes od / id too
-        if (g->out.ntiles > 0)
-            hipLaunchKernelGGL(vgl_k_scc_count_active, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, st, g->out.rowptr, g->out.adj,
-                               g->out.tile_row, g->out.edges, act, od);
-        if (g->in.ntiles > 0)
-            hipLaunchKernelGGL(vgl_k_scc_count_active, dim3((unsigned)g->in.ntiles), dim3(VGL_BLOCK), 0, st, g->in.rowptr, g->in.adj,
-                               g->in.tile_row, g->in.edges, act, id);
+        for (int k = 0; k < 2; k++) {
+            const vgl_dir_csr &d = k == 0 ? g->out : g->in;
+            int32_t *cnt = k == 0 ? od : id;
+            if (d.ntiles == 0) continue;
+            if (all) hipLaunchKernelGGL(vgl_k_scc_count_active<true>, dim3((unsigned)d.ntiles), dim3(VGL_BLOCK), 0, st, d.rowptr, d.adj, d.tile_row, d.edges, act, cnt);
+            else hipLaunchKernelGGL(vgl_k_scc_count_active<false>, dim3((unsigned)d.ntiles), dim3(VGL_BLOCK), 0, st, d.rowptr, d.adj, d.tile_row, d.edges, act, cnt);
+        }
         VGL_HIP_TRY(hipGetLastError());
         return 0;
     };
@@ -224,7 +229,7 @@ int vgl_hip_scc_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_s
         return 0;
     };
     hipLaunchKernelGGL(vgl_k_scc_init, dim3(scc_grid(V)), dim3(VGL_BLOCK), 0, st, V, act, d_comp);
-    SCC_TRY(recount());
+    SCC_TRY(recount(true));
     SCC_TRY(trim());
     int64_t active = 0;
     int32_t pivot = 0, key = 0;
@@ -237,7 +242,7 @@ int vgl_hip_scc_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_s
         hipLaunchKernelGGL(vgl_k_scc_intersect, dim3(scc_grid(V)), dim3(VGL_BLOCK), 0, st, V, fw, bw, act, d_comp, 0, c->d_counters);
         hipLaunchKernelGGL(vgl_k_scc_intersect, dim3(scc_grid(V)), dim3(VGL_BLOCK), 0, st, V, fw, bw, act, d_comp, 1, c->d_counters);
         s.forward_backward_steps++;
-        SCC_TRY(recount());
+        SCC_TRY(recount(false));
         SCC_TRY(trim());
         SCC_TRY(survey(&active, &pivot, &key));
     }
@@ -264,7 +269,7 @@ int vgl_hip_scc_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_s
         hipLaunchKernelGGL(vgl_k_scc_classes, dim3(scc_grid(V)), dim3(VGL_BLOCK), 0, st, V, act, colour, reach, minrep, d_comp, 1);
         hipLaunchKernelGGL(vgl_k_scc_classes, dim3(scc_grid(V)), dim3(VGL_BLOCK), 0, st, V, act, colour, reach, minrep, d_comp, 2);
         s.colour_rounds++;
-        SCC_TRY(recount());
+        SCC_TRY(recount(false));
         SCC_TRY(trim());
         SCC_TRY(survey(&active, &pivot, &key));
     }
