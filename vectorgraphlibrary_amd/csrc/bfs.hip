@@ -107,7 +107,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
                                                                 const int64_t *rowptr, int32_t *vt_cnt, int64_t *vt_deg,
                                                                 int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *offs, int64_t *counters,
-                                                                uint32_t *ticket, volatile int64_t *host, int64_t seq, uint64_t *visited_or)
+                                                                uint32_t *ticket, volatile int64_t *host, int64_t seq)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
@@ -116,7 +116,6 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
     int64_t deg = 0;
     if (wi < nwords) {
         uint64_t w = front[word0 + wi];
-        if (visited_or && w) visited_or[word0 + wi] |= w;          // the frontier joins the visited set here (no separate advance pass)
         cnt = __popcll(w);
         while (w) {
             const int b = __ffsll((long long)w) - 1;
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
 // last edge) -- every frontier vertex knows its own edge range, so the separate vgl_k_tile_first launch is not needed
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
                                                                 const int64_t *rowptr, const int32_t *vt_cnt_off, const int64_t *vt_deg_off,
-                                                                int32_t *ids, int64_t *offs, int32_t *tile_first, int64_t M, uint64_t *clear)
+                                                                int32_t *ids, int64_t *offs, int32_t *tile_first, int64_t M)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
@@ -163,7 +162,6 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, 
     int64_t deg = 0;
     if (wi < nwords) {
         w = front[word0 + wi];
-        if (clear) clear[word0 + wi] = 0;                          // the buffer the expand step will OR its discoveries into
         uint64_t t = w;
         while (t) {
             const int b = __ffsll((long long)t) - 1;
@@ -205,7 +203,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                                                             const int32_t *in_adj, int64_t in_edges, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
                                                             int32_t next_level, int32_t *heavy, int32_t *heavy_cnt, int64_t *partials,
-                                                            int32_t *heavy_off, uint32_t *ticket, uint64_t *visited_rw)
+                                                            int32_t *heavy_off, uint32_t *ticket)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s_nheavy;
@@ -217,12 +215,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
     int32_t *my_heavy = heavy + r_begin;                             // at most `chunk` deferrals per workgroup
     for (int32_t r = r_begin + threadIdx.x; r < r_end; r += VGL_BLOCK) {
         const int32_t v = row_base + r;
-        uint64_t vis_word = visited[v >> 6];                                // wave-uniform
-        if (visited_rw) {                          // the current frontier has not been merged into visited yet: do it for this word
-            const uint64_t fw = front[v >> 6];
-            if (fw & ~vis_word) { vis_word |= fw; if (vgl_lane() == 0) visited_rw[v >> 6] = vis_word; }
-        }
-        const uint64_t cand_word = ~vis_word & in_nz[v >> 6];
+        const uint64_t cand_word = ~visited[v >> 6] & in_nz[v >> 6];       // wave-uniform
         bool found = false, defer = false;
         if (cand_word != 0ULL) {
             if (r < nrows && ((cand_word >> (v & 63)) & 1ULL)) {
@@ -343,6 +336,16 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, in
     }
 }
 
+// visited |= next; front = next; next = 0 (ready for the next emitting step without a memset)   (one word per thread)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_advance(int64_t words, uint64_t *visited, uint64_t *front, uint64_t *next)
+{
+    for (int64_t w = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; w < words; w += (int64_t)gridDim.x * VGL_BLOCK) {
+        const uint64_t n = next[w];
+        if (n) { visited[w] |= n; next[w] = 0; }
+        front[w] = n;
+    }
+}
+
 // bit v = (levels[v] == level), or (levels[v] != level) when NOT_EQUAL (visited bitmap: level = -1)
 template <bool NOT_EQUAL>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_levels_to_bitmap(int32_t V, const int32_t *levels, int32_t level, uint64_t *bits)
@@ -419,7 +422,7 @@ static inline unsigned vgl_grid(int64_t n, int64_t cap = 8192) { return (unsigne
 
 // expand frontier (ids/offs with F vertices, M edges already produced by a frontier-generation write pass)
 static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_t M, int32_t *levels, int32_t next_level, bool emit,
-                             bool have_tile_first, const uint64_t *visited, uint64_t *next)
+                             bool have_tile_first)
 {
     if (F <= 0 || M <= 0) return 0;
     if (!have_tile_first) hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, F, g->offs, g->tile_first);
@@ -428,10 +431,10 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
         vgl_timed_launch tl(c, "bfs_top_down");
         if (emit)
             hipLaunchKernelGGL(vgl_k_td_expand<true>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                               g->out.rowptr, g->out.adj, g->row_begin, visited, levels, next_level, next);
+                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next);
         else
             hipLaunchKernelGGL(vgl_k_td_expand<false>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                               g->out.rowptr, g->out.adj, g->row_begin, visited, levels, next_level, next);
+                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;
@@ -440,8 +443,7 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
 // frontier of the current level from a frontier bitmap (owned words).  count: per-workgroup counts, their scan and F / M in
 // h_counters[C_FRONT] / [C_NEIGH] (one launch, the host waits for it); write: ids + edge offsets + tile_first (needs the M of
 // the count pass)
-static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1,
-                          uint64_t *visited_or = nullptr, uint64_t *clear_next = nullptr)
+static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1)
 {
     const int64_t word0 = g->row_begin >> 6;
     const int64_t nwords = vgl_ceil_div(g->row_end, 64) - word0;
@@ -452,7 +454,7 @@ static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *fron
             vgl_timed_launch tl(c, "gnf");
             hipLaunchKernelGGL(vgl_k_bm_gnf_count, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, front,
                                g->out.rowptr, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, g->offs, c->d_counters, g->tickets + 0 * VGL_TICKET_WORDS,
-                               (volatile int64_t *)c->h_counters, seq, visited_or);
+                               (volatile int64_t *)c->h_counters, seq);
         }
         VGL_HIP_TRY(hipGetLastError());
         VGL_TRY(vgl_wait_counters(c, seq));
@@ -460,7 +462,7 @@ static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *fron
     if (write) {
         vgl_timed_launch tl(c, "gnf");
         hipLaunchKernelGGL(vgl_k_bm_gnf_write, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, front,
-                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs, g->tile_first, M_known >= 0 ? M_known : c->h_counters[C_NEIGH], clear_next);
+                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs, g->tile_first, M_known >= 0 ? M_known : c->h_counters[C_NEIGH]);
         VGL_HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -469,14 +471,14 @@ static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *fron
 // one bottom-up step over the owned rows: probe (+ deferred-list offsets) and the balanced heavy pass (+ fold of the counters
 // C_BU_FOUND / C_BU_EDGES, published to the host under sequence number *seq_out: vgl_wait_counters when they are needed)
 static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, int32_t next_level, const uint64_t *visited,
-                             const uint64_t *front, uint64_t *next, int64_t *seq_out, uint64_t *visited_rw = nullptr)
+                             const uint64_t *front, uint64_t *next, int64_t *seq_out)
 {
     const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
     {
         vgl_timed_launch tl(c, "bfs_bottom_up");
         hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
                            g->in.rowptr, g->in.adj, g->in.edges, visited, g->bm_in_nz, front, next, levels, next_level,
-                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS, visited_rw);
+                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS);
     }
     const int64_t seq = vgl_next_seq(c);
     {
@@ -517,13 +519,9 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     vgl_hip_bfs_stats st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int32_t cur = 1;
     bool bottom_up = false;          // state used to PROCESS level `cur`
-    // Three bitmaps, used through pointers that rotate instead of being copied: bvis (vertices of the levels BEFORE cur, plus level
-    // cur once a step has looked at its frontier), bfront (the frontier of level cur when front_valid), bnext (where a step puts
-    // its discoveries).  There is no "advance" pass: the frontier-count kernel (top-down) and the probe kernel (bottom-up) OR the
-    // frontier into bvis on their way, the write kernel clears bnext, and after a step bfront / bnext trade places.
-    // When a top-down level was too large to emit a bitmap (more than VGL_TD_EMIT_EDGES edges) only `levels` knows the next
-    // frontier and the levels-scanning GNF rebuilds bfront and bvis.
-    uint64_t *bvis = g->bm_visited, *bfront = g->bm_front, *bnext = g->bm_next;
+    // Frontier of level `cur`: bm_front when front_valid (bm_visited is then current too); otherwise only `levels` knows it and
+    // the levels-scanning GNF rebuilds both bitmaps.  Frontiers are kept as bitmaps whenever the level that produced them was
+    // small (bottom-up steps always; top-down steps with at most VGL_TD_EMIT_EDGES edges, which OR their discoveries in).
     bool front_valid = true;
     bool counted = false;            // vt_cnt_off / vt_deg_off describe the frontier (needed by the write pass)
     bool counted_from_bitmap = false;
@@ -531,10 +529,10 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     const int64_t factor = std::max<int64_t>(1, (E / V) / 2);     // change_state.hpp:104
     constexpr int64_t VGL_TD_EMIT_EDGES = 16 << 20;
     auto count_frontier = [&]() -> int {
-        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, bfront, true, false, -1, bvis, nullptr)); counted_from_bitmap = true; }
+        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false)); counted_from_bitmap = true; }
         else {
             vgl_pred_equal_i32 pred{d_levels, cur};
-            VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)bfront, (uint8_t *)bvis, nullptr, false, true));
+            VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, nullptr, false, true));
             front_valid = true; counted_from_bitmap = false;
         }
         F = c->h_counters[C_FRONT]; M = c->h_counters[C_NEIGH];
@@ -559,24 +557,27 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         prevF = F;
         if (!bottom_up) {
             if (!counted) VGL_FAIL("bfs_run: internal error (frontier not counted)");
-            const bool emit = M <= VGL_TD_EMIT_EDGES;
-            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, bfront, false, true, M, nullptr, bnext));      // also clears bnext
+            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, false, true, M));
             else {
-                if (emit) VGL_HIP_TRY(hipMemsetAsync(bnext, 0, sizeof(uint64_t) * (size_t)words, c->stream));
                 vgl_pred_equal_i32 pred{d_levels, cur};
                 vgl_timed_launch tl(c, "gnf");
                 hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_equal_i32>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred,
                                    g->nrows, g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
             }
-            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap, bvis, bnext));
-            if (emit) std::swap(bfront, bnext);              // the discoveries are the next frontier
+            const bool emit = M <= VGL_TD_EMIT_EDGES;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
+            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap));
+            if (emit)
+                hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
+                                   g->bm_front, g->bm_next);
             front_valid = emit;
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
         } else {
             if (!front_valid) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
             int64_t seq = 0;
-            VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, bvis, bfront, bnext, &seq, bvis));      // ORs bfront into bvis word by word
-            std::swap(bfront, bnext);
+            VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next, &seq));
+            hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
+                               g->bm_front, g->bm_next);
+            VGL_HIP_TRY(hipGetLastError());
             VGL_TRY(vgl_wait_counters(c, seq));
             st.bu_steps++; st.edges_examined += c->h_counters[C_BU_EDGES];
             st.bu_edges += c->h_counters[C_BU_EDGES]; st.bu_found += c->h_counters[C_BU_FOUND];
