@@ -203,7 +203,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                                                             const int32_t *in_adj, int64_t in_edges, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
                                                             int32_t next_level, int32_t *heavy, int32_t *heavy_cnt, int64_t *partials,
-                                                            int32_t *heavy_off, uint32_t *ticket)
+                                                            int32_t *heavy_off, uint32_t *ticket, const int4 *in_head, const uint64_t *in_long)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s_nheavy;
@@ -219,31 +219,28 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
         bool found = false, defer = false;
         if (cand_word != 0ULL) {
             if (r < nrows && ((cand_word >> (v & 63)) & 1ULL)) {
-                const int64_t b = in_rowptr[r], e = in_rowptr[r + 1];
-                const int n = (int)min((int64_t)VGL_BU_PROBES, e - b);
-                // two stages of 4 probes: most candidates find their parent among the first neighbours, and each stage is one
-                // 16-byte (4-byte aligned) adjacency load when it stays inside the array instead of four scattered dword loads
+                // The row's first eight in-neighbours come from two planes of 16-byte head records (coalesced over the wavefront, no
+                // row offsets, no dependent adjacency load): most candidates find their parent among the first four, the rest look
+                // at the next four; a row that still misses and is longer than eight goes to the wavefront pass.
+                const int4 h = in_head[r];
+                const int32_t u0[4] = {h.x, h.y, h.z, h.w};
                 uint32_t hit = 0;
+                int n = 0;
 #pragma unroll
-                for (int stage = 0; stage < VGL_BU_PROBES / 4; stage++) {
-                    if (hit == 0 && stage * 4 < n) {
-                        int32_t u[4];
-                        const int64_t p0 = b + stage * 4;
-                        if (p0 + 4 <= in_edges) {
-                            const vgl_int4_u q = *reinterpret_cast<const vgl_int4_u *>(in_adj + p0);
-                            u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
-                        } else {
+                for (int j = 0; j < 4; j++)
+                    if (u0[j] >= 0) { n = j + 1; hit |= (uint32_t)((front[u0[j] >> 6] >> (u0[j] & 63)) & 1ULL) << j; }
+                bool longer = false;
+                if (hit == 0 && n == 4) {
+                    const int4 k = in_head[(int64_t)nrows + r];
+                    const int32_t u1[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
-                            for (int j = 0; j < 4; j++) u[j] = (p0 + j < in_edges) ? in_adj[p0 + j] : 0;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (stage * 4 + j < n) hit |= (uint32_t)((front[u[j] >> 6] >> (u[j] & 63)) & 1ULL) << (stage * 4 + j);
-                    }
+                    for (int j = 0; j < 4; j++)
+                        if (u1[j] >= 0) { n = 5 + j; hit |= (uint32_t)((front[u1[j] >> 6] >> (u1[j] & 63)) & 1ULL) << (4 + j); }
+                    longer = (in_long[v >> 6] >> (v & 63)) & 1ULL;
                 }
                 found = hit != 0;
                 probes += found ? __ffs(hit) : n;        // adjacency entries a sequential scan would have examined
-                defer = !found && (e - b) > VGL_BU_PROBES;
+                defer = !found && longer;
                 if (found) levels[v] = next_level;
             }
         }
@@ -478,7 +475,7 @@ static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, 
         vgl_timed_launch tl(c, "bfs_bottom_up");
         hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
                            g->in.rowptr, g->in.adj, g->in.edges, visited, g->bm_in_nz, front, next, levels, next_level,
-                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS);
+                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS, reinterpret_cast<const int4 *>(g->in_head), g->bm_in_long);
     }
     const int64_t seq = vgl_next_seq(c);
     {

@@ -27,6 +27,27 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_nonempty_rows(int32_t nrows, 
     }
 }
 
+// head[r] = the first four entries of row r (-1 padded): one aligned 16-byte record per row, so the bottom-up probe reads its first
+// candidates with a single coalesced load instead of row offsets + a dependent adjacency load
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_row_heads(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj, int4 *head0,
+                                                             int4 *head1, uint64_t *long_bits)
+{
+    const int32_t nround = (nrows + 63) & ~63;
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nround; r += gridDim.x * VGL_BLOCK) {
+        int64_t n = 0;
+        if (r < nrows) {
+            const int64_t b = rowptr[r];
+            n = rowptr[r + 1] - b;
+            int4 h, k;
+            h.x = n > 0 ? adj[b] : -1; h.y = n > 1 ? adj[b + 1] : -1; h.z = n > 2 ? adj[b + 2] : -1; h.w = n > 3 ? adj[b + 3] : -1;
+            k.x = n > 4 ? adj[b + 4] : -1; k.y = n > 5 ? adj[b + 5] : -1; k.z = n > 6 ? adj[b + 6] : -1; k.w = n > 7 ? adj[b + 7] : -1;
+            head0[r] = h; head1[r] = k;
+        }
+        const unsigned long long m = __ballot(n > 8);
+        if ((threadIdx.x & 63) == 0) long_bits[(row_base + r) >> 6] = m;
+    }
+}
+
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_iota_flags(int32_t n, int32_t *ids, int32_t *flags, int32_t flag)
 {
     for (int32_t i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
@@ -199,6 +220,11 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     if (g->in.rowptr) {
         int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, vgl_ceil_div(g->nrows, VGL_BLOCK)));
         hipLaunchKernelGGL(vgl_k_nonempty_rows, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, g->in.rowptr, g->bm_in_nz);
+        VGL_TRY(vgl_alloc(&g->in_head, (size_t)g->nrows * 8));
+        VGL_TRY(vgl_alloc(&g->bm_in_long, words));
+        VGL_HIP_TRY(hipMemsetAsync(g->bm_in_long, 0, words * 8, c->stream));
+        hipLaunchKernelGGL(vgl_k_row_heads, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, g->in.rowptr, g->in.adj,
+                           reinterpret_cast<int4 *>(g->in_head), reinterpret_cast<int4 *>(g->in_head) + g->nrows, g->bm_in_long);
         VGL_HIP_TRY(hipGetLastError());
     }
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -211,7 +237,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     if (!g) return 0;
     if (c) hipStreamSynchronize(c->stream);
     if (g->transposed) { vgl_hip_graph_destroy(c, g->transposed); g->transposed = nullptr; }
-    void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->ids, g->offs, g->vt_cnt,
+    void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
                     g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->out.hub_rows, g->in.hub_rows};
     for (void *p : ptrs) if (p) hipFree(p);

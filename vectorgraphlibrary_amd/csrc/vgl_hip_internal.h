@@ -75,6 +75,8 @@ struct vgl_hip_graph {
     // scratch shared by the fused algorithms (allocated at creation, sized by V / nrows / edges)
     uint64_t *bm_visited = nullptr, *bm_front = nullptr, *bm_next = nullptr; // ceil(V/64)+1 words each
     uint64_t *bm_in_nz = nullptr;    // bit v = owned vertex v has incoming edges (bottom-up candidates)
+    int32_t *in_head = nullptr;      // two planes of 4 per owned row: in-neighbours 0-3 and 4-7 (-1 padded), 16-byte records (bottom-up probes)
+    uint64_t *bm_in_long = nullptr;  // bit v = owned vertex v has more than 8 incoming edges (deferred to the wavefront pass when it misses)
     int32_t *ids = nullptr;          // nrows
     int64_t *offs = nullptr;         // nrows+1
     int32_t *vt_cnt = nullptr, *vt_cnt_off = nullptr;   // per vertex tile
