@@ -13,7 +13,10 @@
 #include "vgl_hip_internal.h"
 #include "vgl_gnf.h"
 
-constexpr int VGL_BU_PROBES = 8;       // thread-serial probes before a vertex is deferred to the wavefront pass
+constexpr int VGL_BU_PROBES = 8;
+#ifndef VGL_BU_HEAVY_LANES
+#define VGL_BU_HEAVY_LANES 16       // lanes per deferred vertex in the second bottom-up pass
+#endif       // thread-serial probes before a vertex is deferred to the wavefront pass
 constexpr int VGL_DO_ALPHA = 15;       // change_state.hpp:5
 constexpr int VGL_DO_BETA = 18;        // change_state.hpp:6
 
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
     if (threadIdx.x == 0) heavy_off[VGL_BU_BLOCKS] = total;
 }
 
-// pass 2: all deferred vertices, one wavefront per vertex, 64 incoming neighbours per step, early exit on the first hit.
+// pass 2: all deferred vertices, a quarter wavefront per vertex, 16 incoming neighbours per step, early exit on the first hit.
 // The deferred lists are per-workgroup segments (pass 1); wavefronts stride over the CONCATENATION of the segments so the
 // work is balanced even when the deferred vertices cluster (in a degree-sorted graph they are the first ids).
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
@@ -292,21 +295,34 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, in
     __syncthreads();
     const int total = s_off[VGL_BU_BLOCKS];
     int64_t found_cnt = 0, probes = 0;
-    for (int h = blockIdx.x * VGL_WAVES + vgl_wave(); h < total; h += gridDim.x * VGL_WAVES) {
-        int lo = 0, hi = VGL_BU_BLOCKS;                     // segment s with s_off[s] <= h < s_off[s+1]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
-        const int32_t r = heavy[(int64_t)lo * chunk + (h - s_off[lo])];
-        const int64_t b = in_rowptr[r] + VGL_BU_PROBES, e = in_rowptr[r + 1];
-        bool hit_any = false;
-        for (int64_t p = b; p < e && !hit_any; p += 64) {
-            const int64_t q = p + vgl_lane();
-            bool hit = false;
-            if (q < e) { const int32_t u = in_adj[q]; hit = (front[u >> 6] >> (u & 63)) & 1ULL; }
-            const unsigned long long hm = __ballot(hit);
-            hit_any = hm != 0ULL;
-            if (vgl_lane() == 0) probes += hit_any ? (int64_t)(__ffsll((long long)hm)) : min((int64_t)64, e - p);
+    // Four deferred vertices per wavefront, 16 lanes each: most deferred rows have a few dozen entries left, a whole wavefront per
+    // row left three quarters of the lanes idle.  A quarter scans 16 entries per step and stops at its first hit; the wavefront
+    // moves on when all four are done.
+    constexpr int G = VGL_BU_HEAVY_LANES, NG = 64 / G;       // lanes per vertex, vertices per wavefront
+    const int quarter = vgl_lane() / G, ql = vgl_lane() % G;
+    for (int h0 = (blockIdx.x * VGL_WAVES + vgl_wave()) * NG; h0 < total; h0 += gridDim.x * VGL_WAVES * NG) {
+        const int h = h0 + quarter;
+        bool done = h >= total, hit_any = false;
+        int32_t r = 0;
+        int64_t p = 0, e = 0;
+        if (!done) {
+            int lo = 0, hi = VGL_BU_BLOCKS;                 // segment s with s_off[s] <= h < s_off[s+1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
+            r = heavy[(int64_t)lo * chunk + (h - s_off[lo])];
+            p = in_rowptr[r] + VGL_BU_PROBES; e = in_rowptr[r + 1];
         }
-        if (hit_any && vgl_lane() == 0) {
+        while (!__all(done)) {
+            const int64_t q = p + ql;
+            bool hit = false;
+            if (!done && q < e) { const int32_t u = in_adj[q]; hit = (front[u >> 6] >> (u & 63)) & 1ULL; }
+            const unsigned long long hm = __ballot(hit);
+            const unsigned qm = (unsigned)(hm >> (quarter * G)) & ((1u << G) - 1u);
+            if (!done) {
+                if (qm) { hit_any = true; done = true; if (ql == 0) probes += __ffs(qm); }
+                else { if (ql == 0) probes += min((int64_t)G, e - p); p += G; if (p >= e) done = true; }
+            }
+        }
+        if (hit_any && ql == 0) {
             const int32_t v = row_base + r;
             levels[v] = next_level;
             atomicOr((unsigned long long *)&next[v >> 6], 1ULL << (v & 63));
