@@ -229,9 +229,14 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                 const int32_t u0[4] = {h.x, h.y, h.z, h.w};
                 uint32_t hit = 0;
                 int n = 0;
+                // the first in-neighbour alone first: when it is in the frontier (the common case once the frontier is large) the
+                // other three frontier words are never requested -- the kernel is bound by the rate of these scattered requests
+                if (u0[0] >= 0) { n = 1; hit = (uint32_t)((front[u0[0] >> 6] >> (u0[0] & 63)) & 1ULL); }
+                if (hit == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (u0[j] >= 0) { n = j + 1; hit |= (uint32_t)((front[u0[j] >> 6] >> (u0[j] & 63)) & 1ULL) << j; }
+                    for (int j = 1; j < 4; j++)
+                        if (u0[j] >= 0) { n = j + 1; hit |= (uint32_t)((front[u0[j] >> 6] >> (u0[j] & 63)) & 1ULL) << j; }
+                }
                 bool longer = false;
                 if (hit == 0 && n == 4) {
                     const int4 k = in_head[(int64_t)nrows + r];
