@@ -244,6 +244,8 @@ int vgl_hip_bfs_step_top_down(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_lev
 int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *ctx, vgl_hip_graph *graph, int32_t *d_levels, int32_t level,
                                    const uint64_t *d_visited_bits, const uint64_t *d_front_bits, uint64_t *d_next_bits,
                                    int64_t *local_frontier, int64_t *local_edges);
+/* out[w] = OR over p < parts of in[p * words + w]  (merging the bitmap slices a rank received in the two-phase exchange) */
+int vgl_hip_bitmap_or_parts(vgl_hip_ctx *ctx, int64_t words, int parts, const uint64_t *d_in, uint64_t *d_out);
 int vgl_hip_bfs_step_bottom_up(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_levels, int32_t level,
                                const uint64_t *d_visited_bits, const uint64_t *d_front_bits, uint64_t *d_next_bits,
                                int64_t *found, int64_t *probed);

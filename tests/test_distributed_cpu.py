@@ -60,6 +60,9 @@ class NumpyShardOps:
         self._pack(found, mine)
         return int(fr[self.lo:self.hi].sum()), int(m.sum())
 
+    def or_parts(self, parts, bits_in, bits_out):
+        bits_out.numpy()[:] = np.bitwise_or.reduce(bits_in.numpy().reshape(parts, -1), axis=0)
+
     def levels_to_bitmap(self, levels, level, bits):
         b = np.zeros(((self.V + 63) // 64) * 64, np.uint8)
         b[:self.V] = levels.numpy() == level
@@ -179,6 +182,10 @@ def _worker(rank, world, port, results):
     eq = NumpyShardOps(V, rowptr, adj, w, rank * (V // world), (rank + 1) * (V // world))
     levels_eq, _ = vd.bfs_sharded(eq, source, degrees=degrees, edges=len(adj), equal_ranges=True)
     assert (levels_eq.numpy() == levels.numpy()).all(), "sliced exchange (equal ranges) != full-bitmap exchange"
+    levels_2p, _ = vd.bfs_sharded(eq, source, degrees=degrees, edges=len(adj), equal_ranges=True, two_phase=True)
+    assert (levels_2p.numpy() == levels.numpy()).all(), "two-phase top-down exchange != full-bitmap exchange"
+    levels_2p_td, _ = vd.bfs_sharded(eq, source, equal_ranges=True, two_phase=True)          # top-down only: every level two-phase
+    assert (levels_2p_td.numpy() == levels.numpy()).all()
     d, _ = vd.sssp_sharded(ops, source)
     comp, _ = vd.cc_sharded(ops)
     ranks = vd.page_rank_sharded(ops, 3, bounds[rank], bounds[rank + 1])

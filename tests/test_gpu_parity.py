@@ -721,3 +721,24 @@ def test_scc_larger_graphs_match_oracle(kind, scale, ef, ctx, oracle):
     g1 = api.Graph.from_coo(ctx, 1, one, one)
     assert (api.strongly_connected_components(g1)[0].cpu().numpy() == [0]).all()
     g1.close()
+
+
+@pytest.mark.gpu
+def test_bitmap_or_parts(ctx):
+    """the merge step of the two-phase top-down exchange (distributed.bfs_sharded): out = OR of the received slices"""
+    import torch
+    from vectorgraphlibrary_amd import api, distributed as vd
+    V = 64 * 1000
+    src = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+    g = api.Graph.from_coo(ctx, V, src, src)
+    ops = vd.HipShardOps(g)
+    P, words = 5, 200
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    parts = torch.randint(-2**62, 2**62, (P * words,), generator=gen, dtype=torch.int64).to(ctx.device)
+    out = torch.empty(words, dtype=torch.int64, device=ctx.device)
+    ops.or_parts(P, parts, out)
+    want = parts.view(P, words)[0].clone()
+    for p in range(1, P):
+        want |= parts.view(P, words)[p]
+    assert torch.equal(out, want)
+    g.close()

@@ -376,6 +376,15 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_levels_to_bitmap(int32_t V, c
     }
 }
 
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bitmap_or_parts(int64_t words, int parts, const uint64_t *in, uint64_t *out)
+{
+    for (int64_t w = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; w < words; w += (int64_t)gridDim.x * VGL_BLOCK) {
+        uint64_t acc = 0;
+        for (int p = 0; p < parts; p++) acc |= in[(int64_t)p * words + w];
+        out[w] = acc;
+    }
+}
+
 // OR the per-rank discovery bitmaps, mark the newly discovered vertices in levels, and (optionally) keep the replicated
 // visited / frontier bitmaps and the frontier's out-degree sum up to date for the direction decision of the next level
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_bitmaps(int32_t V, int parts, int64_t words, const uint64_t *bits_all,
@@ -672,6 +681,15 @@ int vgl_hip_bfs_step_bottom_up(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_leve
         if (found) *found = c->h_counters[C_BU_FOUND];
         if (probed) *probed = c->h_counters[C_BU_EDGES];
     }
+    return 0;
+}
+
+int vgl_hip_bitmap_or_parts(vgl_hip_ctx *c, int64_t words, int parts, const uint64_t *d_in, uint64_t *d_out)
+{
+    if (!c || !d_in || !d_out) VGL_FAIL("bitmap_or_parts: null argument");
+    if (words < 0 || parts < 1) VGL_FAIL("bitmap_or_parts: bad size");
+    if (words > 0) hipLaunchKernelGGL(vgl_k_bitmap_or_parts, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, parts, d_in, d_out);
+    VGL_HIP_TRY(hipGetLastError());
     return 0;
 }
 

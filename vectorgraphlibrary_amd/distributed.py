@@ -71,6 +71,9 @@ class HipShardOps:
         _l.check(self.L.vgl_hip_bfs_step_bottom_up(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), _ptr(front), _ptr(mine),
                                                    None, None))
 
+    def or_parts(self, parts, bits_in, bits_out):
+        _l.check(self.L.vgl_hip_bitmap_or_parts(self.ctx.h, bits_out.numel(), int(parts), _ptr(bits_in), _ptr(bits_out)))
+
     def levels_to_bitmap(self, levels, level, bits):
         _l.check(self.L.vgl_hip_levels_to_bitmap(self.ctx.h, self.V, _ptr(levels), int(level), _ptr(bits)))
 
@@ -201,14 +204,17 @@ def _allreduce(t, op, group):
 ALPHA, BETA = 15, 18          # change_state.hpp:5-6
 
 
-def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False):
+def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False, two_phase=None):
     """BFS over edge-cut shards; returns the replicated levels array and the number of levels.
     degrees (int32[V] out-degrees of ALL vertices, replicated) + edges (global E) enable direction optimisation: every rank
     evaluates the same switch rule (gpu_change_state, change_state.hpp:100-141) on replicated counters, bottom-up steps scan
     the owned rows' incoming edges.  Without them the traversal is top-down only.
     Exchange per level: all-gather of V/8-byte discovery bitmaps.  equal_ranges=True (every rank owns V/P rows, V/P a multiple
     of 64; build_generated_shard(placement="dealt")) lets the bottom-up levels -- which only discover owned vertices -- gather
-    the owned V/(8P)-byte slices instead, P times less traffic; the caller guarantees the flag is the same on all ranks."""
+    the owned V/(8P)-byte slices instead, P times less traffic; the caller guarantees the flag is the same on all ranks.
+    two_phase (needs equal_ranges; default: on for P >= 4): top-down levels, whose discoveries lie anywhere, exchange in two steps
+    -- all-to-all of the V/(8P)-byte slices (every rank receives the P versions of ITS slice and ORs them), then all-gather of the
+    merged slices -- 2*V/8 bytes per rank instead of P*V/8."""
     P, rank = _world(group)
     V = ops.V
     levels = ops.new_i32()
@@ -221,6 +227,12 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
         if V % (64 * P) or lo != rank * (V // P) or hi != lo + V // P:
             raise ValueError("bfs_sharded: equal_ranges needs rank r to own rows [r*V/P, (r+1)*V/P) with V/P a multiple of 64")
         merged = ops.new_words(1)
+    if two_phase is None:
+        two_phase = merged is not None and P >= 4
+    if two_phase and merged is None:
+        raise ValueError("bfs_sharded: two_phase needs equal_ranges and more than one rank")
+    if two_phase:
+        slices_in, my_slice = ops.new_words(1), ops.new_words(1)[:(hi - lo) // 64]      # P received slices / their OR
     visited, front = ops.new_words(1), ops.new_words(1)
     ops.levels_to_bitmap(levels, 1, front)
     visited.copy_(front)
@@ -248,6 +260,12 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
             ops.sync()
             if bottom_up and merged is not None:
                 dist.all_gather_into_tensor(merged, mine[lo // 64:hi // 64], group=group)
+                parts, bits = 1, merged
+            elif two_phase:
+                dist.all_to_all_single(slices_in, mine, group=group)       # slice r of every rank's bitmap -> rank r
+                ops.or_parts(P, slices_in, my_slice)
+                ops.sync()
+                dist.all_gather_into_tensor(merged, my_slice, group=group)
                 parts, bits = 1, merged
             else:
                 dist.all_gather_into_tensor(everyone, mine, group=group)

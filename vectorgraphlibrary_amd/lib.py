@@ -96,6 +96,7 @@ _SIGNATURES = {
     "vgl_hip_bfs_init": [_p, _i32, _i32, _p],
     "vgl_hip_bfs_step_top_down": [_p, _p, _p, _i32, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_bfs_step_top_down_bits": [_p, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
+    "vgl_hip_bitmap_or_parts": [_p, _i64, _int, _p, _p],
     "vgl_hip_bfs_step_bottom_up": [_p, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_levels_to_bitmap": [_p, _i32, _p, _i32, _p],
     "vgl_hip_bfs_apply_bitmaps": [_p, _i32, _int, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
