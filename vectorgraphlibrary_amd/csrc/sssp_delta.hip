@@ -237,7 +237,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_tile_first(const int64_t *
 // persistent relax over the frontier's edge tiles; prow / adj_p / w_p are the part (light or heavy) the step walks
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *counters, const int32_t *ids, const int64_t *offs, const int32_t *tile_first,
                                                             const int64_t *prow, const int32_t *adj_p, const float *w_p,
-                                                            int32_t row_base, float T, float *dist, uint8_t *state, int64_t *near_partials, int hotskip)
+                                                            int32_t row_base, float T, float *dist, uint8_t *state, int64_t *near_partials)
 {
     constexpr int STAGE = 1024;                             // rows staged per tile: 8 + 8 + 4 KB of LDS => 8 workgroups per CU
     __shared__ int s_map[VGL_TILE];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *count
         for (int j = 0; j < VGL_EPT; j++) olds[j] = dsts[j] >= 0 ? dist[dsts[j]] : 0.0f;
 #pragma unroll
         for (int j = 0; j < VGL_EPT; j++) {
-            if (dsts[j] >= hotskip && olds[j] > nds[j]) {
+            if (dsts[j] >= 0 && olds[j] > nds[j]) {
                 const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
                 if (before > __float_as_int(nds[j])) {
                     state[dsts[j]] = 3;                         // light and heavy edges pending again
@@ -546,7 +546,6 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     const int32_t V = g->V;
     hipStream_t st = c->stream;
     const bool debug = getenv("VGL_HIP_DEBUG") != nullptr;
-    const int hotskip = getenv("VGL_HIP_EXPERIMENT_HOTSKIP") ? atoi(getenv("VGL_HIP_EXPERIMENT_HOTSKIP")) : 0;
     hipLaunchKernelGGL(vgl_k_ds_init, dim3(vgl_ds_grid(V, 8192)), dim3(VGL_BLOCK), 0, st, V, source, d_dist, p->state);
     vgl_hip_sssp_stats s = {0, 0, 0};
     float T = p->delta;
@@ -577,7 +576,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
             hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
             vgl_timed_launch tl(c, "sssp_relax");
             hipLaunchKernelGGL(vgl_k_ds_relax, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
-                               p->prow[k], p->padj[k], p->pw[k], g->row_begin, T, d_dist, p->state, near_partials, hotskip);
+                               p->prow[k], p->padj[k], p->pw[k], g->row_begin, T, d_dist, p->state, near_partials);
         }
         const int64_t seq = vgl_next_seq(c);
         hipLaunchKernelGGL(vgl_k_ds_min_pending, dim3(1024), dim3(VGL_BLOCK), 0, st, V, p->state, d_dist, p->partials, near_partials, (int)(bit == 1),
