@@ -742,3 +742,55 @@ def test_bitmap_or_parts(ctx):
         want |= parts.view(P, words)[p]
     assert torch.equal(out, want)
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_random_graphs_all_algorithms(seed, ctx, oracle):
+    """differential sweep over small random graphs of awkward shapes (V not a multiple of 64 / 2048, isolated vertices, self loops,
+    duplicate edges, a few hub rows spanning several edge tiles, sometimes no edges at all): every fused algorithm against the oracle"""
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    rng = np.random.default_rng(1000 + seed)
+    V = int(rng.integers(1, 5000))
+    E = int(rng.integers(0, 12 * V + 1)) if seed % 5 else 0
+    # skewed endpoints: squaring a uniform variate concentrates edges on low ids (hub rows of thousands of edges)
+    src = np.minimum((rng.random(E) ** (1 + seed % 3) * V).astype(np.int32), V - 1)
+    dst = np.minimum((rng.random(E) ** (1 + (seed // 3) % 3) * V).astype(np.int32), V - 1)
+    rowptr, adj, perm = O.coo_to_csr(V, src, dst)
+    w_in = (rng.random(E) * 100).astype(np.float32)
+    w = w_in[perm] if E else np.zeros(0, np.float32)
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device) if len(a) else torch.zeros(0, dtype=dt, device=ctx.device)
+    g = api.Graph.from_coo(ctx, V, dev(src, torch.int32), dev(dst, torch.int32), want_perm=True)
+    assert (g.out_rowptr.cpu().numpy() == rowptr).all() and (g.out_adj.cpu().numpy()[:E] == adj).all()
+    w_d = ctx.gather_u32(g.perm, dev(w_in, torch.float32)) if E else torch.zeros(1, dtype=torch.float32, device=ctx.device)
+    source = int(rng.integers(0, V))
+    ref_levels, _ = O.bfs_top_down(rowptr, adj, source)
+    for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+        assert (api.bfs(g, source, mode)[0].cpu().numpy() == ref_levels).all(), f"BFS mode {mode}"
+    ref_dist, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
+        d, _ = api.sssp(g, w_d, source, mode, delta=float(rng.choice([0.5, 7.0, 40.0])))
+        assert (d.cpu().numpy().view(np.int32) == ref_dist.view(np.int32)).all(), f"SSSP mode {mode}"
+    ref_width, _ = O.sswp_bellman_ford(rowptr, adj, w, source)
+    assert (api.sswp(g, w_d, source)[0].cpu().numpy().view(np.int32) == ref_width.view(np.int32)).all()
+    assert (api.page_rank(g, 3)[0].cpu().numpy().view(np.int32) == O.pagerank(rowptr, adj, 3, 1).view(np.int32)).all()
+    assert (api.connected_components(g)[0].cpu().numpy() == O.cc_sv(rowptr, adj)[0]).all()
+    assert (api.strongly_connected_components(g)[0].cpu().numpy() == O.scc_tarjan(rowptr, adj)).all()
+    if E:
+        wa, wh = O.hits(rowptr, adj, 2)
+        a, h = api.hits(g, 2)
+        ok = np.isfinite(wa).all() and np.isfinite(wh).all()          # all-zero norms (no edge reaches anything) give NaN in the reference too
+        if ok:
+            assert _relerr64(a.cpu().numpy(), wa) <= HITS_RTOL and _relerr64(h.cpu().numpy(), wh) <= HITS_RTOL
+    g.close()
+    # symmetrised: union-find CC == Shiloach-Vishkin labels
+    if E:
+        s2, d2 = np.concatenate([src, dst]), np.concatenate([dst, src])
+        gs = api.Graph.from_coo(ctx, V, dev(s2, torch.int32), dev(d2, torch.int32), with_incoming=False)
+        rp2, adj2, _ = O.coo_to_csr(V, s2, d2, want_perm=False)
+        want = O.cc_sv(rp2, adj2)[0]
+        assert (api.connected_components(gs, symmetric=True)[0].cpu().numpy() == want).all()
+        assert (api.connected_components(gs)[0].cpu().numpy() == want).all()
+        gs.close()
