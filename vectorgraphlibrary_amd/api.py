@@ -349,6 +349,9 @@ def hits(graph, steps, raw=False):
 
 def connected_components(graph, comp=None, raw=False, symmetric=False):
     """labels = smallest ORIGINAL vertex id that reaches each vertex (raw=True: smallest id in the graph's numbering).
+    On a DIRECTED graph the hook / jump fixed point ("smallest id that reaches v") depends on the vertex numbering -- as in the
+    reference (exact under identical numbering) -- so with a renumbered graph the conversion back to original ids is
+    only meaningful for symmetric inputs, where the labels describe the components.
     symmetric=True: the caller vouches that every edge is stored in both directions; the same labels then come from a min-id
     union-find (vgl_hip_cc_run_symmetric) instead of repeated sweeps over all edges."""
     ctx = graph.ctx
