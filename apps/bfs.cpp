@@ -7,12 +7,13 @@ int main(int argc, char **argv)
         VGL_RUNTIME::init_library(argc, argv);
         Parser parser;
         parser.parse_args(argc, argv);
-        VGL_Graph graph;
+        VGL_Graph graph(parser.format);
         prepare_graph(graph, parser);
         VerticesArray<int> levels(graph, SCATTER);
         double avg_perf = 0;
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {
-            const int source_vertex = parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(SCATTER, i);
+            // -source and select_random_nz_vertex speak ORIGINAL ids; algorithms and checkers work in the stored numbering
+            const int source_vertex = graph.reorder(parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
             const double perf = parser.fused ? BFS::hip_fused(graph, levels, source_vertex, parser.direction_optimising)
                                              : BFS::vgl_top_down(graph, levels, source_vertex);
             avg_perf += perf / parser.get_number_of_rounds();
@@ -21,6 +22,7 @@ int main(int argc, char **argv)
                 verify_results(levels.to_host(), seq_bfs(h, source_vertex));
             }
         }
+        levels.reorder(ORIGINAL);
         dump_array(parser.dump, levels.to_host());
         report_performance(avg_perf);
         VGL_RUNTIME::finalize_library();

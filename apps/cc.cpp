@@ -7,7 +7,7 @@ int main(int argc, char **argv)
         VGL_RUNTIME::init_library(argc, argv);
         Parser parser;
         parser.parse_args(argc, argv);
-        VGL_Graph graph;
+        VGL_Graph graph(parser.format);
         prepare_graph(graph, parser, UNDIRECTED_GRAPH);
         VerticesArray<int> components(graph, SCATTER);
         const bool symmetric = parser.import_file.empty();      // generated UNDIRECTED_GRAPH inputs hold both directions of every edge
@@ -19,6 +19,7 @@ int main(int argc, char **argv)
             HostCSR h(graph);
             equal_components(components.to_host(), seq_components(h));
         }
+        components.reorder_labels_to_original();
         dump_array(parser.dump, components.to_host());
         VGL_RUNTIME::finalize_library();
     } catch (std::string error) { std::cout << error << std::endl; return 1; }

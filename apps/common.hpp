@@ -14,6 +14,7 @@
 struct Parser {
     int scale = 10, avg_degree = 5, rounds = 1, source = -1;
     bool rmat = true, check = false, direction_optimising = false, fused = false;
+    GraphStorageFormat format = CSR_GRAPH;      // -format csr | vcsr (VECTOR_CSR_GRAPH: degree-renumbered, the reference's default)
     unsigned long long seed = 1;
     std::string dump, import_file;
     void parse_args(int argc, char **argv)
@@ -33,7 +34,7 @@ struct Parser {
             else if (a == "-do") direction_optimising = true;
             else if (a == "-td") direction_optimising = false;
             else if (a == "-fused") fused = true;
-            else if (a == "-format") next();                       // csr only; accepted for CLI compatibility
+            else if (a == "-format") { const std::string f = next(); format = (f == "vcsr" || f == "vect_csr") ? VECTOR_CSR_GRAPH : CSR_GRAPH; }
             else if (a == "-push" || a == "-all-active") {}
             else throw "unknown command line option";
         }

@@ -8,7 +8,7 @@ int main(int argc, char **argv)
         VGL_RUNTIME::init_library(argc, argv);
         Parser parser;
         parser.parse_args(argc, argv);
-        VGL_Graph graph;
+        VGL_Graph graph(parser.format);
         prepare_graph(graph, parser);
         VerticesArray<base_type> auth(graph), hub(graph);
         const int steps = parser.get_number_of_rounds();
@@ -25,7 +25,9 @@ int main(int argc, char **argv)
             }
             std::cout << "error count: " << (worst <= 1e-9 ? 0 : 1) << std::endl;
         }
-        a.insert(a.end(), h.begin(), h.end());                     // dump: authorities then hubs
+        auth.reorder(ORIGINAL); hub.reorder(ORIGINAL);
+        a = auth.to_host(); h = hub.to_host();
+        a.insert(a.end(), h.begin(), h.end());                     // dump: authorities then hubs (ORIGINAL numbering)
         dump_array(parser.dump, a);
         VGL_RUNTIME::finalize_library();
     } catch (std::string error) { std::cout << error << std::endl; return 1; }

@@ -7,7 +7,7 @@ int main(int argc, char **argv)
         VGL_RUNTIME::init_library(argc, argv);
         Parser parser;
         parser.parse_args(argc, argv);
-        VGL_Graph graph;
+        VGL_Graph graph(parser.format);
         prepare_graph(graph, parser);
         VerticesArray<float> page_ranks(graph);
         const double perf = parser.fused ? PageRank::hip_fused(graph, page_ranks, parser.get_number_of_rounds())
@@ -20,6 +20,7 @@ int main(int argc, char **argv)
             for (size_t i = 0; i < ref.size(); i++) diff += std::fabs((double)ref[i] - got[i]);
             std::cout << "error count: " << (diff / ref.size() < 1e-4 ? 0 : 1) << std::endl;
         }
+        page_ranks.reorder(ORIGINAL);
         dump_array(parser.dump, page_ranks.to_host());
         VGL_RUNTIME::finalize_library();
     } catch (std::string error) { std::cout << error << std::endl; return 1; }

@@ -7,14 +7,14 @@ int main(int argc, char **argv)
         VGL_RUNTIME::init_library(argc, argv);
         Parser parser;
         parser.parse_args(argc, argv);
-        VGL_Graph graph;
+        VGL_Graph graph(parser.format);
         prepare_graph(graph, parser);
         VerticesArray<float> distances(graph, SCATTER);
         EdgesArray<float> weights(graph);
         weights.set_all_random(MAX_WEIGHT);
         double avg_perf = 0;
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {
-            const int source_vertex = parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(SCATTER, i);
+            const int source_vertex = graph.reorder(parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
             const double perf = parser.fused ? ShortestPaths::hip_fused(graph, weights, distances, source_vertex)
                                              : ShortestPaths::vgl_dijkstra_all_active_push(graph, weights, distances, source_vertex);
             avg_perf += perf / parser.get_number_of_rounds();
@@ -23,6 +23,7 @@ int main(int argc, char **argv)
                 verify_results(distances.to_host(), seq_dijkstra(h, weights.outgoing_to_host(), source_vertex));
             }
         }
+        distances.reorder(ORIGINAL);
         dump_array(parser.dump, distances.to_host());
         report_performance(avg_perf);
         VGL_RUNTIME::finalize_library();

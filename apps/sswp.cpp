@@ -8,14 +8,14 @@ int main(int argc, char **argv)
         VGL_RUNTIME::init_library(argc, argv);
         Parser parser;
         parser.parse_args(argc, argv);
-        VGL_Graph graph;
+        VGL_Graph graph(parser.format);
         prepare_graph(graph, parser);
         VerticesArray<float> widths(graph, SCATTER);
         EdgesArray<float> capacities(graph);
         capacities.set_all_random(MAX_WEIGHT);
         double avg_perf = 0;
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {
-            const int source_vertex = parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(SCATTER, i);
+            const int source_vertex = graph.reorder(parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
             const double perf = parser.fused ? WidestPaths::hip_fused(graph, capacities, widths, source_vertex)
                                              : WidestPaths::vgl_dijkstra(graph, capacities, widths, source_vertex);
             avg_perf += perf / parser.get_number_of_rounds();
@@ -24,6 +24,7 @@ int main(int argc, char **argv)
                 verify_results(widths.to_host(), seq_widest_paths(h, capacities.outgoing_to_host(), source_vertex));
             }
         }
+        widths.reorder(ORIGINAL);
         dump_array(parser.dump, widths.to_host());
         report_performance(avg_perf);
         VGL_RUNTIME::finalize_library();

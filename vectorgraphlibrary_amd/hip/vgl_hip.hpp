@@ -185,18 +185,34 @@ private:
 // ------------------------------------------------------------------------------------------------------------------
 struct vgl_csr_view { const long long *rowptr; const int *adj; long long edges; };
 
+// CSR_GRAPH: vertices keep their ids (csr/csr_graph.h).  VECTOR_CSR_GRAPH: vertices are renumbered by degree, largest first, ties by
+// id (the VectCSR order of vect_csr/import.hpp:61-99) before the CSR build -- here ONE numbering by total degree shared by both
+// directions (the reference sorts the outgoing and the incoming graph separately and permutes arrays in change_traversal_direction);
+// the padded vector extension of the reference format is not materialised, the edge-tile kernels do not need it.
+enum GraphStorageFormat { CSR_GRAPH = 0, VECTOR_CSR_GRAPH = 1 };
+
+template <class T>
+__global__ void vgl_k_permute_values(int n, const int *idx, const T *in, T *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[idx[i]];
+}
+
 class VGL_Graph {
+    GraphStorageFormat format = CSR_GRAPH;
+    int32_t *d_fwd = nullptr, *d_bwd = nullptr;             // VECTOR_CSR_GRAPH: original -> stored id, stored -> original id (device)
+    std::vector<int> h_fwd, h_bwd;
     int vertices_count = 0; long long edges_count = 0;
     int64_t *out_rowptr = nullptr, *in_rowptr = nullptr, *out_perm = nullptr, *in_perm = nullptr;
     int32_t *out_adj = nullptr, *in_adj = nullptr;
     vgl_hip_graph *handle = nullptr;
     std::vector<long long> host_out_rowptr;
 public:
-    VGL_Graph() {}
+    explicit VGL_Graph(GraphStorageFormat f = CSR_GRAPH) : format(f) {}
     ~VGL_Graph()
     {
         if (handle) vgl_hip_graph_destroy(VGL_RUNTIME::ctx(), handle);
-        for (void *p : {(void *)out_rowptr, (void *)in_rowptr, (void *)out_perm, (void *)in_perm, (void *)out_adj, (void *)in_adj})
+        for (void *p : {(void *)out_rowptr, (void *)in_rowptr, (void *)out_perm, (void *)in_perm, (void *)out_adj, (void *)in_adj, (void *)d_fwd,
+                        (void *)d_bwd})
             MemoryAPI::free_device_array((char *)p);
     }
     VGL_Graph(const VGL_Graph &) = delete;
@@ -209,13 +225,27 @@ public:
         MemoryAPI::allocate_device_array(&out_adj, (size_t)E); MemoryAPI::allocate_device_array(&in_adj, (size_t)E);
         MemoryAPI::allocate_device_array(&out_perm, (size_t)E); MemoryAPI::allocate_device_array(&in_perm, (size_t)E);
         int64_t kept = 0;
-        VGL_HIP_CALL(vgl_hip_coo_to_csr(c, V, E, ec.get_src_ids(), ec.get_dst_ids(), 0, V, out_rowptr, out_adj, out_perm, &kept));
+        const int32_t *src_ids = ec.get_src_ids(), *dst_ids = ec.get_dst_ids();
+        int32_t *rs = nullptr, *rd = nullptr;
+        if (format == VECTOR_CSR_GRAPH) {       // renumber, then build exactly as for CSR_GRAPH (edge positions still map to INPUT edges)
+            MemoryAPI::allocate_device_array(&d_fwd, (size_t)V); MemoryAPI::allocate_device_array(&d_bwd, (size_t)V);
+            VGL_HIP_CALL(vgl_hip_degree_order(c, V, E, src_ids, dst_ids, 2, d_fwd, d_bwd));
+            MemoryAPI::allocate_device_array(&rs, (size_t)std::max<long long>(E, 1)); MemoryAPI::allocate_device_array(&rd, (size_t)std::max<long long>(E, 1));
+            VGL_HIP_CALL(vgl_hip_relabel_i32(c, E, d_fwd, src_ids, rs));
+            VGL_HIP_CALL(vgl_hip_relabel_i32(c, E, d_fwd, dst_ids, rd));
+            src_ids = rs; dst_ids = rd;
+            h_fwd.resize((size_t)V); h_bwd.resize((size_t)V);
+            VGL_HIP_CALL(vgl_hip_memcpy_d2h(c, h_fwd.data(), d_fwd, sizeof(int) * (size_t)V));
+            VGL_HIP_CALL(vgl_hip_memcpy_d2h(c, h_bwd.data(), d_bwd, sizeof(int) * (size_t)V));
+        }
+        VGL_HIP_CALL(vgl_hip_coo_to_csr(c, V, E, src_ids, dst_ids, 0, V, out_rowptr, out_adj, out_perm, &kept));
         // the incoming container is built from the OUT-CSR-ordered list transposed (vgl_graph.hpp:61-64): src := adjacency, dst := row
         int32_t *csr_src = nullptr;
         MemoryAPI::allocate_device_array(&csr_src, (size_t)E);
-        VGL_HIP_CALL(vgl_hip_gather_u32(c, E, out_perm, ec.get_src_ids(), csr_src));
+        VGL_HIP_CALL(vgl_hip_gather_u32(c, E, out_perm, src_ids, csr_src));
         VGL_HIP_CALL(vgl_hip_coo_to_csr(c, V, E, out_adj, csr_src, 0, V, in_rowptr, in_adj, in_perm, &kept));
         MemoryAPI::free_device_array(csr_src);
+        MemoryAPI::free_device_array(rs); MemoryAPI::free_device_array(rd);
         VGL_HIP_CALL(vgl_hip_graph_create(c, V, 0, V, out_rowptr, out_adj, E, in_rowptr, in_adj, E, &handle));
         host_out_rowptr.resize((size_t)V + 1);
         VGL_HIP_CALL(vgl_hip_memcpy_d2h(c, host_out_rowptr.data(), out_rowptr, sizeof(long long) * ((size_t)V + 1)));
@@ -230,16 +260,28 @@ public:
     }
     const int64_t *get_outgoing_edges_reorder_indexes() const { return out_perm; }   // CSR position -> input edge
     const int64_t *get_incoming_edges_reorder_indexes() const { return in_perm; }    // in-CSR position -> out-CSR position
-    int reorder(int v, TraversalDirection, TraversalDirection) const { return v; }  // identity numbering (CSR_GRAPH)
-    int get_outgoing_connections_count(int v) const { return (int)(host_out_rowptr[v + 1] - host_out_rowptr[v]); }
-    // deterministic stand-in for select_random_nz_vertex (vgl_graph get_api): k-th draw of a fixed stream
+    GraphStorageFormat get_format() const { return format; }
+    bool is_renumbered() const { return format == VECTOR_CSR_GRAPH; }
+    const int32_t *get_forward_conversion() const { return d_fwd; }      // device, original -> stored
+    const int32_t *get_backward_conversion() const { return d_bwd; }     // device, stored -> original
+    // VGL_Graph::reorder(v, from, to) (vgl_graph get_api): SCATTER and GATHER share one numbering here
+    int reorder(int v, TraversalDirection from, TraversalDirection to) const
+    {
+        if (!is_renumbered() || (from == ORIGINAL) == (to == ORIGINAL)) return v;
+        return from == ORIGINAL ? h_fwd[(size_t)v] : h_bwd[(size_t)v];
+    }
+    int get_outgoing_connections_count(int v) const { return (int)(host_out_rowptr[v + 1] - host_out_rowptr[v]); }   // v in stored numbering
+    // deterministic stand-in for select_random_nz_vertex (vgl_graph get_api): k-th draw of a fixed stream; the result is an ORIGINAL
+    // vertex id with outgoing edges (the same vertex whatever the storage format)
     int select_random_nz_vertex(TraversalDirection = ORIGINAL, unsigned long long draw = 0) const
     {
         unsigned long long x = 0x9E3779B97F4A7C15ULL * (draw + 1) + GraphGenerationAPI::seed();
         x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 29;
         int v = (int)(x % (unsigned long long)vertices_count);
-        for (int i = 0; i < vertices_count; i++, v = (v + 1) % vertices_count)
-            if (host_out_rowptr[v + 1] > host_out_rowptr[v]) return v;
+        for (int i = 0; i < vertices_count; i++, v = (v + 1) % vertices_count) {
+            const int s = reorder(v, ORIGINAL, SCATTER);
+            if (host_out_rowptr[s + 1] > host_out_rowptr[s]) return v;
+        }
         throw "select_random_nz_vertex: graph has no edges";
     }
 };
@@ -251,11 +293,12 @@ public:
 template <typename _T>
 class VerticesArray {
     _T *vertices_data = nullptr; int vertices_count = 0; bool is_copy = false; TraversalDirection direction = SCATTER;
+    VGL_Graph *graph_ptr = nullptr;
 public:
-    VerticesArray(VGL_Graph &g, TraversalDirection d = SCATTER) : vertices_count(g.get_vertices_count()), direction(d)
+    VerticesArray(VGL_Graph &g, TraversalDirection d = SCATTER) : vertices_count(g.get_vertices_count()), direction(d), graph_ptr(&g)
     { MemoryAPI::allocate_device_array(&vertices_data, (size_t)vertices_count); }
     __host__ __device__ VerticesArray(const VerticesArray &o)
-        : vertices_data(o.vertices_data), vertices_count(o.vertices_count), is_copy(true), direction(o.direction) {}
+        : vertices_data(o.vertices_data), vertices_count(o.vertices_count), is_copy(true), direction(o.direction), graph_ptr(o.graph_ptr) {}
     __host__ __device__ ~VerticesArray()
     {
 #ifndef __HIP_DEVICE_COMPILE__
@@ -269,7 +312,39 @@ public:
     int size() const { return vertices_count; }
     TraversalDirection get_direction() const { return direction; }
     void set_direction(TraversalDirection d) { direction = d; }
-    void reorder(TraversalDirection) {}                                   // identity numbering
+    // VerticesArray::reorder (vertices_array.hpp): values move between the stored numbering (SCATTER == GATHER here) and ORIGINAL
+    void reorder(TraversalDirection to)
+    {
+        const bool from_orig = direction == ORIGINAL, to_orig = to == ORIGINAL;
+        if (graph_ptr && graph_ptr->is_renumbered() && from_orig != to_orig && vertices_count > 0) {
+            _T *tmp = nullptr;
+            MemoryAPI::allocate_device_array(&tmp, (size_t)vertices_count);
+            // to ORIGINAL: out[orig] = data[fwd[orig]];  back: out[stored] = data[bwd[stored]]
+            const int *idx = to_orig ? graph_ptr->get_forward_conversion() : graph_ptr->get_backward_conversion();
+            hipLaunchKernelGGL(vgl_k_permute_values<_T>, dim3((unsigned)std::min(8192, (vertices_count + 255) / 256)), dim3(256), 0, VGL_RUNTIME::stream(),
+                               vertices_count, idx, (const _T *)vertices_data, tmp);
+            VGL_HIP_RT(hipGetLastError());
+            VGL_HIP_RT(hipMemcpyAsync(vertices_data, tmp, sizeof(_T) * (size_t)vertices_count, hipMemcpyDeviceToDevice, VGL_RUNTIME::stream()));
+            VGL_RUNTIME::sync();
+            MemoryAPI::free_device_array(tmp);
+        }
+        direction = to;
+    }
+    // component labels (vertex ids of the stored numbering, smallest member per component) -> smallest ORIGINAL id per component
+    void reorder_labels_to_original()
+    {
+        static_assert(sizeof(_T) == 4, "labels are 32-bit vertex ids");
+        if (graph_ptr && graph_ptr->is_renumbered() && direction != ORIGINAL && vertices_count > 0) {
+            int32_t *scratch = nullptr, *out = nullptr;
+            MemoryAPI::allocate_device_array(&scratch, (size_t)vertices_count); MemoryAPI::allocate_device_array(&out, (size_t)vertices_count);
+            VGL_HIP_CALL(vgl_hip_cc_labels_to_original(VGL_RUNTIME::ctx(), vertices_count, (const int32_t *)vertices_data, graph_ptr->get_forward_conversion(),
+                                                       graph_ptr->get_backward_conversion(), scratch, out));
+            VGL_HIP_RT(hipMemcpyAsync(vertices_data, out, sizeof(_T) * (size_t)vertices_count, hipMemcpyDeviceToDevice, VGL_RUNTIME::stream()));
+            VGL_RUNTIME::sync();
+            MemoryAPI::free_device_array(scratch); MemoryAPI::free_device_array(out);
+        }
+        direction = ORIGINAL;
+    }
     void set_all_constant(_T v)
     {
         std::vector<_T> h((size_t)vertices_count, v);
@@ -443,7 +518,7 @@ class GraphAbstractionsHIP {
 
     void set_correct_direction() {}
     template <typename _T, typename... Types>
-    void set_correct_direction(_T &first, Types &...rest) { first.set_direction(current_traversal_direction); first.reorder(current_traversal_direction); set_correct_direction(rest...); }
+    void set_correct_direction(_T &first, Types &...rest) { first.reorder(current_traversal_direction); first.set_direction(current_traversal_direction); set_correct_direction(rest...); }
 
     template <class Op>
     void vertex_pass(VGL_Graph &g, VGL_Frontier &f, TraversalDirection dir, Op &&op)
