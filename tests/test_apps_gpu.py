@@ -182,3 +182,22 @@ def test_apps_vector_csr_format(app, mode, tmp_path, oracle, ctx):
         V = len(rowptr) - 1
         assert np.max(np.abs(got[:V] - auth) / np.maximum(np.abs(auth), 1e-300)) < 1e-9
         assert np.max(np.abs(got[V:] - hub) / np.maximum(np.abs(hub), 1e-300)) < 1e-9
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,ef,seed", CASES + [("rmat", 14, 16, 9)])
+def test_coloring_app(kind, scale, ef, seed, fmt, tmp_path, oracle, ctx):
+    """greedy speculative colouring (f1 widening) entirely on the generic operator path -- sparse frontiers, vertex post-ops, 64-bit
+    vertex arrays, reduce<int>, generate_new_frontier.  The result is order-dependent (in the reference too): the test checks that
+    it is a PROPER colouring of the symmetrised graph with no more colours than the largest degree + 1."""
+    O = oracle
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed, symmetric=True)
+    out, dump = run_app("coloring", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-format", fmt, "-check"], tmp_path)
+    assert "error count: 0" in out
+    colors = np.fromfile(dump, np.int32)                       # ORIGINAL numbering
+    V = len(rowptr) - 1
+    assert colors.shape == (V,) and (colors >= 0).all()
+    u = np.repeat(np.arange(V), np.diff(rowptr))
+    proper = (colors[u] != colors[adj]) | (u == adj)
+    assert proper.all(), f"{int((~proper).sum())} edges join vertices of one colour"
+    assert colors.max() <= int(np.diff(rowptr).max())
