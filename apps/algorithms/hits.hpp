@@ -1,45 +1,43 @@
-// HITS against the operator API: the call sequence of HITS::vgl_hits (algorithms/hits/hits.hpp:5-100) -- gather with a vertex
-// pre-op that zeroes the accumulator and an edge-op that adds (VGL_SRC_ID_ADD = atomicAdd, as in the reference's GPU flavour,
-// architecture_independent_api.h), reduce<double> of the squares, compute to normalise, then the same in the scatter direction.
-// The f64 atomics make the last bits of this version order-dependent (like the reference's GPU variant); the fused path
-// (vgl_hip_hits_run) keeps the sequential per-vertex order.
+// HITS on the operator API.  The primitives and their order are those of HITS::vgl_hits (algorithms/hits/hits.hpp:5-100): per
+// step, in the GATHER direction authorities are rebuilt from the hubs of the in-neighbours (vertex pre-op zeroes, edge-op adds with
+// VGL_SRC_ID_ADD = atomicAdd as in the reference's GPU flavour), reduce<double> of the squares + compute normalise; then the same in
+// the SCATTER direction for the hubs.  The two halves differ only in the direction and in which array is read / written, so they
+// share one helper here.  The f64 atomics make the last bits of this version order-dependent (like the reference's GPU variant);
+// the fused path (vgl_hip_hits_run) keeps the sequential per-vertex order.
 #pragma once
 
 struct HITS {
+    // target[v] = sum over v's neighbours (in the current traversal direction) of source[neighbour], then target /= ||target||_2
+    template <typename _T, typename Advance>
+    static void half_step(VGL_GRAPH_ABSTRACTIONS &api, VGL_Graph &graph, VGL_FRONTIER &all, VerticesArray<_T> &target, VerticesArray<_T> &source,
+                          Advance &&advance)
+    {
+        auto zero = [target] __VGL_ADVANCE_PREPROCESS_ARGS__ { target[src_id] = 0.0; };
+        auto accumulate = [target, source] __VGL_ADVANCE_ARGS__ { VGL_SRC_ID_ADD(target[src_id], source[dst_id]); };
+        advance(accumulate, zero);
+        const _T norm = sqrt(api.template reduce<_T>(graph, all, [target] __VGL_REDUCE_DBL_ARGS__ { return target[src_id] * target[src_id]; }, REDUCE_SUM));
+        api.compute(graph, all, [target, norm] __VGL_COMPUTE_ARGS__ { target[src_id] /= norm; });
+    }
+
     template <typename _T>
     static double vgl_hits(VGL_Graph &graph, VerticesArray<_T> &auth, VerticesArray<_T> &hub, int num_steps)
     {
-        VGL_GRAPH_ABSTRACTIONS graph_API(graph);
-        VGL_FRONTIER frontier(graph);
-        graph_API.change_traversal_direction(GATHER, hub, auth, frontier);
-        frontier.set_all_active();
+        VGL_GRAPH_ABSTRACTIONS api(graph);
+        VGL_FRONTIER all(graph);
+        api.change_traversal_direction(GATHER, hub, auth, all);
+        all.set_all_active();
         Timer tm;
         tm.start();
-        auto init_op = [auth, hub] __VGL_COMPUTE_ARGS__ {
-            auth[src_id] = 1;
-            hub[src_id] = 1;
-        };
-        graph_API.compute(graph, frontier, init_op);
+        api.compute(graph, all, [auth, hub] __VGL_COMPUTE_ARGS__ { auth[src_id] = 1; hub[src_id] = 1; });
         for (int step = 0; step < num_steps; step++) {
-            graph_API.change_traversal_direction(GATHER, hub, auth, frontier);
-            auto update_auth_op_preprocess = [auth] __VGL_ADVANCE_PREPROCESS_ARGS__ { auth[src_id] = 0.0; };
-            auto update_auth_op = [auth, hub] __VGL_ADVANCE_ARGS__ { VGL_SRC_ID_ADD(auth[src_id], hub[dst_id]); };
-            graph_API.gather(graph, frontier, update_auth_op, update_auth_op_preprocess, EMPTY_VERTEX_OP,
-                             update_auth_op, update_auth_op_preprocess, EMPTY_VERTEX_OP);
-            auto reduce_auth_op = [auth] __VGL_REDUCE_DBL_ARGS__ { return auth[src_id] * auth[src_id]; };
-            _T norm = sqrt(graph_API.reduce<_T>(graph, frontier, reduce_auth_op, REDUCE_SUM));
-            auto normalize_auth_op = [auth, norm] __VGL_COMPUTE_ARGS__ { auth[src_id] /= norm; };
-            graph_API.compute(graph, frontier, normalize_auth_op);
-
-            graph_API.change_traversal_direction(SCATTER, hub, auth, frontier);
-            auto update_hub_op_preprocess = [hub] __VGL_ADVANCE_PREPROCESS_ARGS__ { hub[src_id] = 0.0; };
-            auto update_hub_op = [hub, auth] __VGL_ADVANCE_ARGS__ { VGL_SRC_ID_ADD(hub[src_id], auth[dst_id]); };
-            graph_API.scatter(graph, frontier, update_hub_op, update_hub_op_preprocess, EMPTY_VERTEX_OP,
-                              update_hub_op, update_hub_op_preprocess, EMPTY_VERTEX_OP);
-            auto reduce_hub_op = [hub] __VGL_REDUCE_DBL_ARGS__ { return hub[src_id] * hub[src_id]; };
-            norm = sqrt(graph_API.reduce<_T>(graph, frontier, reduce_hub_op, REDUCE_SUM));
-            auto normalize_hub_op = [hub, norm] __VGL_COMPUTE_ARGS__ { hub[src_id] /= norm; };
-            graph_API.compute(graph, frontier, normalize_hub_op);
+            api.change_traversal_direction(GATHER, hub, auth, all);
+            half_step(api, graph, all, auth, hub, [&](auto &edge_op, auto &pre_op) {
+                api.gather(graph, all, edge_op, pre_op, EMPTY_VERTEX_OP, edge_op, pre_op, EMPTY_VERTEX_OP);
+            });
+            api.change_traversal_direction(SCATTER, hub, auth, all);
+            half_step(api, graph, all, hub, auth, [&](auto &edge_op, auto &pre_op) {
+                api.scatter(graph, all, edge_op, pre_op, EMPTY_VERTEX_OP, edge_op, pre_op, EMPTY_VERTEX_OP);
+            });
         }
         tm.end();
         performance_stats.print_algorithm_performance_stats("VGL HITS (operator API)", tm.get_time(), graph.get_edges_count());
