@@ -1,5 +1,5 @@
 // Top-down BFS written against the operator API exactly as a VGL user would (same call sequence as the reference's
-// BFS::vgl_top_down, algorithms/bfs/bfs.hpp:6-90): compute(init) -> [scatter(edge_op) -> generate_new_frontier(filter)]*.
+// BFS::vgl_top_down, algorithms/bfs/bfs.hpp:6-90): compute(init) -> [scatter(discover) -> generate_new_frontier(filter)]*.
 #pragma once
 #define UNVISITED_VERTEX -1
 #define FIRST_LEVEL_VERTEX 1
@@ -8,29 +8,29 @@ struct BFS {
     template <typename _T>
     static double vgl_top_down(VGL_Graph &graph, VerticesArray<_T> &levels, int source_vertex)
     {
-        VGL_GRAPH_ABSTRACTIONS graph_API(graph);
-        VGL_FRONTIER frontier(graph);
-        graph_API.change_traversal_direction(SCATTER, levels, frontier);
+        VGL_GRAPH_ABSTRACTIONS api(graph);
+        VGL_FRONTIER front(graph);
+        api.change_traversal_direction(SCATTER, levels, front);
         Timer tm;
         tm.start();
-        auto init_levels = [levels, source_vertex] __VGL_COMPUTE_ARGS__ {
+        auto mark_source = [levels, source_vertex] __VGL_COMPUTE_ARGS__ {
             levels[src_id] = (src_id == source_vertex) ? FIRST_LEVEL_VERTEX : UNVISITED_VERTEX;
         };
-        frontier.set_all_active();
-        graph_API.compute(graph, frontier, init_levels);
-        frontier.clear();
-        frontier.add_vertex(source_vertex);
-        int current_level = FIRST_LEVEL_VERTEX;
-        while (frontier.size() > 0) {
-            auto edge_op = [levels, current_level] __VGL_SCATTER_ARGS__ {
-                if (levels[src_id] == current_level && levels[dst_id] == UNVISITED_VERTEX) levels[dst_id] = current_level + 1;
+        front.set_all_active();
+        api.compute(graph, front, mark_source);
+        front.clear();
+        front.add_vertex(source_vertex);
+        int cur = FIRST_LEVEL_VERTEX;
+        while (front.size() > 0) {
+            auto discover = [levels, cur] __VGL_SCATTER_ARGS__ {
+                if (levels[src_id] == cur && levels[dst_id] == UNVISITED_VERTEX) levels[dst_id] = cur + 1;
             };
-            graph_API.scatter(graph, frontier, edge_op);
-            auto on_next_level = [levels, current_level] __VGL_GNF_ARGS__ {
-                return levels[src_id] == current_level + 1 ? IN_FRONTIER_FLAG : NOT_IN_FRONTIER_FLAG;
+            api.scatter(graph, front, discover);
+            auto just_found = [levels, cur] __VGL_GNF_ARGS__ {
+                return levels[src_id] == cur + 1 ? IN_FRONTIER_FLAG : NOT_IN_FRONTIER_FLAG;
             };
-            graph_API.generate_new_frontier(graph, frontier, on_next_level);
-            current_level++;
+            api.generate_new_frontier(graph, front, just_found);
+            cur++;
         }
         tm.end();
         performance_stats.print_algorithm_performance_stats("BFS Top-down (operator API)", tm.get_time(), graph.get_edges_count());

@@ -6,34 +6,34 @@ struct ConnectedComponents {
     template <typename _T>
     static double vgl_shiloach_vishkin(VGL_Graph &graph, VerticesArray<_T> &components)
     {
-        VGL_GRAPH_ABSTRACTIONS graph_API(graph);
-        VGL_FRONTIER frontier(graph);
-        graph_API.change_traversal_direction(SCATTER, components, frontier);
+        VGL_GRAPH_ABSTRACTIONS api(graph);
+        VGL_FRONTIER all(graph);
+        api.change_traversal_direction(SCATTER, components, all);
         Timer tm;
         tm.start();
-        frontier.set_all_active();
-        auto init_components_op = [components] __VGL_COMPUTE_ARGS__ { components[src_id] = src_id; };
-        graph_API.compute(graph, frontier, init_components_op);
+        all.set_all_active();
+        auto own_id = [components] __VGL_COMPUTE_ARGS__ { components[src_id] = src_id; };
+        api.compute(graph, all, own_id);
         int *flags;
         MemoryAPI::allocate_array(&flags, 2);
-        int *hook_changes = flags, *jump_changes = flags + 1;
+        int *hooked = flags, *jumped = flags + 1;
         do {
-            hook_changes[0] = 0;
-            auto edge_op = [components, hook_changes] __VGL_SCATTER_ARGS__ {
-                const int src_val = components[src_id];
-                if (src_val < components[dst_id]) { atomicMin(&components[dst_id], src_val); hook_changes[0] = 1; }
+            hooked[0] = 0;
+            auto hook = [components, hooked] __VGL_SCATTER_ARGS__ {
+                const int label = components[src_id];
+                if (label < components[dst_id]) { atomicMin(&components[dst_id], label); hooked[0] = 1; }
             };
-            graph_API.scatter(graph, frontier, edge_op);
+            api.scatter(graph, all, hook);
             do {
-                jump_changes[0] = 0;
-                auto jump_op = [components, jump_changes] __VGL_COMPUTE_ARGS__ {
-                    const int src_val = components[src_id];
-                    const int src_src_val = components[src_val];
-                    if (src_val != src_src_val) { components[src_id] = src_src_val; jump_changes[0] = 1; }
+                jumped[0] = 0;
+                auto shortcut = [components, jumped] __VGL_COMPUTE_ARGS__ {
+                    const int label = components[src_id];
+                    const int grand = components[label];
+                    if (label != grand) { components[src_id] = grand; jumped[0] = 1; }
                 };
-                graph_API.compute(graph, frontier, jump_op);
-            } while (jump_changes[0]);
-        } while (hook_changes[0]);
+                api.compute(graph, all, shortcut);
+            } while (jumped[0]);
+        } while (hooked[0]);
         MemoryAPI::free_array(flags);
         tm.end();
         performance_stats.print_algorithm_performance_stats("CC (Shiloach-Vishkin, operator API)", tm.get_time(), graph.get_edges_count());
