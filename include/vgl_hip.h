@@ -168,6 +168,9 @@ int vgl_hip_sssp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights,
  * width[dst] = max(width[dst], min(width[src], capacity)) to the fixed point.  Same kernel and modes as vgl_hip_sssp_run with the
  * (max, min) path algebra; only min / max of the inputs occur, so the result is bit-identical to the reference (and to its
  * sequential checker, seq_widest_paths.hpp:5-64).  d_capacities is indexed like the outgoing CSR (global_edge_pos). */
+/* super-step pieces of the widest-path algorithm for shards (exchange between steps: allreduce(MAX) of the widths) */
+int vgl_hip_sswp_init(vgl_hip_ctx *ctx, int32_t V, int32_t source, float *d_widths);
+int vgl_hip_sswp_relax_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capacities, float *d_widths, int *changed);
 int vgl_hip_sswp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capacities, int32_t source, int mode,
                      float *d_widths, vgl_hip_sssp_stats *stats);
 

@@ -114,6 +114,17 @@ class NumpyShardOps:
         np.minimum.at(dv, self.ed[live], cand)
         return int((before != dv).any())
 
+    def sswp_init(self, wd, source):
+        wd.fill_(0.0); wd[source] = float(FLT_MAX)
+
+    def sswp_relax(self, wd):
+        wv = wd.numpy()
+        live = wv[self.es] > 0
+        cand = np.minimum(wv[self.es][live], self.ew[live]).astype(np.float32)
+        before = wv.copy()
+        np.maximum.at(wv, self.ed[live], cand)
+        return int((before != wv).any())
+
     def cc_init(self, comp): comp.copy_(torch.arange(self.V, dtype=torch.int32))
 
     def cc_hook(self, comp):
@@ -187,6 +198,8 @@ def _worker(rank, world, port, results):
     levels_2p_td, _ = vd.bfs_sharded(eq, source, equal_ranges=True, two_phase=True)          # top-down only: every level two-phase
     assert (levels_2p_td.numpy() == levels.numpy()).all()
     d, _ = vd.sssp_sharded(ops, source)
+    wd, _ = vd.sswp_sharded(ops, source)
+    assert (wd.numpy().view(np.int32) == O.sswp_bellman_ford(rowptr, adj, w, source)[0].view(np.int32)).all(), "sharded SSWP != oracle"
     comp, _ = vd.cc_sharded(ops)
     ranks = vd.page_rank_sharded(ops, 3, bounds[rank], bounds[rank + 1])
     ok = [(levels.numpy() == O.bfs_top_down(rowptr, adj, source)[0]).all(),

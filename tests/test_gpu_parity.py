@@ -311,6 +311,20 @@ def test_sharded_super_steps_single_process(ctx, oracle):
     dref, _ = O.sssp_bellman_ford(rowptr, adj, O.gen_weights(len(hs), 21)[perm], source)
     assert (reps[0].cpu().numpy().view(np.int32) == dref.view(np.int32)).all()
 
+    # SSWP: relax owned rows, elementwise max across replicas
+    reps = [o.new_f32() for o in ops]
+    for o, r in zip(ops, reps):
+        o.sswp_init(r, source)
+    while True:
+        ch = [o.sswp_relax(r) for o, r in zip(ops, reps)]
+        m = torch.stack(reps).max(dim=0).values
+        for r in reps:
+            r.copy_(m)
+        if not any(ch):
+            break
+    wref, _ = O.sswp_bellman_ford(rowptr, adj, O.gen_weights(len(hs), 21)[perm], source)
+    assert (reps[0].cpu().numpy().view(np.int32) == wref.view(np.int32)).all()
+
     # CC (directed labels) and PageRank with owned-slice exchange
     reps = [o.new_i32() for o in ops]
     for o, r in zip(ops, reps):

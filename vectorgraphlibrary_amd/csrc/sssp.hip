@@ -197,6 +197,25 @@ int vgl_hip_sswp_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_capacities
     return vgl_path_run<vgl_path_widest>(c, g, d_capacities, source, mode, d_widths, stats, "sswp_run");
 }
 
+int vgl_hip_sswp_init(vgl_hip_ctx *c, int32_t V, int32_t source, float *d_widths)
+{
+    if (!c || !d_widths) VGL_FAIL("sswp_init: null argument");
+    if (source < 0 || source >= V) VGL_FAIL("sswp_init: source vertex out of range");
+    hipLaunchKernelGGL(vgl_k_sssp_init<vgl_path_widest>, dim3(vgl_grid1(V)), dim3(VGL_BLOCK), 0, c->stream, V, source, d_widths, (int32_t *)nullptr);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int vgl_hip_sswp_relax_owned(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_capacities, float *d_widths, int *changed)
+{
+    if (!c || !g || !d_capacities || !d_widths) VGL_FAIL("sswp_relax_owned: null argument");
+    VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
+    VGL_TRY(vgl_sssp_launch<vgl_path_widest>(c, g, d_capacities, d_widths, false, 1));
+    VGL_TRY(vgl_read_counters(c));
+    if (changed) *changed = (int)c->h_counters[C_CHANGED];
+    return 0;
+}
+
 int vgl_hip_sssp_relax_owned(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, float *d_dist, int *changed)
 {
     if (!c || !g || !d_weights || !d_dist) VGL_FAIL("sssp_relax_owned: null argument");

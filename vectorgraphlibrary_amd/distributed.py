@@ -91,6 +91,14 @@ class HipShardOps:
         _l.check(self.L.vgl_hip_sssp_relax_owned(self.ctx.h, self.g.h, _ptr(self.weights), _ptr(d), C.byref(ch)))
         return ch.value
 
+    def sswp_init(self, wd, source):
+        _l.check(self.L.vgl_hip_sswp_init(self.ctx.h, self.V, int(source), _ptr(wd)))
+
+    def sswp_relax(self, wd):
+        ch = C.c_int()
+        _l.check(self.L.vgl_hip_sswp_relax_owned(self.ctx.h, self.g.h, _ptr(self.weights), _ptr(wd), C.byref(ch)))
+        return ch.value
+
     def cc_init(self, comp):
         _l.check(self.L.vgl_hip_cc_init(self.ctx.h, self.V, _ptr(comp)))
 
@@ -293,6 +301,27 @@ def sssp_sharded(ops, source, group=None):
         if not changed:
             break
     return d, iters
+
+
+def sswp_sharded(ops, source, group=None):
+    """single-source widest paths over edge-cut shards: every rank relaxes its owned rows, the widths are merged with allreduce(MAX)
+    (the exchange of SSWP::vgl_dijkstra under MPI would be EXCHANGE_ALL with a max op, like shortest_paths.hpp:136-141 with min)"""
+    P, _ = _world(group)
+    wd = ops.new_f32()
+    ops.sswp_init(wd, source)
+    iters = 0
+    while True:
+        changed = ops.sswp_relax(wd)
+        iters += 1
+        if P > 1:
+            ops.sync()
+            dist.all_reduce(wd, op=dist.ReduceOp.MAX, group=group)
+            flag = ops.scalar([changed])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            changed = int(flag.item())
+        if not changed:
+            break
+    return wd, iters
 
 
 def cc_sharded(ops, group=None):

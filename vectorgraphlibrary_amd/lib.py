@@ -102,6 +102,8 @@ _SIGNATURES = {
     "vgl_hip_bfs_apply_bitmaps": [_p, _i32, _int, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_sssp_init": [_p, _i32, _i32, _p],
     "vgl_hip_sssp_relax_owned": [_p, _p, _p, _p, C.POINTER(_int)],
+    "vgl_hip_sswp_init": [_p, _i32, _i32, _p],
+    "vgl_hip_sswp_relax_owned": [_p, _p, _p, _p, C.POINTER(_int)],
     "vgl_hip_cc_init": [_p, _i32, _p],
     "vgl_hip_cc_hook_owned": [_p, _p, _p, C.POINTER(_int)],
     "vgl_hip_cc_jump": [_p, _i32, _p],
