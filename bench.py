@@ -213,7 +213,32 @@ def main():
             plan.close()
             extra["sssp"] = res
             extra["sssp_value_teps"] = res["delta_stepping"]["teps"]
+            # widest paths (f1 widening): same graph, the weights as capacities
+            api.sswp(g, w, sources[0], raw=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            wst = [api.sswp(g, w, s, raw=True)[1] for s in sources[args.warmup:args.warmup + 3]]
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / len(wst)
+            extra["sswp"] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "super_steps": wst[0]["iterations"]}
             del w
+
+        # ---- HITS (f64) and SCC on the same graph (f1 widening) ----
+        if not args.no_pr_cc:
+            api.hits(g, 1, raw=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            api.hits(g, 5, raw=True)
+            torch.cuda.synchronize()
+            dth = (time.perf_counter() - t1) / 5
+            extra["hits"] = {"teps": round(2 * E / dth, 1), "ms_per_step": round(dth * 1e3, 3), "edge_sweeps_per_step": 2, "dtype": "f64"}
+            api.strongly_connected_components(g, raw=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, sst = api.strongly_connected_components(g, raw=True)
+            torch.cuda.synchronize()
+            dtsc = time.perf_counter() - t1
+            extra["scc"] = {"teps": round(E / dtsc, 1), "ms": round(dtsc * 1e3, 3), **sst}
 
         # ---- CPU baseline: the oracle's OpenMP port of the reference top-down BFS, same graph, host cores ----
         if not args.no_cpu_baseline:
