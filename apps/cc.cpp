@@ -10,7 +10,7 @@ int main(int argc, char **argv)
         VGL_Graph graph(parser.format);
         prepare_graph(graph, parser, UNDIRECTED_GRAPH);
         VerticesArray<int> components(graph, SCATTER);
-        const bool symmetric = parser.import_file.empty();      // generated UNDIRECTED_GRAPH inputs hold both directions of every edge
+        const bool symmetric = parser.compute_mode == Parser::GENERATE_NEW_GRAPH;      // generated UNDIRECTED_GRAPH inputs hold both directions of every edge
         auto run = [&]() { return parser.fused ? ConnectedComponents::hip_fused(graph, components, symmetric)
                                                : ConnectedComponents::vgl_shiloach_vishkin(graph, components); };
         run();                                   // heat run

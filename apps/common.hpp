@@ -16,7 +16,8 @@ struct Parser {
     bool rmat = true, check = false, direction_optimising = false, fused = false;
     GraphStorageFormat format = CSR_GRAPH;      // -format csr | vcsr (VECTOR_CSR_GRAPH: degree-renumbered, the reference's default)
     unsigned long long seed = 1;
-    std::string dump, import_file;
+    std::string dump, graph_file_name;
+    enum ComputeMode { GENERATE_NEW_GRAPH, LOAD_GRAPH_FROM_FILE, IMPORT_EDGES_CONTAINER } compute_mode = GENERATE_NEW_GRAPH;   // cmd_parser.hpp:58-68
     void parse_args(int argc, char **argv)
     {
         for (int i = 1; i < argc; i++) {
@@ -30,11 +31,16 @@ struct Parser {
             else if (a == "-seed") seed = strtoull(next(), nullptr, 10);
             else if (a == "-dump") dump = next();
             else if (a == "-source") source = atoi(next());
-            else if (a == "-import") import_file = next();          // .el_container written by the reference's create_vgl_graphs
+            else if (a == "-import") { graph_file_name = next(); compute_mode = IMPORT_EDGES_CONTAINER; }     // .el_container
+            else if (a == "-load" || a == "-file" || a == "-f") { graph_file_name = next(); compute_mode = LOAD_GRAPH_FROM_FILE; }   // .csr / .vcsr graph file
+            else if (a == "-gen" || a == "-generate") compute_mode = GENERATE_NEW_GRAPH;
             else if (a == "-do") direction_optimising = true;
             else if (a == "-td") direction_optimising = false;
             else if (a == "-fused") fused = true;
-            else if (a == "-format") { const std::string f = next(); format = (f == "vcsr" || f == "vect_csr") ? VECTOR_CSR_GRAPH : CSR_GRAPH; }
+            else if (a == "-format") {
+                const std::string f = next();
+                format = (f == "vcsr" || f == "vect_csr") ? VECTOR_CSR_GRAPH : f == "el_container" ? EDGES_CONTAINER : CSR_GRAPH;
+            }
             else if (a == "-push" || a == "-all-active") {}
             else throw "unknown command line option";
         }
@@ -47,8 +53,12 @@ inline void prepare_graph(VGL_Graph &graph, const Parser &p, DirectionType dir =
 {
     GraphGenerationAPI::seed() = p.seed;
     EdgesContainer ec;
-    if (!p.import_file.empty()) {
-        if (!ec.load_from_binary_file(p.import_file)) throw "Error: can not open the graph file given with -import";
+    if (p.compute_mode == Parser::LOAD_GRAPH_FROM_FILE) {              // vgl_runtime.hpp:52-60
+        if (!graph.load_from_binary_file(p.graph_file_name)) throw "Error: graph file not found";
+        return;
+    }
+    if (p.compute_mode == Parser::IMPORT_EDGES_CONTAINER) {            // vgl_runtime.hpp:61-75
+        if (!ec.load_from_binary_file(p.graph_file_name)) throw "Error: edges container file not found";
         graph.import(ec);
         return;
     }

@@ -18,6 +18,7 @@
 // numbering (CSR_GRAPH), so reorder() is the identity and every direction shares one vertex numbering.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
@@ -89,6 +90,7 @@ public:
     void start() { VGL_RUNTIME::sync(); t0 = std::chrono::steady_clock::now(); }
     void end() { VGL_RUNTIME::sync(); t1 = std::chrono::steady_clock::now(); }
     double get_time() const { return std::chrono::duration<double>(t1 - t0).count(); }
+    void print_time_stats(const std::string &name) const { std::cout << name << " time: " << get_time() * 1000.0 << " ms" << std::endl; }   // timer.hpp
 };
 struct PerformanceStats {                     // performance_stats.hpp:248-275
     double get_algorithm_performance(double t, long long edges) const { return edges / (t * 1e6); }   // MTEPS
@@ -189,7 +191,72 @@ struct vgl_csr_view { const long long *rowptr; const int *adj; long long edges; 
 // id (the VectCSR order of vect_csr/import.hpp:61-99) before the CSR build -- here ONE numbering by total degree shared by both
 // directions (the reference sorts the outgoing and the incoming graph separately and permutes arrays in change_traversal_direction);
 // the padded vector extension of the reference format is not materialised, the edge-tile kernels do not need it.
-enum GraphStorageFormat { CSR_GRAPH = 0, VECTOR_CSR_GRAPH = 1 };
+// the enumerators keep the reference's values (framework_types.h:49-57): they are written into graph files
+enum GraphStorageFormat { VECTOR_CSR_GRAPH = 1, CSR_GRAPH = 3, EDGES_CONTAINER = 4 };
+
+inline std::string get_graph_extension(GraphStorageFormat f)           // framework_types.h:87-101
+{ return f == VECTOR_CSR_GRAPH ? ".vcsr" : f == CSR_GRAPH ? ".csr" : f == EDGES_CONTAINER ? ".el_container" : ".unknown"; }
+inline std::string add_extension(const std::string &short_name, GraphStorageFormat f) { return short_name + get_graph_extension(f); }
+
+// one direction of a graph file on the host (csr_graph.hpp:73-104, vect_csr_graph.hpp:141-181)
+struct vgl_file_container {
+    std::vector<long long> rowptr, perm; std::vector<int> adj, fwd, bwd;
+    void write(FILE *f, int V, long long E, GraphStorageFormat fmt) const
+    {
+        const int type = (int)fmt;
+        fwrite(&V, sizeof(int), 1, f); fwrite(&E, sizeof(long long), 1, f); fwrite(&type, sizeof(int), 1, f);
+        fwrite(rowptr.data(), sizeof(long long), (size_t)V + 1, f); fwrite(adj.data(), sizeof(int), (size_t)E, f);
+        if (fmt == VECTOR_CSR_GRAPH) { fwrite(fwd.data(), sizeof(int), (size_t)V, f); fwrite(bwd.data(), sizeof(int), (size_t)V, f); }
+        fwrite(perm.data(), sizeof(long long), (size_t)E, f);
+    }
+    bool read(FILE *f, int V, long long E, GraphStorageFormat fmt)
+    {
+        int v = 0, type = 0; long long e = 0;
+        if (fread(&v, sizeof(int), 1, f) != 1 || fread(&e, sizeof(long long), 1, f) != 1 || fread(&type, sizeof(int), 1, f) != 1) return false;
+        if (v != V || e != E || type != (int)fmt) throw "Error in VGL_Graph::load_from_binary_file : container header does not match the file header";
+        rowptr.resize((size_t)V + 1); adj.resize((size_t)E); perm.resize((size_t)E);
+        bool ok = fread(rowptr.data(), sizeof(long long), (size_t)V + 1, f) == (size_t)V + 1 && fread(adj.data(), sizeof(int), (size_t)E, f) == (size_t)E;
+        if (ok && fmt == VECTOR_CSR_GRAPH) {
+            fwd.resize((size_t)V); bwd.resize((size_t)V);
+            ok = fread(fwd.data(), sizeof(int), (size_t)V, f) == (size_t)V && fread(bwd.data(), sizeof(int), (size_t)V, f) == (size_t)V;
+        }
+        ok = ok && fread(perm.data(), sizeof(long long), (size_t)E, f) == (size_t)E;
+        if (!ok) return false;
+        // the kernels trust these arrays: refuse a file whose offsets or ids leave their ranges
+        if (rowptr[0] != 0 || rowptr[(size_t)V] != E) throw "Error in VGL_Graph::load_from_binary_file : corrupt vertex pointers";
+        for (int i = 0; i < V; i++) if (rowptr[(size_t)i + 1] < rowptr[(size_t)i]) throw "Error in VGL_Graph::load_from_binary_file : corrupt vertex pointers";
+        for (long long i = 0; i < E; i++)
+            if (adj[(size_t)i] < 0 || adj[(size_t)i] >= V || perm[(size_t)i] < 0 || perm[(size_t)i] >= E) throw "Error in VGL_Graph::load_from_binary_file : id out of range";
+        for (size_t i = 0; i < fwd.size(); i++)
+            if (fwd[i] < 0 || fwd[i] >= V || bwd[i] < 0 || bwd[i] >= V || bwd[(size_t)fwd[i]] != (int)i) throw "Error in VGL_Graph::load_from_binary_file : corrupt conversion arrays";
+        return true;
+    }
+    // the VectCSR container of an edge list (vect_csr/import.hpp:61-99,257-337): vertices renumbered by THIS direction's degree
+    // (largest first, stable), edges stably sorted by renumbered source; src / dst are left in that order (original ids), as the
+    // reference leaves its EdgesContainer
+    void build_vect_csr(int V, std::vector<int> &src, std::vector<int> &dst)
+    {
+        const size_t E = src.size();
+        std::vector<int> deg((size_t)V, 0);
+        for (size_t i = 0; i < E; i++) deg[(size_t)src[i]]++;
+        bwd.resize((size_t)V); fwd.resize((size_t)V);
+        for (int i = 0; i < V; i++) bwd[(size_t)i] = i;
+        std::stable_sort(bwd.begin(), bwd.end(), [&](int a, int b) { return deg[(size_t)a] > deg[(size_t)b]; });
+        for (int i = 0; i < V; i++) fwd[(size_t)bwd[(size_t)i]] = i;
+        rowptr.assign((size_t)V + 1, 0);
+        for (size_t i = 0; i < E; i++) rowptr[(size_t)fwd[(size_t)src[i]] + 1]++;
+        for (int i = 0; i < V; i++) rowptr[(size_t)i + 1] += rowptr[(size_t)i];
+        std::vector<long long> cursor(rowptr.begin(), rowptr.end() - 1);
+        perm.resize(E); adj.resize(E);
+        for (size_t i = 0; i < E; i++) {                     // counting sort == stable sort by renumbered source
+            const long long p = cursor[(size_t)fwd[(size_t)src[i]]]++;
+            perm[(size_t)p] = (long long)i; adj[(size_t)p] = fwd[(size_t)dst[i]];
+        }
+        std::vector<int> s2(E), d2(E);
+        for (size_t p = 0; p < E; p++) { s2[p] = src[(size_t)perm[p]]; d2[p] = dst[(size_t)perm[p]]; }
+        src.swap(s2); dst.swap(d2);
+    }
+};
 
 template <class T>
 __global__ void vgl_k_permute_values(int n, const int *idx, const T *in, T *out)
@@ -208,16 +275,113 @@ class VGL_Graph {
     std::vector<long long> host_out_rowptr;
 public:
     explicit VGL_Graph(GraphStorageFormat f = CSR_GRAPH) : format(f) {}
-    ~VGL_Graph()
+    ~VGL_Graph() { release(); }
+    VGL_Graph(const VGL_Graph &) = delete;
+private:
+    void release()
     {
         if (handle) vgl_hip_graph_destroy(VGL_RUNTIME::ctx(), handle);
         for (void *p : {(void *)out_rowptr, (void *)in_rowptr, (void *)out_perm, (void *)in_perm, (void *)out_adj, (void *)in_adj, (void *)d_fwd,
                         (void *)d_bwd})
             MemoryAPI::free_device_array((char *)p);
+        handle = nullptr; out_rowptr = in_rowptr = out_perm = in_perm = nullptr; out_adj = in_adj = nullptr; d_fwd = d_bwd = nullptr;
+        h_fwd.clear(); h_bwd.clear();
     }
-    VGL_Graph(const VGL_Graph &) = delete;
+    template <class T> static T *upload(const std::vector<T> &h)
+    {
+        T *d = nullptr;
+        MemoryAPI::allocate_device_array(&d, std::max<size_t>(h.size(), 1));
+        if (!h.empty()) VGL_HIP_CALL(vgl_hip_memcpy_h2d(VGL_RUNTIME::ctx(), d, h.data(), h.size() * sizeof(T)));
+        return d;
+    }
+    template <class T, class D> static std::vector<T> download(const D *d, size_t n)
+    {
+        static_assert(sizeof(T) == sizeof(D), "download: element size");
+        std::vector<T> h(n);
+        if (n) VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h.data(), d, n * sizeof(T)));
+        return h;
+    }
+public:
+    // Graph files of the reference (VGL_Graph::save_to_binary_file / load_from_binary_file, vgl_graph.hpp:109-161): header, outgoing
+    // container, incoming container.  `.csr` files are this class's arrays as they are.  `.vcsr` files carry one degree numbering PER
+    // DIRECTION; this class keeps one numbering for both, so saving rebuilds the two containers on the host from the stored graph
+    // (the result is the file the reference writes for the same edge list, byte for byte) and loading adopts the outgoing
+    // container's numbering and re-expresses the incoming container in it (rows permuted, ids mapped, adjacency order kept).
+    bool save_to_binary_file(const std::string &file_name)
+    {
+        if (!handle) throw "Error in VGL_Graph::save_to_binary_file : the graph is empty";
+        const int V = vertices_count; const long long E = edges_count;
+        vgl_file_container out, in;
+        out.rowptr = download<long long>(out_rowptr, (size_t)V + 1); out.adj = download<int>(out_adj, (size_t)E);
+        out.perm = download<long long>(out_perm, (size_t)E);
+        if (format == CSR_GRAPH) {
+            in.rowptr = download<long long>(in_rowptr, (size_t)V + 1); in.adj = download<int>(in_adj, (size_t)E);
+            in.perm = download<long long>(in_perm, (size_t)E);
+        } else {
+            std::vector<int> src((size_t)E), dst((size_t)E);             // the imported edge list: original ids, input order
+            for (int r = 0; r < V; r++)
+                for (long long p = out.rowptr[(size_t)r]; p < out.rowptr[(size_t)r + 1]; p++) {
+                    src[(size_t)out.perm[(size_t)p]] = h_bwd[(size_t)r]; dst[(size_t)out.perm[(size_t)p]] = h_bwd[(size_t)out.adj[(size_t)p]];
+                }
+            out.build_vect_csr(V, src, dst);
+            src.swap(dst);                                               // EdgesContainer::transpose (vgl_graph.hpp:62)
+            in.build_vect_csr(V, src, dst);
+        }
+        FILE *f = fopen(file_name.c_str(), "wb");
+        if (!f) return false;
+        const int type = (int)format;
+        fwrite(&V, sizeof(int), 1, f); fwrite(&E, sizeof(long long), 1, f); fwrite(&type, sizeof(int), 1, f);
+        out.write(f, V, E, format); in.write(f, V, E, format);
+        return fclose(f) == 0;
+    }
+    bool load_from_binary_file(const std::string &file_name)
+    {
+        FILE *f = fopen(file_name.c_str(), "rb");
+        if (!f) return false;
+        int V = 0, type = 0; long long E = 0;
+        if (fread(&V, sizeof(int), 1, f) != 1 || fread(&E, sizeof(long long), 1, f) != 1 || fread(&type, sizeof(int), 1, f) != 1) { fclose(f); return false; }
+        if ((type != (int)CSR_GRAPH && type != (int)VECTOR_CSR_GRAPH) || V <= 0 || E < 0) {
+            fclose(f); throw "Error in VGL_Graph::load_from_binary_file : unsupported container type in the graph file";
+        }
+        const GraphStorageFormat fmt = (GraphStorageFormat)type;
+        vgl_file_container out, in;
+        bool ok = false;
+        try { ok = out.read(f, V, E, fmt) && in.read(f, V, E, fmt); } catch (...) { fclose(f); throw; }
+        fclose(f);
+        if (!ok) return false;
+        if (fmt != format) std::cout << "Warning! changing container type to the one of the graph file" << std::endl;    // vgl_graph.hpp:147-151
+        release();
+        format = fmt; vertices_count = V; edges_count = E;
+        if (fmt == VECTOR_CSR_GRAPH) {
+            // stored numbering := the outgoing container's; incoming row of stored vertex s = the file's row fwd_in[bwd_out[s]]
+            std::vector<int> to_out((size_t)V);                           // incoming-numbering id -> stored id
+            for (int x = 0; x < V; x++) to_out[(size_t)x] = out.fwd[(size_t)in.bwd[(size_t)x]];
+            vgl_file_container t;
+            t.rowptr.assign((size_t)V + 1, 0); t.adj.resize((size_t)E); t.perm.resize((size_t)E);
+            for (int s = 0; s < V; s++) {
+                const int r = in.fwd[(size_t)out.bwd[(size_t)s]];
+                t.rowptr[(size_t)s + 1] = t.rowptr[(size_t)s] + (in.rowptr[(size_t)r + 1] - in.rowptr[(size_t)r]);
+            }
+            for (int s = 0; s < V; s++) {
+                const int r = in.fwd[(size_t)out.bwd[(size_t)s]];
+                long long q = t.rowptr[(size_t)s];
+                for (long long p = in.rowptr[(size_t)r]; p < in.rowptr[(size_t)r + 1]; p++, q++) {
+                    t.adj[(size_t)q] = to_out[(size_t)in.adj[(size_t)p]]; t.perm[(size_t)q] = in.perm[(size_t)p];
+                }
+            }
+            in.rowptr.swap(t.rowptr); in.adj.swap(t.adj); in.perm.swap(t.perm);
+            h_fwd = out.fwd; h_bwd = out.bwd;
+            d_fwd = upload(h_fwd); d_bwd = upload(h_bwd);
+        }
+        out_rowptr = (int64_t *)upload(out.rowptr); out_adj = upload(out.adj); out_perm = (int64_t *)upload(out.perm);
+        in_rowptr = (int64_t *)upload(in.rowptr); in_adj = upload(in.adj); in_perm = (int64_t *)upload(in.perm);
+        VGL_HIP_CALL(vgl_hip_graph_create(VGL_RUNTIME::ctx(), V, 0, V, out_rowptr, out_adj, E, in_rowptr, in_adj, E, &handle));
+        host_out_rowptr = out.rowptr;
+        return true;
+    }
     void import(EdgesContainer &ec)
     {
+        release();
         vgl_hip_ctx *c = VGL_RUNTIME::ctx();
         const int V = ec.get_vertices_count(); const long long E = ec.get_edges_count();
         vertices_count = V; edges_count = E;
