@@ -201,3 +201,21 @@ def test_coloring_app(kind, scale, ef, seed, fmt, tmp_path, oracle, ctx):
     proper = (colors[u] != colors[adj]) | (u == adj)
     assert proper.all(), f"{int((~proper).sum())} edges join vertices of one colour"
     assert colors.max() <= int(np.diff(rowptr).max())
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,ef,seed", [("rmat", 12, 16, 3), ("ru", 11, 1, 5), ("ru", 11, 2, 5), ("ru", 10, 2, 9)])
+def test_tc_app(kind, scale, ef, seed, fmt, tmp_path, oracle, ctx):
+    """transitive-closure queries (algorithms/tc/tc.hpp): Purdom's algorithm (SCC + condensation, REDUCE_MAX, copy_if_indexes, an
+    EdgesArray written in scatter) against one oracle BFS per distinct source; the app's own -check runs BFS per source on the device"""
+    O = oracle
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
+    out, dump = run_app("tc", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 96, "-check", "-format", fmt], tmp_path)
+    assert "error count: 0" in out and "condensation:" in out
+    t = np.fromfile(dump, np.int32).reshape(-1, 3)
+    assert len(t) == 96 and ((t[:, :2] >= 0) & (t[:, :2] < (1 << scale))).all()
+    for s in np.unique(t[:, 0]):
+        levels = O.bfs_top_down(rowptr, adj, int(s))[0]
+        rows = t[t[:, 0] == s]
+        assert np.array_equal(rows[:, 2] != 0, levels[rows[:, 1]] != -1), int(s)
+    assert 0 < t[:, 2].sum() < len(t) or ef != 2              # uniform graphs of out-degree 2 give both answers

@@ -41,6 +41,7 @@
 #define __VGL_ADVANCE_PREPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
 #define __VGL_ADVANCE_POSTPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
 #define __VGL_GNF_ARGS__ __device__ (int src_id, int connections_count)->int
+#define __VGL_COPY_IF_INDEXES_ARGS__ __device__ (long long idx)->int
 #define __VGL_REDUCE_ANY_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
 #define __VGL_REDUCE_INT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->int
 #define __VGL_REDUCE_FLT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->float
@@ -263,6 +264,70 @@ __global__ void vgl_k_permute_values(int n, const int *idx, const T *in, T *out)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[idx[i]];
 }
+
+template <class T>
+__global__ void vgl_k_fill_values(long long n, T v, T *out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = v;
+}
+
+// ParallelPrimitives::copy_if_indexes (vgl_compute_api/common/copy_if: indexes i in [0, size) with cond(i) > 0, in ascending order):
+// per-workgroup counts, a scan of the (at most 4096) counts on the host, ordered writes with wave ballots
+template <class Cond>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_copy_if_count(long long n, long long chunk, Cond cond, long long *counts)
+{
+    __shared__ long long s[VGL_BLOCK / 64];
+    const long long lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    long long mine = 0;
+    for (long long i = lo + threadIdx.x; i < hi; i += VGL_BLOCK) mine += cond(i) > 0;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long t = 0; for (int w = 0; w < VGL_BLOCK / 64; w++) t += s[w]; counts[blockIdx.x] = t; }
+}
+template <class Cond>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_copy_if_write(long long n, long long chunk, Cond cond, const long long *offsets, long long *out)
+{
+    __shared__ int wave_cnt[VGL_BLOCK / 64];
+    const long long lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    long long base = offsets[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long start = lo; start < hi; start += VGL_BLOCK) {          // every thread of the workgroup runs every trip
+        const long long i = start + threadIdx.x;
+        const bool keep = i < hi && cond(i) > 0;
+        const unsigned long long ballot = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(ballot);
+        __syncthreads();
+        long long before = 0; int total = 0;
+        for (int w = 0; w < VGL_BLOCK / 64; w++) { if (w < wave) before += wave_cnt[w]; total += wave_cnt[w]; }
+        if (keep) out[base + before + __popcll(ballot & ((1ULL << lane) - 1ULL))] = i;
+        base += total;
+        __syncthreads();
+    }
+}
+struct ParallelPrimitives {
+    template <class Cond>
+    static long long copy_if_indexes(Cond cond, long long *out_indexes, long long size)
+    {
+        if (size <= 0) return 0;
+        const int nb = (int)std::min<long long>(4096, (size + VGL_BLOCK - 1) / VGL_BLOCK);
+        const long long chunk = ((size + nb - 1) / nb + VGL_BLOCK - 1) / VGL_BLOCK * VGL_BLOCK;
+        long long *d_counts = nullptr;
+        MemoryAPI::allocate_device_array(&d_counts, (size_t)nb);
+        hipLaunchKernelGGL((vgl_k_copy_if_count<Cond>), dim3(nb), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), size, chunk, cond, d_counts);
+        VGL_HIP_RT(hipGetLastError());
+        std::vector<long long> h((size_t)nb);
+        VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h.data(), d_counts, sizeof(long long) * h.size()));
+        long long total = 0;
+        for (auto &x : h) { const long long c = x; x = total; total += c; }
+        VGL_HIP_CALL(vgl_hip_memcpy_h2d(VGL_RUNTIME::ctx(), d_counts, h.data(), sizeof(long long) * h.size()));
+        if (total > 0) hipLaunchKernelGGL((vgl_k_copy_if_write<Cond>), dim3(nb), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), size, chunk, cond, d_counts, out_indexes);
+        VGL_HIP_RT(hipGetLastError());
+        VGL_RUNTIME::sync();
+        MemoryAPI::free_device_array(d_counts);
+        return total;
+    }
+};
 
 class VGL_Graph {
     GraphStorageFormat format = CSR_GRAPH;
@@ -552,6 +617,14 @@ public:
         VGL_RUNTIME::sync();
         MemoryAPI::free_device_array(w_in);
     }
+    void set_all_constant(_T v)            // both halves (csr_edges_array.hpp)
+    {
+        hipLaunchKernelGGL(vgl_k_fill_values<_T>, dim3(1024), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), 2 * edges_count, v, edges_data);
+        VGL_HIP_RT(hipGetLastError());
+        VGL_RUNTIME::sync();
+    }
+    void finalize_advance() {}             // NEC-only merge of per-core copies (tc.hpp:77-78): nothing to do here
+    template <class Merge> void finalize_advance(Merge &&) {}
     std::vector<_T> outgoing_to_host() const
     {
         std::vector<_T> h((size_t)edges_count);
@@ -658,6 +731,20 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_reduce_values(int n, const lo
         out[i] = v;
     }
 }
+// REDUCE_MAX: maximum of the materialised values per workgroup (the host folds the 256 partial results)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_max_partials(int n, const double *values, double *partials)
+{
+    __shared__ double s[VGL_BLOCK / 64];
+    double m = 0.0;                                   // the reference's maximum starts from 0 (multicore/reduce.hpp:80)
+    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) m = values[i] > m ? values[i] : m;
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < VGL_BLOCK / 64; w++) m = s[w] > m ? s[w] : m;
+        partials[blockIdx.x] = m;
+    }
+}
 template <class Cond>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_filter_flags(int n, const long long *rowptr, Cond cond, int *flags)
 {
@@ -675,7 +762,7 @@ static const vgl_empty_edge_op EMPTY_EDGE_OP;
 // ------------------------------------------------------------------------------------------------------------------
 class GraphAbstractionsHIP {
     VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
-    double *reduce_buffer = nullptr;
+    double *reduce_buffer = nullptr, *reduce_partials = nullptr;
 
     static unsigned grid_for(long long n) { long long b = (n + VGL_BLOCK - 1) / VGL_BLOCK; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
     template <class T> static constexpr bool is_empty_vertex_op() { return std::is_same<typename std::decay<T>::type, vgl_empty_vertex_op>::value; }
@@ -732,8 +819,8 @@ class GraphAbstractionsHIP {
 
 public:
     GraphAbstractionsHIP(VGL_Graph &g, TraversalDirection initial = SCATTER) : processed_graph_ptr(&g), current_traversal_direction(initial)
-    { MemoryAPI::allocate_device_array(&reduce_buffer, (size_t)g.get_vertices_count()); }
-    ~GraphAbstractionsHIP() { MemoryAPI::free_device_array(reduce_buffer); }
+    { MemoryAPI::allocate_device_array(&reduce_buffer, (size_t)g.get_vertices_count()); MemoryAPI::allocate_device_array(&reduce_partials, 256); }
+    ~GraphAbstractionsHIP() { MemoryAPI::free_device_array(reduce_buffer); MemoryAPI::free_device_array(reduce_partials); }
 
     // change_traversal_direction (graph_abstractions.hpp:87-125): tags and permutes every passed container; with identity
     // numbering only the tag changes
@@ -779,7 +866,7 @@ public:
     template <typename _T, typename ReduceOperation>
     _T reduce(VGL_Graph &g, VGL_Frontier &f, ReduceOperation &&reduce_op, REDUCE_TYPE type)
     {
-        if (type != REDUCE_SUM) throw "VGL ERROR: only REDUCE_SUM is implemented (as in the reference, multicore/reduce.hpp:88-121)";
+        if (type != REDUCE_SUM && type != REDUCE_MAX) throw "Error in GraphAbstractionsHIP::reduce : unsupported reduce type";   // reduce.hpp:144-150
         const vgl_csr_view v = g.get_direction_view(current_traversal_direction);
         const FrontierSparsityType t = f.get_sparsity_type();
         hipStream_t st = VGL_RUNTIME::stream();
@@ -791,6 +878,16 @@ public:
         else { n = f.size(); if (n > 0) hipLaunchKernelGGL((vgl_k_reduce_values<2, R>), dim3(grid_for(n)), dim3(VGL_BLOCK), 0, st, n, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_buffer); }
         VGL_HIP_RT(hipGetLastError());
         double r = 0.0;
+        if (type == REDUCE_MAX) {                         // max(0, values of the active vertices), the reference's definition
+            if (n <= 0) return (_T)0;
+            constexpr int NP = 256;
+            hipLaunchKernelGGL(vgl_k_max_partials, dim3(NP), dim3(VGL_BLOCK), 0, st, n, reduce_buffer, reduce_partials);
+            VGL_HIP_RT(hipGetLastError());
+            double h[NP];
+            VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h, reduce_partials, sizeof(h)));
+            for (int i = 0; i < NP; i++) r = h[i] > r ? h[i] : r;
+            return (_T)r;
+        }
         VGL_HIP_CALL(vgl_hip_reduce_sum_f64_buffer(VGL_RUNTIME::ctx(), n, reduce_buffer, &r));
         return (_T)r;
     }
