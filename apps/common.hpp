@@ -12,7 +12,7 @@
 #include <queue>
 
 struct Parser {
-    int scale = 10, avg_degree = 5, rounds = 1, source = -1;
+    int scale = 10, avg_degree = 5, rounds = 1, source = -1, walk_vertices_percent = 1;
     bool rmat = true, check = false, direction_optimising = false, fused = false;
     GraphStorageFormat format = CSR_GRAPH;      // -format csr | vcsr (VECTOR_CSR_GRAPH: degree-renumbered, the reference's default)
     unsigned long long seed = 1;
@@ -34,6 +34,7 @@ struct Parser {
             else if (a == "-import") { graph_file_name = next(); compute_mode = IMPORT_EDGES_CONTAINER; }     // .el_container
             else if (a == "-load" || a == "-file" || a == "-f") { graph_file_name = next(); compute_mode = LOAD_GRAPH_FROM_FILE; }   // .csr / .vcsr graph file
             else if (a == "-gen" || a == "-generate") compute_mode = GENERATE_NEW_GRAPH;
+            else if (a == "-walk-vertices" || a == "-wv") walk_vertices_percent = atoi(next());     // cmd_parser.hpp:223-226
             else if (a == "-do") direction_optimising = true;
             else if (a == "-td") direction_optimising = false;
             else if (a == "-fused") fused = true;

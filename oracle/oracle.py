@@ -273,3 +273,33 @@ def write_el_container(path, V, src, dst):
         f.write(np.int32(4).tobytes())
         f.write(np.ascontiguousarray(src, np.int32).tobytes())
         f.write(np.ascontiguousarray(dst, np.int32).tobytes())
+
+
+def _rw_draw(seed, step, walk):
+    """counter-based draw of the random-walk app (apps/algorithms/rw.hpp RandomWalk::draw): splitmix64 finaliser, uint64 wrap-around"""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (np.asarray(step, np.uint64) + np.uint64(1)) \
+            + np.uint64(0xD1B54A32D192ED03) * (np.asarray(walk, np.uint64) + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def random_walk(rowptr, adj, seed, percent, length):
+    """algorithms/rw/random_walk.hpp:60-85 (seq_random_walk's loop) with the app's reproducible draws in place of rand():
+    walk vertices v (draw(seed, 2^64-1, v) % 100 < percent) start at themselves; per step every live walk moves to out-neighbour
+    number draw(seed, step, v) % degree of its current vertex, or to DEAD_END (-1) where the degree is 0.  Returns int32[V]."""
+    V = len(rowptr) - 1
+    ids = np.arange(V, dtype=np.uint64)
+    walkers = np.nonzero((_rw_draw(seed, np.uint64(0xFFFFFFFFFFFFFFFF), ids) % np.uint64(100)).astype(np.int64) < percent)[0]
+    cur = walkers.astype(np.int64)
+    for step in range(length):
+        live = cur >= 0
+        c = cur[live]
+        deg = rowptr[c + 1] - rowptr[c]
+        r = (_rw_draw(seed, np.uint64(step), walkers[live].astype(np.uint64)) % np.maximum(deg, 1).astype(np.uint64)).astype(np.int64)
+        nxt = np.where(deg > 0, adj[np.minimum(rowptr[c] + r, len(adj) - 1)], -1)
+        cur[live] = nxt
+    out = np.full(V, -1, np.int32)
+    out[walkers] = cur
+    return out

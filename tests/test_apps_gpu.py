@@ -219,3 +219,22 @@ def test_tc_app(kind, scale, ef, seed, fmt, tmp_path, oracle, ctx):
         rows = t[t[:, 0] == s]
         assert np.array_equal(rows[:, 2] != 0, levels[rows[:, 1]] != -1), int(s)
     assert 0 < t[:, 2].sum() < len(t) or ef != 2              # uniform graphs of out-degree 2 give both answers
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,ef,seed,percent,length", [("rmat", 12, 8, 3, 10, 7), ("ru", 11, 4, 5, 100, 12), ("ru", 10, 1, 9, 50, 3)])
+def test_rw_app(kind, scale, ef, seed, percent, length, fmt, tmp_path, oracle, ctx):
+    """random walks (algorithms/rw/random_walk.hpp) on compute() over a sparse frontier: identical to the CPU restatement under
+    both storage formats (the draws are keyed on ORIGINAL ids), every hop is an edge, walks stop at vertices without out-edges"""
+    O = oracle
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed, symmetric=True)
+    out, dump = run_app("rw", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-wv", percent, "-it", length, "-check", "-format", fmt], tmp_path)
+    assert "error count: 0" in out
+    got = np.fromfile(dump, np.int32)
+    ref = O.random_walk(rowptr, adj, seed, percent, length)
+    assert np.array_equal(got, ref)
+    walkers = np.nonzero(O.random_walk(rowptr, adj, seed, percent, 0) >= 0)[0]      # length 0: every walk vertex holds itself
+    assert abs(len(walkers) / (1 << scale) - percent / 100) < 0.05 or percent == 100
+    one = O.random_walk(rowptr, adj, seed, percent, 1)             # a single hop lands on a neighbour
+    w = np.nonzero(one >= 0)[0]
+    assert all(one[v] in adj[rowptr[v]:rowptr[v + 1]] for v in w[:200])
