@@ -12,8 +12,8 @@
 #include <queue>
 
 struct Parser {
-    int scale = 10, avg_degree = 5, rounds = 1, source = -1, walk_vertices_percent = 1;
-    bool rmat = true, check = false, direction_optimising = false, fused = false;
+    int scale = 10, avg_degree = 5, rounds = 1, source = -1, sink = -1, walk_vertices_percent = 1;
+    bool rmat = true, check = false, direction_optimising = false, fused = false, undirected = false;
     GraphStorageFormat format = CSR_GRAPH;      // -format csr | vcsr (VECTOR_CSR_GRAPH: degree-renumbered, the reference's default)
     unsigned long long seed = 1;
     std::string dump, graph_file_name;
@@ -31,6 +31,8 @@ struct Parser {
             else if (a == "-seed") seed = strtoull(next(), nullptr, 10);
             else if (a == "-dump") dump = next();
             else if (a == "-source") source = atoi(next());
+            else if (a == "-sink") sink = atoi(next());
+            else if (a == "-undirected") undirected = true;
             else if (a == "-import") { graph_file_name = next(); compute_mode = IMPORT_EDGES_CONTAINER; }     // .el_container
             else if (a == "-load" || a == "-file" || a == "-f") { graph_file_name = next(); compute_mode = LOAD_GRAPH_FROM_FILE; }   // .csr / .vcsr graph file
             else if (a == "-gen" || a == "-generate") compute_mode = GENERATE_NEW_GRAPH;
@@ -254,4 +256,41 @@ inline int equal_components(const std::vector<int> &a, const std::vector<int> &b
     }
     std::cout << "error count: " << errors << std::endl;
     return errors;
+}
+
+// sequential Ford-Fulkerson with the rules of apps/algorithms/mf.hpp (seq_mf.hpp:5-154 in spirit): level-synchronous search over
+// edges with positive residual, parent = smallest id among the previous level's vertices that reach a vertex; the value of u->v is
+// the first match in u's row, an augmentation updates every parallel u->v and every stored v->u
+inline int seq_ford_fulkerson(const HostCSR &h, int source, int sink, int capacity)
+{
+    std::vector<int> flow(h.adj.size(), capacity), parent((size_t)h.V), level((size_t)h.V);
+    int total = 0;
+    while (source != sink) {
+        std::fill(parent.begin(), parent.end(), 0x7FFFFFFF); std::fill(level.begin(), level.end(), -1);
+        level[(size_t)source] = 1;
+        std::vector<int> front{source}, next;
+        for (int cur = 1; !front.empty(); cur++, front.swap(next), next.clear())
+            for (int u : front)
+                for (long long p = h.rowptr[(size_t)u]; p < h.rowptr[(size_t)u + 1]; p++) {
+                    const int v = h.adj[(size_t)p];
+                    if (flow[(size_t)p] <= 0 || (level[(size_t)v] != -1 && level[(size_t)v] != cur + 1)) continue;
+                    if (level[(size_t)v] == -1) { level[(size_t)v] = cur + 1; next.push_back(v); }
+                    parent[(size_t)v] = std::min(parent[(size_t)v], u);
+                }
+        if (level[(size_t)sink] == -1) break;
+        int path_flow = 0x7FFFFFFF;
+        for (int v = sink; v != source; v = parent[(size_t)v]) {
+            const int u = parent[(size_t)v]; int w = 0;
+            for (long long p = h.rowptr[(size_t)u]; p < h.rowptr[(size_t)u + 1]; p++) if (h.adj[(size_t)p] == v) { w = flow[(size_t)p]; break; }
+            path_flow = std::min(path_flow, w);
+        }
+        if (path_flow <= 0) break;
+        for (int v = sink; v != source; v = parent[(size_t)v]) {
+            const int u = parent[(size_t)v];
+            for (long long p = h.rowptr[(size_t)u]; p < h.rowptr[(size_t)u + 1]; p++) if (h.adj[(size_t)p] == v) flow[(size_t)p] -= path_flow;
+            for (long long p = h.rowptr[(size_t)v]; p < h.rowptr[(size_t)v + 1]; p++) if (h.adj[(size_t)p] == u) flow[(size_t)p] += path_flow;
+        }
+        total += path_flow;
+    }
+    return total;
 }

@@ -303,3 +303,50 @@ def random_walk(rowptr, adj, seed, percent, length):
     out = np.full(V, -1, np.int32)
     out[walkers] = cur
     return out
+
+
+def max_flow_ford_fulkerson(rowptr, adj, source, sink, capacity=100):
+    """algorithms/mf/mf.hpp:67-128 + seq_mf.hpp:51-97 with the reproducible parent rule of apps/algorithms/mf.hpp: every stored edge
+    holds a residual value (initially `capacity`); level-synchronous search over positive edges, parent = smallest id among the
+    previous level's vertices reaching a vertex; bottleneck from the FIRST u->v match, update of ALL parallel u->v (minus) and ALL
+    stored v->u (plus).  Returns (flow value, number of augmentations).  On a symmetric graph the value is the maximum flow
+    (tests compare it with scipy.sparse.csgraph.maximum_flow)."""
+    V = len(rowptr) - 1
+    rowptr = np.asarray(rowptr, np.int64)
+    adj = np.asarray(adj, np.int64)
+    res = np.full(len(adj), capacity, np.int64)
+    deg = np.diff(rowptr)
+    total, rounds = 0, 0
+    while source != sink:
+        level = np.full(V, -1, np.int64)
+        parent = np.full(V, np.iinfo(np.int64).max, np.int64)
+        level[source] = 1
+        front = np.array([source], np.int64)
+        cur = 1
+        while front.size:
+            cnt = deg[front]
+            srcs = np.repeat(front, cnt)
+            pos = np.repeat(rowptr[front] - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(cnt.sum())
+            dsts = adj[pos]
+            ok = (res[pos] > 0) & (level[dsts] == -1)
+            np.minimum.at(parent, dsts[ok], srcs[ok])
+            front = np.unique(dsts[ok])
+            level[front] = cur + 1
+            cur += 1
+        if level[sink] == -1:
+            break
+        path = []
+        v = sink
+        while v != source:
+            u = int(parent[v])
+            path.append((u, v))
+            v = u
+        flow = min(int(res[rowptr[u] + np.nonzero(adj[rowptr[u]:rowptr[u + 1]] == v)[0][0]]) for u, v in path)
+        if flow <= 0:
+            break
+        for u, v in path:
+            res[rowptr[u] + np.nonzero(adj[rowptr[u]:rowptr[u + 1]] == v)[0]] -= flow
+            res[rowptr[v] + np.nonzero(adj[rowptr[v]:rowptr[v + 1]] == u)[0]] += flow
+        total += flow
+        rounds += 1
+    return total, rounds

@@ -238,3 +238,52 @@ def test_rw_app(kind, scale, ef, seed, percent, length, fmt, tmp_path, oracle, c
     one = O.random_walk(rowptr, adj, seed, percent, 1)             # a single hop lands on a neighbour
     w = np.nonzero(one >= 0)[0]
     assert all(one[v] in adj[rowptr[v]:rowptr[v + 1]] for v in w[:200])
+
+
+def scipy_max_flow(V, rowptr, adj, source, sink, capacity=100):
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import maximum_flow
+    rows = np.repeat(np.arange(V), np.diff(rowptr))
+    keep = rows != adj
+    m = sp.csr_matrix((np.ones(keep.sum(), np.int32), (rows[keep], adj[keep])), shape=(V, V))
+    m.data[:] = capacity                                   # parallel edges act as ONE edge (they are always updated together)
+    return int(maximum_flow(m.astype(np.int32), source, sink).flow_value)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,ef,seed", [("rmat", 10, 8, 3), ("ru", 10, 3, 5), ("ru", 9, 1, 9)])
+def test_mf_app_symmetric(kind, scale, ef, seed, fmt, tmp_path, oracle, ctx):
+    """maximum flow (algorithms/mf/mf.hpp) on symmetric inputs, where the reference's residual scheme is the textbook one: the app,
+    the CPU restatement and scipy's independent maximum_flow agree, for both storage formats"""
+    O = oracle
+    V = 1 << scale
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed, symmetric=True)
+    nz = np.nonzero(np.diff(rowptr))[0]
+    pairs = [(int(nz[(7 * k + 1) % len(nz)]), int(nz[(13 * k + 5) % len(nz)])) for k in range(3)]
+    hubs = np.argsort(-np.diff(rowptr), kind="stable")[:2]
+    pairs.append((int(hubs[0]), int(hubs[1])))                # many augmentations, residual edges actually used
+    for s, t in pairs:
+        out, dump = run_app("mf", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-undirected", "-source", s, "-sink", t, "-check", "-format", fmt], tmp_path)
+        assert "error count: 0" in out
+        got = np.fromfile(dump, np.int32)
+        assert tuple(got[:2]) == (s, t)
+        ref, rounds = O.max_flow_ford_fulkerson(rowptr, adj, s, t)
+        assert got[2] == ref == scipy_max_flow(V, rowptr, adj, s, t), (s, t, rounds)
+
+
+@pytest.mark.parametrize("kind,scale,ef,seed", [("rmat", 10, 8, 3), ("ru", 10, 3, 5)])
+def test_mf_app_directed(kind, scale, ef, seed, tmp_path, oracle, ctx):
+    """directed inputs: reverse residuals exist only where the graph stores the reverse edge, so the value depends on the paths taken;
+    with the smallest-id parent rule the device run reproduces the CPU restatement exactly (csr numbering) and never exceeds the
+    true maximum flow"""
+    O = oracle
+    V = 1 << scale
+    src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
+    nz = np.nonzero(np.diff(rowptr))[0]
+    for k in range(3):
+        s, t = int(nz[(5 * k + 2) % len(nz)]), int(nz[(11 * k + 7) % len(nz)])
+        out, dump = run_app("mf", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-source", s, "-sink", t, "-check"], tmp_path)
+        assert "error count: 0" in out
+        got = int(np.fromfile(dump, np.int32)[2])
+        assert got == O.max_flow_ford_fulkerson(rowptr, adj, s, t)[0]
+        assert got <= scipy_max_flow(V, rowptr, adj, s, t)
