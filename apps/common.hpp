@@ -13,7 +13,7 @@
 
 struct Parser {
     int scale = 10, avg_degree = 5, rounds = 1, source = -1, sink = -1, walk_vertices_percent = 1;
-    bool rmat = true, check = false, direction_optimising = false, fused = false, undirected = false;
+    bool rmat = true, check = false, direction_optimising = false, fused = false, undirected = false, bfs_based = false;
     GraphStorageFormat format = CSR_GRAPH;      // -format csr | vcsr (VECTOR_CSR_GRAPH: degree-renumbered, the reference's default)
     unsigned long long seed = 1;
     std::string dump, graph_file_name;
@@ -44,7 +44,10 @@ struct Parser {
                 const std::string f = next();
                 format = (f == "vcsr" || f == "vect_csr") ? VECTOR_CSR_GRAPH : f == "el_container" ? EDGES_CONTAINER : CSR_GRAPH;
             }
-            else if (a == "-push" || a == "-all-active") {}
+            else if (a == "-bfs-based") bfs_based = true;            // tc: one BFS per source instead of Purdom's; cc: accepted
+            else if (a == "-directed") undirected = false;
+            // algorithm selectors of the reference's harness (apps/scripts/settings.py:15-25) that name what this backend does anyway
+            else if (a == "-push" || a == "-pull" || a == "-all-active" || a == "-partial-active" || a == "-top-down" || a == "-cv" || a == "-purdoms") {}
             else throw "unknown command line option";
         }
     }

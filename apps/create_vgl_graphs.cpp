@@ -37,8 +37,9 @@ int main(int argc, char **argv)
             if (!edges_container.load_from_binary_file(in_name)) throw "Error: edges container file not found";
         } else {
             const int v = 1 << parser.scale;
-            if (parser.rmat) GraphGenerationAPI::R_MAT(edges_container, v, (long long)v * parser.avg_degree, 57, 19, 19, 5, DIRECTED_GRAPH);
-            else GraphGenerationAPI::random_uniform(edges_container, v, (long long)v * parser.avg_degree, DIRECTED_GRAPH);
+            const DirectionType dir = parser.undirected ? UNDIRECTED_GRAPH : DIRECTED_GRAPH;        // -undirected stores every edge both ways
+            if (parser.rmat) GraphGenerationAPI::R_MAT(edges_container, v, (long long)v * parser.avg_degree, 57, 19, 19, 5, dir);
+            else GraphGenerationAPI::random_uniform(edges_container, v, (long long)v * parser.avg_degree, dir);
         }
         tm.end();
         tm.print_time_stats(in_name.empty() ? "Generate" : "Load edges container");

@@ -21,10 +21,10 @@ int main(int argc, char **argv)
             vertex_pairs.push_back({graph.reorder(a, ORIGINAL, SCATTER), graph.reorder(b, ORIGINAL, SCATTER)});
         }
         std::vector<int> answer(vertex_pairs.size(), 0);
-        report_performance(TC::vgl_purdoms(graph, vertex_pairs, answer));
+        report_performance(parser.bfs_based ? TC::vgl_bfs_based(graph, vertex_pairs, answer) : TC::vgl_purdoms(graph, vertex_pairs, answer));
         if (parser.get_check_flag()) {
             std::vector<int> check_answer(vertex_pairs.size(), 0);
-            TC::vgl_bfs_based(graph, vertex_pairs, check_answer);
+            if (parser.bfs_based) TC::vgl_purdoms(graph, vertex_pairs, check_answer); else TC::vgl_bfs_based(graph, vertex_pairs, check_answer);
             verify_results(answer, check_answer);
         }
         std::vector<int> triples;

@@ -287,3 +287,17 @@ def test_mf_app_directed(kind, scale, ef, seed, tmp_path, oracle, ctx):
         got = int(np.fromfile(dump, np.int32)[2])
         assert got == O.max_flow_ford_fulkerson(rowptr, adj, s, t)[0]
         assert got <= scipy_max_flow(V, rowptr, adj, s, t)
+
+
+def test_run_tests_harness(tmp_path, ctx):
+    """apps/run_tests.py (the reference's apps/run_tests.py + scripts/*_api.py): prepares the graph set with create_vgl_graphs, runs
+    every app's argument sets in both storage formats, greps AVG_PERF / error count and exports JSON + CSV"""
+    import json
+    out = subprocess.run(["python", os.path.join(ROOT, "apps", "run_tests.py"), "-m", "smoke", "-a", "all", "-f", "csr,vcsr", "-b", "-v", "-t", "120",
+                          "-n", "harness_smoke"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    res = json.load(open(os.path.join(BIN, "harness_smoke.json")))
+    rows = res["rows"]
+    assert {r["app"] for r in rows} == {"bfs", "sssp", "pr", "cc", "sswp", "hits", "scc", "coloring", "rw", "tc", "mf"}
+    assert all(r["errors"] == 0 and isinstance(r["perf"], float) and r["perf"] > 0 for r in rows), [r for r in rows if r["errors"] != 0]
+    assert os.path.exists(os.path.join(BIN, "harness_smoke.csv")) and "VERIFIED 19 TESTS" in out.stdout
