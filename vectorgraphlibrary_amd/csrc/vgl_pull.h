@@ -143,8 +143,21 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32
             if (!hub) {
                 const int lo = (int)(max(seg_b, base) - base);
                 const int hi = (int)(min(seg_e, base + n) - base);
-                for (int i = lo; i < hi; i++)
-                    if (!SKIP_SELF || s_dst[i] != self) acc = vgl_add_rn(acc, s_val[i]);     // if(src_id != dst_id) rank += ... (pr.hpp:115-116)
+                // if(src_id != dst_id) rank += ... (pr.hpp:115-116).  Eight LDS reads are issued before the eight dependent adds: one
+                // element per trip waits for a full LDS round trip per add, and on degree-sorted graphs the first workgroups own 256
+                // rows of almost VGL_PULL_HUB_DEGREE edges each -- their chains are the launch's critical path below ~2^21 vertices
+                // (RMAT-18 degree-sorted: 2.26 -> 0.7 ms per PageRank iteration; handing rows of 128+ edges to the hub wavefronts
+                // instead made those the critical path: 20 % slower on unsorted graphs).
+                int i = lo;
+                for (; i + 8 <= hi; i += 8) {
+                    T v[8]; int32_t d[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { v[u] = s_val[i + u]; d[u] = SKIP_SELF ? s_dst[i + u] : -1; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const T t = vgl_add_rn(acc, v[u]); acc = (SKIP_SELF && d[u] == self) ? acc : t; }
+                }
+                for (; i < hi; i++)
+                    if (!SKIP_SELF || s_dst[i] != self) acc = vgl_add_rn(acc, s_val[i]);
             }
             base += n;
         }
