@@ -152,21 +152,32 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_count(int32_t nrows, int32
 // one workgroup: exclusive offsets of the per-tile counts, totals into counters[C_FRONT] = F, [C_NEIGH] = M, [C_TMP1] = rows with
 // heavy pending below T, and offs[F] = M.  (Doing this in the last workgroup of the count kernel was tried: with 8192 small
 // workgroups the per-workgroup arrival atomics cost more than this launch.)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_scan(int ntiles, const int32_t *vt_cnt, const int64_t *vt_deg, const int32_t *vt_aux,
-                                                           int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *counters, int64_t *offs)
+constexpr int VGL_DS_SCAN_THREADS = 1024;     // 16 wavefronts: 8 tiles per thread for the 8192 vertex tiles of a 2^24-vertex graph (256 threads: 36 us)
+__global__ __launch_bounds__(VGL_DS_SCAN_THREADS) void vgl_k_ds_scan(int ntiles, const int32_t *vt_cnt, const int64_t *vt_deg, const int32_t *vt_aux,
+                                                                     int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *counters, int64_t *offs)
 {
-    __shared__ int s32[VGL_WAVES];
-    __shared__ int64_t s64[VGL_WAVES];
-    const int per = (ntiles + VGL_BLOCK - 1) / VGL_BLOCK;
+    constexpr int NW = VGL_DS_SCAN_THREADS / 64;
+    __shared__ int s_c[NW], s_a[NW];
+    __shared__ int64_t s_d[NW];
+    const int per = (ntiles + VGL_DS_SCAN_THREADS - 1) / VGL_DS_SCAN_THREADS;
     const int lo = min(ntiles, (int)threadIdx.x * per), hi = min(ntiles, lo + per);
     int c = 0, a = 0;
     int64_t d = 0;
     for (int t = lo; t < hi; t++) { c += vt_cnt[t]; d += vt_deg[t]; a += vt_aux[t]; }
-    int ctot, atot;
-    int64_t dtot;
-    int cpre = vgl_block_excl_add(c, s32, &ctot);
-    int64_t dpre = vgl_block_excl_add(d, s64, &dtot);
-    (void)vgl_block_excl_add(a, s32, &atot);
+    const int ci = vgl_wave_incl_add(c), ai = vgl_wave_incl_add(a);
+    const int64_t di = vgl_wave_incl_add(d);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) { s_c[wave] = ci; s_a[wave] = ai; s_d[wave] = di; }
+    __syncthreads();
+    int cbase = 0, ctot = 0, atot = 0;
+    int64_t dbase = 0, dtot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        if (w < wave) { cbase += s_c[w]; dbase += s_d[w]; }
+        ctot += s_c[w]; dtot += s_d[w]; atot += s_a[w];
+    }
+    int cpre = cbase + ci - c;
+    int64_t dpre = dbase + di - d;
     for (int t = lo; t < hi; t++) {
         vt_cnt_off[t] = cpre; vt_deg_off[t] = dpre;
         cpre += vt_cnt[t]; dpre += vt_deg[t];
@@ -218,6 +229,83 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_write(int32_t nrows, int32
         const int32_t v0 = row_base + r0;
         if (nvalid == 8) *reinterpret_cast<uint64_t *>(state + v0) = st_new;
         else for (int j = 0; j < nvalid; j++) state[v0 + j] = (uint8_t)(st_new >> (8 * j));
+    }
+}
+
+// SMALL step: count + scan + write in one pass.  Workgroups that schedule rows reserve their slice of ids / offs with ONE packed
+// atomic (rows << 40 | edges), so both cursors advance together and offs stays ascending along ids; the order of the slices is
+// the order of arrival, which the relax does not care about (atomic minima).  Same-address atomics serialise (~12 ns each), so the
+// host only takes this path when it expects few scheduled rows; a wrong guess costs at most one atomic per vertex tile.
+constexpr int VGL_DS_EDGE_BITS = 40;
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_select(int32_t nrows, int32_t row_base, const int64_t *prow, uint8_t *state, const float *dist,
+                                                             uint8_t bit, float T, unsigned long long *cursor, int32_t *vt_aux, int32_t *ids,
+                                                             int64_t *offs)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    __shared__ int s32[VGL_WAVES];
+    __shared__ unsigned long long s_base;
+    const int32_t r0 = blockIdx.x * VGL_TILE + threadIdx.x * VGL_EPT;
+    uint32_t bits = 0, aux = 0;
+    int nvalid = 0;
+    int64_t degs[VGL_EPT], deg = 0;
+    uint64_t st8 = 0;
+    if (r0 < nrows) {
+        nvalid = min(VGL_EPT, nrows - r0);
+        bits = vgl_ds_bits8(state, dist, row_base + r0, nvalid, bit, T, &aux, &st8);
+        if (bits) {
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) {
+                degs[j] = 0;
+                if (j < nvalid && ((bits >> j) & 1)) { degs[j] = vgl_ds_degree(prow, r0 + j); deg += degs[j]; }
+            }
+        }
+    }
+    const int ta = vgl_block_reduce_add((int)__popc(aux), s32);
+    int ctot; int64_t dtot;
+    int pos = vgl_block_excl_add((int)__popc(bits), s32, &ctot);
+    int64_t eoff = vgl_block_excl_add(deg, s64, &dtot);
+    if (threadIdx.x == 0) {
+        vt_aux[blockIdx.x] = ta;
+        s_base = ctot ? atomicAdd(cursor, ((unsigned long long)ctot << VGL_DS_EDGE_BITS) | (unsigned long long)dtot) : 0ULL;
+    }
+    __syncthreads();
+    if (ctot == 0) return;                                   // the same value in every thread
+    pos += (int)(s_base >> VGL_DS_EDGE_BITS);
+    eoff += (int64_t)(s_base & ((1ULL << VGL_DS_EDGE_BITS) - 1ULL));
+    if (bits) {
+        uint64_t st_new = st8;
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            if ((bits >> j) & 1) {
+                ids[pos] = row_base + r0 + j;
+                offs[pos] = eoff; eoff += degs[j];
+                pos++;
+                st_new &= ~((uint64_t)bit << (8 * j));
+            }
+        }
+        const int32_t v0 = row_base + r0;
+        if (nvalid == 8) *reinterpret_cast<uint64_t *>(state + v0) = st_new;
+        else for (int j = 0; j < nvalid; j++) state[v0 + j] = (uint8_t)(st_new >> (8 * j));
+    }
+}
+// totals of a SMALL step where the scan kernel leaves them, and the cursor back to zero
+__global__ __launch_bounds__(VGL_DS_SCAN_THREADS) void vgl_k_ds_select_finish(int ntiles, const int32_t *vt_aux, unsigned long long *cursor, int64_t *counters,
+                                                                              int64_t *offs)
+{
+    __shared__ int s_a[VGL_DS_SCAN_THREADS / 64];
+    int a = 0;
+    for (int t = threadIdx.x; t < ntiles; t += VGL_DS_SCAN_THREADS) a += vt_aux[t];
+    a = vgl_wave_incl_add(a);
+    if ((threadIdx.x & 63) == 63) s_a[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int atot = 0;
+        for (int w = 0; w < VGL_DS_SCAN_THREADS / 64; w++) atot += s_a[w];
+        const unsigned long long cur = *cursor;
+        const int64_t F = (int64_t)(cur >> VGL_DS_EDGE_BITS), M = (int64_t)(cur & ((1ULL << VGL_DS_EDGE_BITS) - 1ULL));
+        counters[C_FRONT] = F; counters[C_NEIGH] = M; counters[C_TMP1] = atot;
+        offs[F] = M;
+        *cursor = 0ULL;
     }
 }
 
@@ -486,8 +574,8 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     VGL_HIP_TRY(hipMalloc((void **)&p->active, (size_t)g->V + 8));
     VGL_HIP_TRY(hipMemsetAsync(p->active, 0, (size_t)g->V + 8, st));
     VGL_HIP_TRY(hipMalloc((void **)&p->vt_aux, sizeof(int32_t) * (size_t)std::max<int64_t>(g->nvtiles, 1)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->partials, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS + 1)));
-    VGL_HIP_TRY(hipMemsetAsync(p->partials, 0, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS + 1), st));
+    VGL_HIP_TRY(hipMalloc((void **)&p->partials, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS + 2)));          // minima | near counts + flag | select cursor
+    VGL_HIP_TRY(hipMemsetAsync(p->partials, 0, sizeof(int64_t) * (1024 + VGL_DS_BLOCKS + 2), st));
     VGL_HIP_TRY(hipMalloc((void **)&p->tickets, sizeof(uint32_t) * 2 * VGL_TICKET_WORDS));
     VGL_HIP_TRY(hipMemsetAsync(p->tickets, 0, sizeof(uint32_t) * 2 * VGL_TICKET_WORDS, st));
     uint32_t *flags = nullptr, *S = nullptr;
@@ -556,23 +644,30 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     // the relax produced improvements below T, and the smallest pending distance after the relax.
     // dense = sweep the whole part as static tiles (rows marked in p->active) instead of walking a compacted frontier: chosen by
     // the caller from a PREDICTION of the step's size, so a wrong guess only costs time
-    auto step = [&](uint8_t bit, bool dense) -> int {
+    unsigned long long *cursor = reinterpret_cast<unsigned long long *>(p->partials + 1024 + VGL_DS_BLOCKS + 1);
+    auto step = [&](uint8_t bit, bool dense, bool small) -> int {
         const int k = bit == 1 ? 0 : 1;                     // which part this step walks
         if (dense && p->part[k].ntiles > 0) {
             hipLaunchKernelGGL(vgl_k_ds_mark, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist, bit, T,
                                p->active, g->vt_cnt, g->vt_deg, p->vt_aux);
-            hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_BLOCK), 0, st, (int)g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
+            hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, (int)g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
                                g->vt_deg_off, c->d_counters, g->offs);
             vgl_timed_launch tl(c, "sssp_relax");
             hipLaunchKernelGGL(vgl_k_ds_relax_static, dim3((unsigned)p->part[k].ntiles), dim3(VGL_BLOCK), 0, st, p->prow[k], p->padj[k], p->pw[k],
                                p->part[k].tile_row, p->part[k].edges, g->row_begin, p->active, T, d_dist, p->state, near_partials);
         } else {
-            hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
-                               bit, T, g->vt_cnt, g->vt_deg, p->vt_aux);
-            hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_BLOCK), 0, st, (int)g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
-                               g->vt_deg_off, c->d_counters, g->offs);
-            hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
-                               bit, T, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
+            if (small) {
+                hipLaunchKernelGGL(vgl_k_ds_select, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist, bit, T, cursor,
+                                   p->vt_aux, g->ids, g->offs);
+                hipLaunchKernelGGL(vgl_k_ds_select_finish, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, (int)g->nvtiles, p->vt_aux, cursor, c->d_counters, g->offs);
+            } else {
+                hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
+                                   bit, T, g->vt_cnt, g->vt_deg, p->vt_aux);
+                hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, (int)g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
+                                   g->vt_deg_off, c->d_counters, g->offs);
+                hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
+                                   bit, T, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
+            }
             hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
             vgl_timed_launch tl(c, "sssp_relax");
             hipLaunchKernelGGL(vgl_k_ds_relax, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
@@ -586,7 +681,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
         if (c->h_counters[C_FRONT] > 0) { s.iterations++; s.edges_relaxed += c->h_counters[C_NEIGH]; }
         if (debug) { static double t_last = 0; timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); const double t_now = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
                      fprintf(stderr, "[%7.0f us] ", t_now - t_last); t_last = t_now; }
-        if (debug) fprintf(stderr, "ds %s%s T=%g rows=%lld edges=%lld heavy_pending_below_T=%lld near_improved=%lld\n", bit == 1 ? "light" : "heavy", dense ? " (dense)" : "", T,
+        if (debug) fprintf(stderr, "ds %s%s%s T=%g rows=%lld edges=%lld heavy_pending_below_T=%lld near_improved=%lld\n", bit == 1 ? "light" : "heavy", dense ? " (dense)" : "", small && !dense ? " (small)" : "", T,
                            (long long)c->h_counters[C_FRONT], (long long)c->h_counters[C_NEIGH], (long long)c->h_counters[C_TMP1],
                            (long long)c->h_counters[C_TMP0]);
         return 0;
@@ -603,8 +698,14 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     const double dense_frac = envf("VGL_DS_DENSE", 0.4);    // dense when the predicted rows exceed this share of the part's non-empty rows
     int64_t bucket_rows = 0, bucket_edges = 0;
     int64_t pred_light_rows = 0;                             // improvements below T seen by the last relax: the next light frontier, roughly
+    // small = expected to schedule at most `small_rows` rows: one selection pass with a packed atomic cursor instead of count + scan +
+    // write.  Light steps inside a bucket are predicted by the previous relax's improvements below T, heavy steps know their size;
+    // the first step of a bucket has no prediction and takes the ordinary path.
+    const int64_t small_rows = (int64_t)envf("VGL_DS_SMALL", 4096.0);
+    bool fresh_bucket = true;
     for (;;) {
-        VGL_TRY(step(1, (double)pred_light_rows > dense_frac * (double)p->rows_nonempty[0]));
+        VGL_TRY(step(1, (double)pred_light_rows > dense_frac * (double)p->rows_nonempty[0], !fresh_bucket && pred_light_rows <= small_rows));
+        fresh_bucket = false;
         pred_light_rows = c->h_counters[C_TMP0];
         bucket_rows += c->h_counters[C_FRONT];
         bucket_edges += c->h_counters[C_NEIGH];
@@ -613,7 +714,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
         const bool near = c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0;
         if (near) continue;                                             // the bucket received improvements: light edges again
         if (c->h_counters[C_TMP1] > 0) {                                // bucket settled: its heavy edges, once
-            VGL_TRY(step(2, (double)c->h_counters[C_TMP1] > dense_frac * (double)p->rows_nonempty[1]));
+            VGL_TRY(step(2, (double)c->h_counters[C_TMP1] > dense_frac * (double)p->rows_nonempty[1], c->h_counters[C_TMP1] <= small_rows));
             pred_light_rows = c->h_counters[C_TMP0];
             bucket_edges += c->h_counters[C_NEIGH];
             if (c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0) continue;
@@ -629,6 +730,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
         if (debug) fprintf(stderr, "ds bucket done: rows=%lld edges=%lld next width=%g\n", (long long)bucket_rows, (long long)bucket_edges, width);
         bucket_rows = bucket_edges = 0;
         T = std::max(min_far + width, std::nextafter(min_far, FLT_MAX));
+        fresh_bucket = true;
     }
     s.algorithmic_bytes = 12 * s.edges_relaxed + 5 * (int64_t)V * s.iterations;
     if (stats) *stats = s;
