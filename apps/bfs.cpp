@@ -1,4 +1,5 @@
 // bfs app: counterpart of apps/bfs/bfs.cpp:15-62 (rounds with random non-isolated sources, optional -check).
+#define INT_ELEMENTS_PER_EDGE 4.0      // VGL byte accounting of this app (apps/bfs/bfs.cpp:3)
 #include "common.hpp"
 #include "algorithms/bfs.hpp"
 int main(int argc, char **argv)

@@ -1,4 +1,5 @@
 // cc app: counterpart of apps/cc/cc.cpp:11-60 (undirected input, heat run + timed run).
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/cc/cc.cpp:3)
 #include "common.hpp"
 #include "algorithms/cc.hpp"
 int main(int argc, char **argv)

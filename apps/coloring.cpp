@@ -1,6 +1,7 @@
 // coloring app: counterpart of apps/coloring/coloring.cpp:10-44 (undirected input; -check = verify_colors: no edge joins two
 // vertices of the same colour).  Runs entirely on the generic operator path: sparse frontiers, vertex post-ops, 64-bit vertex
 // arrays, reduce<int>, generate_new_frontier.
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/coloring/coloring.cpp:3)
 #include "common.hpp"
 #include "algorithms/coloring.hpp"
 int main(int argc, char **argv)

@@ -95,7 +95,13 @@ inline void dump_array(const std::string &path, const std::vector<T> &a)
     f.write((const char *)a.data(), (std::streamsize)(a.size() * sizeof(T)));
 }
 
-inline void report_performance(double mteps) { std::cout << "AVG_PERF: " << mteps << " MTEPS" << std::endl; }
+// VGL_RUNTIME::report_performance + stop_measuring_stats (vgl_runtime.hpp): the line the harness greps, then -- when operator-API
+// primitives ran -- the per-abstraction timers and the bandwidth under VGL's byte accounting (settings.h:140-155)
+inline void report_performance(double mteps)
+{
+    std::cout << "AVG_PERF: " << mteps << " MTEPS" << std::endl;
+    if (performance_stats.inner_wall_time > 0) performance_stats.print_timers_stats();
+}
 
 // verify_results (verify_results.h:33-92): exact for integers, |a-b| <= 100*FLT_EPSILON for floats
 template <class T>

@@ -1,4 +1,5 @@
 // hits app: counterpart of apps/hits/hits.cpp:17-62 (f64; -it = number of steps; -check against a sequential run).
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/hits/hits.cpp:3)
 #include "common.hpp"
 #include "algorithms/hits.hpp"
 #define base_type double

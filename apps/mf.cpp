@@ -1,5 +1,6 @@
 // mf app: counterpart of apps/mf/mf.cpp:11-70 (rounds with a source / sink pair each; -source / -sink fix them; -undirected generates the
 // symmetric input on which the result is the maximum flow; -check compares with a sequential run of the same rules on the host).
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/mf/mf.cpp:3)
 #include "common.hpp"
 #include "algorithms/mf.hpp"
 int main(int argc, char **argv)

@@ -1,4 +1,5 @@
 // pr app: counterpart of apps/pr/pr.cpp:11-63 (-it = number of iterations).
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/pr/pr.cpp:3)
 #include "common.hpp"
 #include "algorithms/pr.hpp"
 int main(int argc, char **argv)

@@ -1,4 +1,5 @@
 // scc app: counterpart of apps/scc/scc.cpp:11-52 (directed input; -check against a sequential Tarjan, partitions compared).
+#define INT_ELEMENTS_PER_EDGE 4.0      // VGL byte accounting of this app (apps/scc/scc.cpp:3)
 #include "common.hpp"
 #include "algorithms/scc.hpp"
 int main(int argc, char **argv)

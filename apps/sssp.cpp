@@ -1,4 +1,5 @@
 // sssp app: counterpart of apps/sssp/sssp.cpp:16-80.
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/sssp/sssp.cpp:3)
 #include "common.hpp"
 #include "algorithms/sssp.hpp"
 int main(int argc, char **argv)

@@ -1,5 +1,6 @@
 // sswp app: counterpart of apps/sswp/sswp.cpp:11-66 (random capacities, random non-isolated sources, -check against a
 // sequential label-correcting run).
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/sswp/sswp.cpp:3)
 #include "common.hpp"
 #include "algorithms/sswp.hpp"
 int main(int argc, char **argv)

@@ -1,5 +1,6 @@
 // tc app: counterpart of apps/tc/tc.cpp:8-70 (-it = number of vertex pairs; -check compares Purdom's algorithm with one BFS per
 // source).  -dump writes int32 triples (first, second, answer) with ORIGINAL vertex ids.
+#define INT_ELEMENTS_PER_EDGE 5.0      // VGL byte accounting of this app (apps/tc/tc.cpp:3)
 #include "common.hpp"
 #include "algorithms/tc.hpp"
 int main(int argc, char **argv)

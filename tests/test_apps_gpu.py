@@ -301,3 +301,19 @@ def test_run_tests_harness(tmp_path, ctx):
     assert {r["app"] for r in rows} == {"bfs", "sssp", "pr", "cc", "sswp", "hits", "scc", "coloring", "rw", "tc", "mf"}
     assert all(r["errors"] == 0 and isinstance(r["perf"], float) and r["perf"] > 0 for r in rows), [r for r in rows if r["errors"] != 0]
     assert os.path.exists(os.path.join(BIN, "harness_smoke.csv")) and "VERIFIED 19 TESTS" in out.stdout
+
+
+def test_api_performance_stats(tmp_path, ctx):
+    """VGL byte accounting (settings.h:140-155, performance_stats.hpp): operator-API runs report per-abstraction times and the bandwidth
+    the reference's model charges them; a top-down BFS visits exactly the edges of the reached vertices, 4 ints per edge in the bfs app"""
+    out, _ = run_app("bfs", ["-s", 12, "-e", 16, "-type", "rmat", "-seed", 3, "-source", 1], tmp_path)
+    m = re.search(r"edges visited: (\d+)", out)
+    assert m and "total bandwidth:" in out and "Advance" in out and "GNF" in out and "Compute" in out
+    visited = int(m.group(1))
+    assert 0 < visited <= 16 << 12
+    bw = float(re.search(r"total bandwidth: ([0-9.e+-]+) GB/s", out).group(1))
+    rate = float(re.search(r"edges rate: ([0-9.e+-]+) MTEPS", out).group(1))
+    # bytes = 16 B per visited edge + 8 B per computed vertex + 4 B per GNF vertex, over the same inner wall time as the edges rate
+    assert bw * 1e9 / (rate * 1e6) >= 16.0
+    fused, _ = run_app("bfs", ["-s", 12, "-e", 16, "-type", "rmat", "-seed", 3, "-source", 1, "-fused", "-do"], tmp_path)
+    assert "total bandwidth:" not in fused                     # the fused path does not go through the operator primitives

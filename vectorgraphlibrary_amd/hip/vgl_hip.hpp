@@ -93,7 +93,49 @@ public:
     double get_time() const { return std::chrono::duration<double>(t1 - t0).count(); }
     void print_time_stats(const std::string &name) const { std::cout << name << " time: " << get_time() * 1000.0 << " ms" << std::endl; }   // timer.hpp
 };
-struct PerformanceStats {                     // performance_stats.hpp:248-275
+// element counts of the reference's bandwidth accounting (settings.h:140-155; apps override INT_ELEMENTS_PER_EDGE before the include)
+#ifndef INT_ELEMENTS_PER_EDGE
+#define INT_ELEMENTS_PER_EDGE 3.0
+#endif
+#ifndef COMPUTE_INT_ELEMENTS
+#define COMPUTE_INT_ELEMENTS 2.0
+#endif
+#ifndef REDUCE_INT_ELEMENTS
+#define REDUCE_INT_ELEMENTS 2.0
+#endif
+#ifndef GNF_INT_ELEMENTS
+#define GNF_INT_ELEMENTS 1.0
+#endif
+
+// PerformanceStats (performance_stats.h:11-100, performance_stats.hpp:13-120,248-330): wall time per abstraction and the bytes the
+// reference's accounting charges them (work items x INT elements x 4 B -- VGL's own model, not measured traffic), so that
+// print_timers_stats() reports the same "total bandwidth / edges rate" lines a VGL user compares across backends.
+struct vgl_stopwatch {                        // primitives end with a stream sync: plain host clocks bracket them
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+struct PerformanceStats {
+    double inner_wall_time = 0, advance_time = 0, gather_time = 0, scatter_time = 0, compute_time = 0, reduce_time = 0, gnf_time = 0;
+    size_t bytes_requested = 0, edges_visited = 0;
+    void reset_timers() { *this = PerformanceStats(); }
+    void update_advance_stats(double t, size_t bytes, size_t edges, bool gather)
+    { advance_time += t; (gather ? gather_time : scatter_time) += t; inner_wall_time += t; bytes_requested += bytes; edges_visited += edges; }
+    void update_compute_stats(double t, size_t vertices) { compute_time += t; inner_wall_time += t; bytes_requested += (size_t)(vertices * COMPUTE_INT_ELEMENTS * sizeof(int)); }
+    void update_reduce_stats(double t, size_t vertices) { reduce_time += t; inner_wall_time += t; bytes_requested += (size_t)(vertices * REDUCE_INT_ELEMENTS * sizeof(int)); }
+    void update_gnf_stats(double t, size_t vertices) { gnf_time += t; inner_wall_time += t; bytes_requested += (size_t)(vertices * GNF_INT_ELEMENTS * sizeof(int)); }
+    double get_sustained_bandwidth() const { return inner_wall_time > 0 ? bytes_requested / (inner_wall_time * 1e9) : 0.0; }    // GB/s
+    double get_edges_rate() const { return inner_wall_time > 0 ? edges_visited / (inner_wall_time * 1e6) : 0.0; }               // MTEPS
+    void print_timers_stats() const
+    {
+        auto line = [this](const char *name, double t) {
+            if (t > 0) std::cout << name << " : " << t * 1e3 << " (ms), " << (inner_wall_time > 0 ? 100.0 * t / inner_wall_time : 0.0) << " %" << std::endl;
+        };
+        std::cout << std::endl;
+        line("Inner wall    ", inner_wall_time); line("Advance       ", advance_time); line("Gather        ", gather_time); line("Scatter       ", scatter_time);
+        line("Compute       ", compute_time); line("Reduce        ", reduce_time); line("GNF           ", gnf_time);
+        std::cout << std::endl << "total bandwidth: " << get_sustained_bandwidth() << " GB/s" << std::endl << "edges rate: " << get_edges_rate() << " MTEPS" << std::endl
+                  << "edges visited: " << edges_visited << std::endl << std::endl;
+    }
     double get_algorithm_performance(double t, long long edges) const { return edges / (t * 1e6); }   // MTEPS
     void print_algorithm_performance_stats(const std::string &name, double t, long long edges) const
     {
@@ -764,6 +806,7 @@ class GraphAbstractionsHIP {
     VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
     double *reduce_buffer = nullptr, *reduce_partials = nullptr;
 
+    static int active_count(VGL_Graph &g, VGL_Frontier &f) { return f.get_sparsity_type() == ALL_ACTIVE_FRONTIER ? g.get_vertices_count() : f.size(); }
     static unsigned grid_for(long long n) { long long b = (n + VGL_BLOCK - 1) / VGL_BLOCK; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
     template <class T> static constexpr bool is_empty_vertex_op() { return std::is_same<typename std::decay<T>::type, vgl_empty_vertex_op>::value; }
 
@@ -791,6 +834,8 @@ class GraphAbstractionsHIP {
     {
         vgl_hip_ctx *c = VGL_RUNTIME::ctx();
         hipStream_t st = VGL_RUNTIME::stream();
+        const vgl_stopwatch watch;
+        long long work = 0;                                 // edges the frontier touches (advance_worker.hpp:140-149)
         const vgl_csr_view v = g.get_direction_view(dir);
         const long long process_shift = (dir == GATHER) ? g.get_edges_count() : 0;     // compute_process_shift (graph_abstractions.hpp:19-28)
         if (!is_empty_vertex_op<PreOp>()) vertex_pass(g, f, dir, pre_op);
@@ -799,12 +844,14 @@ class GraphAbstractionsHIP {
         if (t == SPARSE_FRONTIER) {
             const int64_t *offs; const int32_t *tile_first; int64_t M;
             VGL_HIP_CALL(vgl_hip_frontier_advance_plan(c, g.get_handle(), f.get_handle(), dir == GATHER, &offs, &tile_first, &M));
+            work = M;
             if (M > 0) {
                 const unsigned nt = (unsigned)((M + VGL_TILE - 1) / VGL_TILE);
                 hipLaunchKernelGGL((vgl_k_advance_sparse<E>), dim3(nt), dim3(VGL_BLOCK), 0, st, f.get_ids(), offs, tile_first, f.size(), (long long)M,
                                    v.rowptr, v.adj, process_shift, edge_op);
             }
         } else if (v.edges > 0) {
+            work = t == ALL_ACTIVE_FRONTIER ? v.edges : f.get_neighbours_count();
             const int32_t *tile_row; int64_t ntiles;
             VGL_HIP_CALL(vgl_hip_graph_tile_rows(g.get_handle(), dir == GATHER, &tile_row, &ntiles));
             if (t == DENSE_FRONTIER)
@@ -815,6 +862,7 @@ class GraphAbstractionsHIP {
         VGL_HIP_RT(hipGetLastError());
         if (!is_empty_vertex_op<PostOp>()) vertex_pass(g, f, dir, post_op);
         VGL_RUNTIME::sync();                 // primitives are synchronous, like the reference GPU backend (advance_csr.hpp:204)
+        performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, dir == GATHER);
     }
 
 public:
@@ -859,14 +907,17 @@ public:
     template <typename ComputeOperation>
     void compute(VGL_Graph &g, VGL_Frontier &f, ComputeOperation &&compute_op)
     {
+        const vgl_stopwatch watch;
         vertex_pass(g, f, current_traversal_direction, compute_op);
         VGL_RUNTIME::sync();
+        performance_stats.update_compute_stats(watch.seconds(), (size_t)active_count(g, f));
     }
 
     template <typename _T, typename ReduceOperation>
     _T reduce(VGL_Graph &g, VGL_Frontier &f, ReduceOperation &&reduce_op, REDUCE_TYPE type)
     {
         if (type != REDUCE_SUM && type != REDUCE_MAX) throw "Error in GraphAbstractionsHIP::reduce : unsupported reduce type";   // reduce.hpp:144-150
+        const vgl_stopwatch watch;
         const vgl_csr_view v = g.get_direction_view(current_traversal_direction);
         const FrontierSparsityType t = f.get_sparsity_type();
         hipStream_t st = VGL_RUNTIME::stream();
@@ -886,9 +937,11 @@ public:
             double h[NP];
             VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h, reduce_partials, sizeof(h)));
             for (int i = 0; i < NP; i++) r = h[i] > r ? h[i] : r;
+            performance_stats.update_reduce_stats(watch.seconds(), (size_t)n);
             return (_T)r;
         }
         VGL_HIP_CALL(vgl_hip_reduce_sum_f64_buffer(VGL_RUNTIME::ctx(), n, reduce_buffer, &r));
+        performance_stats.update_reduce_stats(watch.seconds(), (size_t)n);
         return (_T)r;
     }
 
@@ -898,10 +951,12 @@ public:
         const vgl_csr_view v = g.get_direction_view(current_traversal_direction);
         using C = typename std::decay<FilterCondition>::type;
         const int V = g.get_vertices_count();
+        const vgl_stopwatch watch;
         hipLaunchKernelGGL((vgl_k_filter_flags<C>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), V, v.rowptr, filter_cond, f.get_flags());
         VGL_HIP_RT(hipGetLastError());
         f.set_direction(current_traversal_direction);
         VGL_HIP_CALL(vgl_hip_gnf_from_flags(VGL_RUNTIME::ctx(), g.get_handle(), f.get_flags(), 0.0, f.get_handle()));
+        performance_stats.update_gnf_stats(watch.seconds(), (size_t)V);
     }
 
     void enable_safe_stores() {}         // no-op off NEC (graph_abstractions_multicore.h:295-296)
