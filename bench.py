@@ -328,6 +328,32 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
+        # ---- roofline of rank 0's dominant kernel: one more, UNTIMED pass over the same sources with HIP-event timing and this shard's
+        # work counters on (the counters cost a host read per bottom-up level, so they stay out of the timed region) ----
+        ctx.timing(True)
+        st = {}
+        for s in sources[args.warmup:]:
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, stats=st)
+        barrier()
+        kern = {}
+        for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "gnf"):
+            n, ms = ctx.timing_get(name)
+            kern[name] = {"launches": n, "total_ms": round(ms, 4)}
+        ctx.timing(False)
+        owned = int(shard.row_end - shard.row_begin)
+        bytes_k = {"bfs_bottom_up": 8 * st.get("bu_edges", 0) + 4 * st.get("bu_found", 0) + st.get("bu_steps", 0) * (owned // 8),
+                   "bfs_top_down": 8 * st.get("td_edges", 0) + 20 * st.get("td_frontier", 0)}
+        dom = max(bytes_k, key=lambda k: kern[k]["total_ms"])
+        if kern[dom]["launches"] > 0 and kern[dom]["total_ms"] > 0:
+            per_launch_bytes = bytes_k[dom] / kern[dom]["launches"]
+            per_launch_ms = kern[dom]["total_ms"] / kern[dom]["launches"]
+            achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "bytes_per_launch": int(per_launch_bytes),
+                        "ms_per_launch": round(per_launch_ms, 5), "launches": kern[dom]["launches"], "rank": 0,
+                        "note": "rank 0's shard, measured in an untimed repeat of the timed traversals"}
+        extra["bfs"] = {"kernels_rank0": kern, "levels_per_bfs": st.get("levels", 0) / max(1, args.steps), "td_steps": st.get("td_steps", 0),
+                        "bu_steps": st.get("bu_steps", 0)}
         extra["shard_edges"] = int(shard.E)
         workload = (f"BFS direction-optimising super-steps (bitmap all-gather per level) on RMAT scale-{scale} "
                     f"(edge factor {ef}), edge-cut over {world} GPUs")

@@ -14,12 +14,19 @@ Exchange payloads:
   PR   : owned slices of the new ranks               (EXCHANGE_PRIVATE_DATA, pr.hpp:127), as a sum with zeros elsewhere
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
 
 from . import lib as _l
 from .api import _ptr
+
+
+def _exchanging(P, group=None):
+    """True when the super-step exchanges run.  VGL_SHARD_FORCE_COLLECTIVES=1 runs them in a one-rank process group too: every
+    collective call of the N > 1 path then executes through RCCL on a one-GPU box (tests/test_distributed_gpu.py)"""
+    return P > 1 or (os.environ.get("VGL_SHARD_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
 
 
 def _world(group):
@@ -67,9 +74,16 @@ class HipShardOps:
                                                        _ptr(mine), C.byref(f), C.byref(m)))
         return f.value, m.value
 
-    def bfs_step_bu(self, levels, level, visited, front, mine):
+    def bfs_step_bu(self, levels, level, visited, front, mine, want_counts=False):
+        """bottom-up step over the owned rows; want_counts: wait for and return (found, adjacency entries probed) of THIS shard"""
+        if not want_counts:
+            _l.check(self.L.vgl_hip_bfs_step_bottom_up(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), _ptr(front), _ptr(mine),
+                                                       None, None))
+            return None
+        f, m = C.c_int64(), C.c_int64()
         _l.check(self.L.vgl_hip_bfs_step_bottom_up(self.ctx.h, self.g.h, _ptr(levels), int(level), _ptr(visited), _ptr(front), _ptr(mine),
-                                                   None, None))
+                                                   C.byref(f), C.byref(m)))
+        return f.value, m.value
 
     def or_parts(self, parts, bits_in, bits_out):
         _l.check(self.L.vgl_hip_bitmap_or_parts(self.ctx.h, bits_out.numel(), int(parts), _ptr(bits_in), _ptr(bits_out)))
@@ -205,14 +219,14 @@ def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat
 
 
 def _allreduce(t, op, group):
-    if _world(group)[0] > 1:
+    if _exchanging(_world(group)[0]):
         dist.all_reduce(t, op=op, group=group)
 
 
 ALPHA, BETA = 15, 18          # change_state.hpp:5-6
 
 
-def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False, two_phase=None):
+def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False, two_phase=None, stats=None):
     """BFS over edge-cut shards; returns the replicated levels array and the number of levels.
     degrees (int32[V] out-degrees of ALL vertices, replicated) + edges (global E) enable direction optimisation: every rank
     evaluates the same switch rule (gpu_change_state, change_state.hpp:100-141) on replicated counters, bottom-up steps scan
@@ -222,15 +236,18 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
     the owned V/(8P)-byte slices instead, P times less traffic; the caller guarantees the flag is the same on all ranks.
     two_phase (needs equal_ranges; default: on for P >= 4): top-down levels, whose discoveries lie anywhere, exchange in two steps
     -- all-to-all of the V/(8P)-byte slices (every rank receives the P versions of ITS slice and ORs them), then all-gather of the
-    merged slices -- 2*V/8 bytes per rank instead of P*V/8."""
+    merged slices -- 2*V/8 bytes per rank instead of P*V/8.
+    stats (dict, optional): accumulates THIS shard's work -- bu_steps / bu_edges / bu_found, td_steps / td_edges / td_frontier,
+    levels -- for the roofline accounting of bench.py; bottom-up steps then wait for their counters (one more host read per level)."""
     P, rank = _world(group)
     V = ops.V
     levels = ops.new_i32()
     ops.bfs_init(levels, source)
     mine = ops.new_words(1)
-    everyone = ops.new_words(P) if P > 1 else mine
+    exchanging = _exchanging(P)
+    everyone = ops.new_words(P) if exchanging else mine
     merged = None
-    if equal_ranges and P > 1:
+    if equal_ranges and exchanging:
         lo, hi = ops.row_range()
         if V % (64 * P) or lo != rank * (V // P) or hi != lo + V // P:
             raise ValueError("bfs_sharded: equal_ranges needs rank r to own rows [r*V/P, (r+1)*V/P) with V/P a multiple of 64")
@@ -260,11 +277,21 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
         prevF = F
         parts, bits = P, everyone
         if bottom_up:
-            ops.bfs_step_bu(levels, level, visited, front, mine)          # owned unvisited vertices look for a parent
+            counts = ops.bfs_step_bu(levels, level, visited, front, mine, *((True,) if stats is not None else ()))   # owned unvisited vertices look for a parent
+            if stats is not None:
+                stats["bu_steps"] = stats.get("bu_steps", 0) + 1
+                stats["bu_found"] = stats.get("bu_found", 0) + counts[0]
+                stats["bu_edges"] = stats.get("bu_edges", 0) + counts[1]
         else:
-            ops.bfs_step_bits(levels, level, visited, front, mine)        # owned frontier vertices expand; mine = discoveries
+            fm = ops.bfs_step_bits(levels, level, visited, front, mine)   # owned frontier vertices expand; mine = discoveries
+            if stats is not None and fm is not None:
+                stats["td_steps"] = stats.get("td_steps", 0) + 1
+                stats["td_frontier"] = stats.get("td_frontier", 0) + fm[0]
+                stats["td_edges"] = stats.get("td_edges", 0) + fm[1]
         nlevels += 1
-        if P > 1:
+        if stats is not None:
+            stats["levels"] = stats.get("levels", 0) + 1
+        if exchanging:
             ops.sync()
             if bottom_up and merged is not None:
                 dist.all_gather_into_tensor(merged, mine[lo // 64:hi // 64], group=group)
@@ -292,7 +319,7 @@ def sssp_sharded(ops, source, group=None):
     while True:
         changed = ops.sssp_relax(d)
         iters += 1
-        if P > 1:
+        if _exchanging(P):
             ops.sync()
             dist.all_reduce(d, op=dist.ReduceOp.MIN, group=group)
             flag = ops.scalar([changed])
@@ -313,7 +340,7 @@ def sswp_sharded(ops, source, group=None):
     while True:
         changed = ops.sswp_relax(wd)
         iters += 1
-        if P > 1:
+        if _exchanging(P):
             ops.sync()
             dist.all_reduce(wd, op=dist.ReduceOp.MAX, group=group)
             flag = ops.scalar([changed])
@@ -332,7 +359,7 @@ def cc_sharded(ops, group=None):
     while True:
         changed = ops.cc_hook(comp)
         passes += 1
-        if P > 1:
+        if _exchanging(P):
             ops.sync()
             dist.all_reduce(comp, op=dist.ReduceOp.MIN, group=group)
             flag = ops.scalar([changed])
@@ -349,14 +376,14 @@ def page_rank_sharded(ops, iterations, row_begin, row_end, group=None):
     indeg = ops.new_i32()
     indeg.zero_()
     ops.indeg_add(indeg)
-    if P > 1:
+    if _exchanging(P):
         ops.sync()
         dist.all_reduce(indeg, op=dist.ReduceOp.SUM, group=group)
     ranks, rdeg, contrib = ops.new_f32(), ops.new_f32(), ops.new_f32()
     ops.pr_setup(indeg, ranks, rdeg)
     for _ in range(iterations):
         ops.pr_iteration(indeg, rdeg, ranks, contrib)     # writes the owned rows of `ranks`
-        if P > 1:
+        if _exchanging(P):
             ops.sync()
             ranks[:row_begin] = 0
             ranks[row_end:] = 0
