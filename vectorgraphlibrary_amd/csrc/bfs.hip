@@ -107,10 +107,15 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
 // ---- frontier generation from the frontier BITMAP (small frontiers): one 64-bit word per thread, 256 words per workgroup ----
 // The last workgroup to finish also does what used to be two more launches: the exclusive scan of the per-workgroup counts
 // (<= a few thousand entries) and the hand-over of F and M to the host (counters + pinned mirror + sequence number).
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
+// ADVANCE: the launch also turns the discoveries of the level before into the frontier it counts (what vgl_k_bm_advance does:
+// visited |= next, front = next, next = 0) -- after a top-down level the count always follows, so the two passes over the same
+// words share one launch.
+template <bool ADVANCE>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, int64_t word0, int32_t row_base, uint64_t *front,
                                                                 const int64_t *rowptr, int32_t *vt_cnt, int64_t *vt_deg,
                                                                 int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *offs, int64_t *counters,
-                                                                uint32_t *ticket, volatile int64_t *host, int64_t seq)
+                                                                uint32_t *ticket, volatile int64_t *host, int64_t seq, uint64_t *visited,
+                                                                uint64_t *next)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
@@ -118,7 +123,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
     int cnt = 0;
     int64_t deg = 0;
     if (wi < nwords) {
-        uint64_t w = front[word0 + wi];
+        uint64_t w;
+        if (ADVANCE) {
+            w = next[word0 + wi];
+            front[word0 + wi] = w;
+            if (w) { visited[word0 + wi] |= w; next[word0 + wi] = 0; }
+        } else w = front[word0 + wi];
         cnt = __popcll(w);
         while (w) {
             const int b = __ffsll((long long)w) - 1;
@@ -470,7 +480,8 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
 // frontier of the current level from a frontier bitmap (owned words).  count: per-workgroup counts, their scan and F / M in
 // h_counters[C_FRONT] / [C_NEIGH] (one launch, the host waits for it); write: ids + edge offsets + tile_first (needs the M of
 // the count pass)
-static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1)
+static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1,
+                          bool advance = false)
 {
     const int64_t word0 = g->row_begin >> 6;
     const int64_t nwords = vgl_ceil_div(g->row_end, 64) - word0;
@@ -479,9 +490,14 @@ static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *fron
         const int64_t seq = vgl_next_seq(c);
         {
             vgl_timed_launch tl(c, "gnf");
-            hipLaunchKernelGGL(vgl_k_bm_gnf_count, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, front,
-                               g->out.rowptr, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, g->offs, c->d_counters, g->tickets + 0 * VGL_TICKET_WORDS,
-                               (volatile int64_t *)c->h_counters, seq);
+            if (advance)                 // front == g->bm_front: rebuilt from g->bm_next first (whole-graph handles only)
+                hipLaunchKernelGGL(vgl_k_bm_gnf_count<true>, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, g->bm_front,
+                                   g->out.rowptr, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, g->offs, c->d_counters,
+                                   g->tickets + 0 * VGL_TICKET_WORDS, (volatile int64_t *)c->h_counters, seq, g->bm_visited, g->bm_next);
+            else
+                hipLaunchKernelGGL(vgl_k_bm_gnf_count<false>, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin,
+                                   const_cast<uint64_t *>(front), g->out.rowptr, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, g->offs, c->d_counters,
+                                   g->tickets + 0 * VGL_TICKET_WORDS, (volatile int64_t *)c->h_counters, seq, (uint64_t *)nullptr, (uint64_t *)nullptr);
         }
         VGL_HIP_TRY(hipGetLastError());
         VGL_TRY(vgl_wait_counters(c, seq));
@@ -552,11 +568,12 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     bool front_valid = true;
     bool counted = false;            // vt_cnt_off / vt_deg_off describe the frontier (needed by the write pass)
     bool counted_from_bitmap = false;
+    bool advance_pending = false;    // bm_next holds the discoveries of the last (top-down, emitting) level: the count launch applies them
     int64_t F = 0, M = 0, prevF = 0, visited_total = 0;
     const int64_t factor = std::max<int64_t>(1, (E / V) / 2);     // change_state.hpp:104
     constexpr int64_t VGL_TD_EMIT_EDGES = 16 << 20;
     auto count_frontier = [&]() -> int {
-        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false)); counted_from_bitmap = true; }
+        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false, -1, advance_pending)); counted_from_bitmap = true; advance_pending = false; }
         else {
             vgl_pred_equal_i32 pred{d_levels, cur};
             VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, nullptr, false, true));
@@ -593,9 +610,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             }
             const bool emit = M <= VGL_TD_EMIT_EDGES;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
             VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap));
-            if (emit)
-                hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
-                                   g->bm_front, g->bm_next);
+            advance_pending = emit;          // a top-down level is always followed by count_frontier (or the loop ends below)
             front_valid = emit;
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
         } else {
