@@ -818,3 +818,35 @@ def test_random_graphs_all_algorithms(seed, ctx, oracle):
         assert (api.connected_components(gs, symmetric=True)[0].cpu().numpy() == want).all()
         assert (api.connected_components(gs)[0].cpu().numpy() == want).all()
         gs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef", [("rmat", 15, 8), ("ru", 14, 2), ("ru", 13, 1), ("rmat", 10, 4)])
+def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
+    """the single-workgroup kernel that runs the first and the last levels of a traversal (vgl_k_bfs_small_levels): off, default and
+    with a bound that lets it take whole traversals of sparse graphs -- levels, level count and examined edges must not move"""
+    import os
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    V = 1 << scale
+    src, dst = (O.gen_rmat if kind == "rmat" else O.gen_uniform)(scale, ef, 77)
+    rowptr, adj, _ = O.coo_to_csr(V, src, dst)
+    g = api.Graph.from_coo(ctx, V, torch.from_numpy(src).to(ctx.device), torch.from_numpy(dst).to(ctx.device))
+    nz = np.nonzero(np.diff(rowptr))[0]
+    for source in (int(nz[0]), int(nz[len(nz) // 2]), int(np.argmax(np.diff(rowptr)))):
+        ref = O.bfs_top_down(rowptr, adj, source)[0]
+        for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+            seen = []
+            for cap in ("0", None, "1000000"):
+                if cap is None:
+                    os.environ.pop("VGL_BFS_SMALL_M", None)
+                else:
+                    os.environ["VGL_BFS_SMALL_M"] = cap
+                try:
+                    lv, st = api.bfs(g, source, mode)
+                finally:
+                    os.environ.pop("VGL_BFS_SMALL_M", None)
+                assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap)
+                seen.append((st["levels"], st["edges_examined"], st["frontier_total"], st["discovered"], st["td_steps"], st["bu_steps"]))
+            assert seen[0] == seen[1] == seen[2], (source, mode, seen)
