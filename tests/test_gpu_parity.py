@@ -821,7 +821,7 @@ def test_random_graphs_all_algorithms(seed, ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,scale,ef", [("rmat", 15, 8), ("ru", 14, 2), ("ru", 13, 1), ("rmat", 10, 4)])
+@pytest.mark.parametrize("kind,scale,ef", [("rmat", 15, 8), ("rmat", 18, 16), ("ru", 16, 8), ("ru", 14, 2), ("ru", 13, 1), ("rmat", 10, 4)])
 def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
     """the single-workgroup kernel that runs the first and the last levels of a traversal (vgl_k_bfs_small_levels): off, default and
     with a bound that lets it take whole traversals of sparse graphs -- levels, level count and examined edges must not move"""
@@ -838,15 +838,18 @@ def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
         ref = O.bfs_top_down(rowptr, adj, source)[0]
         for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
             seen = []
-            for cap in ("0", None, "1000000"):
-                if cap is None:
-                    os.environ.pop("VGL_BFS_SMALL_M", None)
-                else:
-                    os.environ["VGL_BFS_SMALL_M"] = cap
+            # (edge bound of the list kernel, frontier bound of the bitmap-driven level at the bottom-up -> top-down switch)
+            for cap, bm in (("0", None), (None, None), ("1000000", None), (None, "0"), (None, "1000000000"), ("256", "1000000000")):
+                for name, val in (("VGL_BFS_SMALL_M", cap), ("VGL_BFS_BM_EXPAND", bm)):
+                    if val is None:
+                        os.environ.pop(name, None)
+                    else:
+                        os.environ[name] = val
                 try:
                     lv, st = api.bfs(g, source, mode)
                 finally:
                     os.environ.pop("VGL_BFS_SMALL_M", None)
-                assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap)
+                    os.environ.pop("VGL_BFS_BM_EXPAND", None)
+                assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap, bm)
                 seen.append((st["levels"], st["edges_examined"], st["frontier_total"], st["discovered"], st["td_steps"], st["bu_steps"]))
-            assert seen[0] == seen[1] == seen[2], (source, mode, seen)
+            assert all(x == seen[0] for x in seen), (source, mode, seen)

@@ -28,8 +28,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bfs_init(int32_t V, int32_t s
 
 // start of a fused traversal: levels, the three bitmaps (visited = front = {source}, next = 0) and the tickets in one launch
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bfs_init_all(int32_t V, int32_t source, int32_t *levels, int64_t words, uint64_t *visited,
-                                                                uint64_t *front, uint64_t *next, uint32_t *tickets)
+                                                                uint64_t *front, uint64_t *next, uint32_t *tickets, unsigned long long *list_count)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0ULL;
     for (int32_t v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < V; v += gridDim.x * VGL_BLOCK)
         levels[v] = (v == source) ? 1 : -1;      // FIRST_LEVEL_VERTEX / UNVISITED_VERTEX (change_state.h:21-23)
     for (int64_t w = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; w < words; w += (int64_t)gridDim.x * VGL_BLOCK) {
@@ -215,12 +216,66 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, 
 // C_EDGES = edges examined, C_TMP1 = frontier vertices of the levels run AFTER the first one, C_JUMP = size of the last level run,
 // C_NEIGH = edges of the first level (source mode).
 constexpr int VGL_SMALL_F = 2048;
+// One top-down level straight from the frontier BITMAP (one word per thread), for the switch from bottom-up back to top-down: the
+// host knows the frontier is small-ish (its size is the bottom-up step's found count) but has neither ids nor edge counts, and the
+// rows left that late are short.  Rows of at most 32 edges are walked by their thread, longer ones by the wavefront.  Discoveries
+// are claimed by the atomicOr on `next` (state afterwards = after an emitting top-down level) and, while they are few, appended to
+// `list` so that vgl_k_bfs_small_levels can carry on without a count / host / write round: *list_count may run past `cap`, which
+// then means "too many".  edge_partials[block] = edges examined.
+constexpr int VGL_BM_EXPAND_THREAD_ROW = 32;
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_expand(int64_t nwords, const uint64_t *front, const int64_t *rowptr, const int32_t *adj,
+                                                             const uint64_t *visited, uint64_t *next, int32_t *levels, int32_t next_level,
+                                                             int32_t *list, unsigned long long *list_count, int32_t cap, int64_t *edge_partials)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    const int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x;
+    uint64_t w = wi < nwords ? front[wi] : 0ULL;
+    uint64_t big = 0;
+    int64_t my_edges = 0;
+    auto visit = [&](int32_t dst) {
+        const unsigned long long bit = 1ULL << (dst & 63);
+        if (visited[dst >> 6] & bit) return;
+        const unsigned long long old = atomicOr((unsigned long long *)&next[dst >> 6], bit);
+        if (old & bit) return;
+        levels[dst] = next_level;
+        if (__hip_atomic_load(list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= (unsigned long long)cap) {
+            const unsigned long long pos = atomicAdd(list_count, 1ULL);
+            if (pos < (unsigned long long)cap) list[pos] = dst;
+        }
+    };
+    while (w) {
+        const int b = __ffsll((long long)w) - 1;
+        w &= w - 1;
+        const int64_t v = (wi << 6) + b;
+        const int64_t lo = rowptr[v], hi = rowptr[v + 1];
+        my_edges += hi - lo;
+        if (hi - lo > VGL_BM_EXPAND_THREAD_ROW) { big |= 1ULL << b; continue; }
+        for (int64_t q = lo; q < hi; q++) visit(adj[q]);
+    }
+    // longer rows: the wavefront walks them one after the other (lanes stride over the row)
+    unsigned long long todo = __ballot(big != 0);
+    while (todo) {
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t base = __shfl(wi, src_lane) << 6;
+        uint64_t m = __shfl(big, src_lane);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int64_t lo = rowptr[base + b], hi = rowptr[base + b + 1];
+            for (int64_t q = lo + vgl_lane(); q < hi; q += 64) visit(adj[q]);
+        }
+    }
+    const int64_t tot = vgl_block_reduce_add(my_edges, s64);
+    if (threadIdx.x == 0) edge_partials[blockIdx.x] = tot;
+}
 constexpr int VGL_SMALL_THREADS = 1024;
 constexpr int VGL_SMALL_UNROLL = 4;            // edges per thread and round: their loads / atomics are in flight together
 __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(const int32_t *ids_in, int32_t F0, int32_t source, const int64_t *rowptr,
                                                                             const int32_t *adj, uint64_t *visited, uint64_t *next, int32_t *levels,
                                                                             int32_t level0, int64_t cap_m, int64_t *counters, volatile int64_t *host,
-                                                                            int64_t seq)
+                                                                            int64_t seq, unsigned long long *list_count, const int64_t *edge_partials,
+                                                                            int n_partials)
 {
     constexpr int NT = VGL_SMALL_THREADS, NW = NT / 64, U = VGL_SMALL_UNROLL;
     __shared__ int32_t s_list[2][VGL_SMALL_F];
@@ -231,10 +286,34 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int cur = 0;
     int32_t F = source >= 0 ? 1 : F0;
-    for (int i = tid; i < F; i += NT) s_list[0][i] = source >= 0 ? source : ids_in[i];
+    // list_count != nullptr: the list comes from vgl_k_bm_expand (length on the device, entries also set in `next` but not in
+    // `visited` yet); its edge count is folded here so that the host gets everything in one read (C_CHANGED, list length in C_BU_FOUND)
+    bool usable = true;
+    int64_t n_list = 0, bm_edges = 0;
+    if (list_count) {
+        n_list = (int64_t)*list_count;
+        usable = n_list > 0 && n_list <= VGL_SMALL_F;
+        F = usable ? (int32_t)n_list : 0;
+        for (int i = tid; i < n_partials; i += NT) bm_edges += edge_partials[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bm_edges += __shfl_xor(bm_edges, o);
+        __shared__ int64_t s_bm[NW];
+        if (lane == 0) s_bm[wave] = bm_edges;
+        __syncthreads();                                       // (also: everyone has read *list_count)
+        bm_edges = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) bm_edges += s_bm[w];
+        if (tid == 0) *list_count = 0ULL;                      // ready for the next traversal
+    }
+    for (int i = tid; i < F; i += NT) {
+        const int32_t v = source >= 0 ? source : ids_in[i];
+        s_list[0][i] = v;
+        if (list_count) atomicOr((unsigned long long *)&visited[v >> 6], 1ULL << (v & 63));
+    }
     int32_t level = level0, run = 0, last_f = 0;
     int64_t edges = 0, later_front = 0, first_m = 0;
     for (;;) {
+        if (!usable) break;                                    // (uniform) empty or overflowed list: nothing is done
         __syncthreads();                                       // the list of this level is complete (and everyone has read the old s_cnt)
         // degrees of the (at most 2 per thread) list entries, exclusive prefix over the workgroup
         int64_t b0 = 0, b1 = 0, d0 = 0, d1 = 0;
@@ -256,7 +335,7 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(cons
         if (i0 < F) { s_beg[i0] = b0; s_off[i0] = excl; }
         if (i1 < F) { s_beg[i1] = b1; s_off[i1] = excl + (int)d0; }
         if (tid == 0) { s_cnt = 0; s_off[F] = (int)M; }
-        if (run > 0)                                           // these vertices are the frontier now, not discoveries any more
+        if (run > 0 || list_count)                             // these vertices are the frontier now, not discoveries any more
             for (int i = tid; i < F; i += NT) { const int32_t v = s_list[cur][i]; atomicAnd((unsigned long long *)&next[v >> 6], ~(1ULL << (v & 63))); }
         __syncthreads();                                       // offsets staged; (a discovery below can share a word with a bit cleared above)
         const int m = (int)M;
@@ -301,8 +380,9 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(cons
     }
     if (tid == 0) {
         counters[C_FRONT] = F; counters[C_TMP0] = run; counters[C_EDGES] = edges; counters[C_TMP1] = later_front; counters[C_JUMP] = last_f;
-        counters[C_NEIGH] = first_m;
+        counters[C_NEIGH] = first_m; counters[C_BU_FOUND] = n_list; counters[C_CHANGED] = bm_edges;
         host[C_FRONT] = F; host[C_TMP0] = run; host[C_EDGES] = edges; host[C_TMP1] = later_front; host[C_JUMP] = last_f; host[C_NEIGH] = first_m;
+        host[C_BU_FOUND] = n_list; host[C_CHANGED] = bm_edges;
         __threadfence_system();
         host[C_NSLOTS] = seq;
         __threadfence_system();
@@ -666,7 +746,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     const int64_t words = vgl_ceil_div(V, 64);
     if (source < 0 || source >= V) VGL_FAIL("bfs_run: source vertex out of range");
     hipLaunchKernelGGL(vgl_k_bfs_init_all, dim3(vgl_grid(V)), dim3(VGL_BLOCK), 0, c->stream, V, source, d_levels, words, g->bm_visited, g->bm_front,
-                       g->bm_next, g->tickets);
+                       g->bm_next, g->tickets, reinterpret_cast<unsigned long long *>(c->d_counters + C_HEAVY));
 
     vgl_hip_bfs_stats st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int32_t cur = 1;
@@ -700,12 +780,24 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     if (small_m < 64) small_m = 0;                       // not worth a launch of its own
     bool finished = false;
     // runs the kernel on the list g->ids[0..F) of level `cur` (or on {source}); returns through C_* what it did
-    auto small_levels = [&](int32_t listF, int32_t src) -> int {
+    unsigned long long *list_count = reinterpret_cast<unsigned long long *>(c->d_counters + C_HEAVY);      // slot unused by the fused traversal
+    const unsigned bm_blocks = (unsigned)vgl_ceil_div(words, VGL_BLOCK);
+    int64_t bm_expand_f = 262144;                        // bottom-up -> top-down switch: frontiers up to this size are expanded from the bitmap
+    if (const char *e = getenv("VGL_BFS_BM_EXPAND")) bm_expand_f = atoll(e);
+    if (bm_blocks > 8192) bm_expand_f = 0;               // (edge partials live in g->bu_partials: 4 * VGL_BU_BLOCKS slots)
+    // from_bitmap: level `cur` is expanded from bm_front by vgl_k_bm_expand first, the list kernel starts at level cur + 1
+    auto small_levels = [&](int32_t listF, int32_t src, bool from_bitmap = false) -> int {
+        if (from_bitmap) {
+            vgl_timed_launch tl(c, "bfs_top_down");
+            hipLaunchKernelGGL(vgl_k_bm_expand, dim3(bm_blocks), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_front, g->out.rowptr, g->out.adj, g->bm_visited,
+                               g->bm_next, d_levels, cur + 1, g->ids, list_count, (int32_t)VGL_SMALL_F, g->bu_partials);
+        }
         const int64_t seq = vgl_next_seq(c);
         {
             vgl_timed_launch tl(c, "bfs_top_down");
             hipLaunchKernelGGL(vgl_k_bfs_small_levels, dim3(1), dim3(VGL_SMALL_THREADS), 0, c->stream, g->ids, listF, src, g->out.rowptr, g->out.adj,
-                               g->bm_visited, g->bm_next, d_levels, cur, small_m, c->d_counters, (volatile int64_t *)c->h_counters, seq);
+                               g->bm_visited, g->bm_next, d_levels, from_bitmap ? cur + 1 : cur, small_m, c->d_counters, (volatile int64_t *)c->h_counters,
+                               seq, from_bitmap ? list_count : (unsigned long long *)nullptr, (const int64_t *)g->bu_partials, from_bitmap ? (int)bm_blocks : 0);
         }
         VGL_HIP_TRY(hipGetLastError());
         VGL_TRY(vgl_wait_counters(c, seq));
@@ -742,6 +834,21 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                 if (F > prevF && M >= ((V - visited_total) * factor + V) / VGL_DO_ALPHA) bottom_up = true;
             } else if (F < prevF && F < ((V - visited_total) * factor + V) / (factor * VGL_DO_BETA)) {
                 bottom_up = false;
+                if (small_m > 0 && F <= bm_expand_f) {
+                    // a modest frontier of short rows: expand it from the bitmap and let the list kernel run whatever follows -- no
+                    // count / host / write rounds.  Level cur is booked here, the list kernel's levels by account_small.
+                    VGL_TRY(small_levels(0, -1, true));
+                    const int64_t m_level = c->h_counters[C_CHANGED], n_next = c->h_counters[C_BU_FOUND];
+                    st.td_steps++; st.edges_examined += m_level; st.td_edges += m_level; st.td_frontier += F;
+                    prevF = F;
+                    cur++;
+                    if (n_next == 0) break;                                     // nothing discovered: the traversal is complete
+                    if (c->h_counters[C_TMP0] > 0) {                            // the list kernel ran level cur (and maybe more)
+                        visited_total += n_next; st.levels++; st.frontier_total += n_next; prevF = n_next;
+                        account_small(n_next);
+                    } else { advance_pending = true; front_valid = true; }      // too many discoveries (or edges) for it: they wait in bm_next
+                    continue;
+                }
                 VGL_TRY(count_frontier());              // ids / offsets of level cur are needed again (bm_front is valid: cheap)
             }
         }
