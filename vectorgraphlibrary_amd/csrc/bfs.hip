@@ -271,11 +271,11 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_expand(int64_t nwords, con
 }
 constexpr int VGL_SMALL_THREADS = 1024;
 constexpr int VGL_SMALL_UNROLL = 4;            // edges per thread and round: their loads / atomics are in flight together
-__global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(const int32_t *ids_in, int32_t F0, int32_t source, const int64_t *rowptr,
+__global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(int32_t *ids_in, int32_t F0, int32_t source, const int64_t *rowptr,
                                                                             const int32_t *adj, uint64_t *visited, uint64_t *next, int32_t *levels,
                                                                             int32_t level0, int64_t cap_m, int64_t *counters, volatile int64_t *host,
                                                                             int64_t seq, unsigned long long *list_count, const int64_t *edge_partials,
-                                                                            int n_partials)
+                                                                            int n_partials, uint64_t *front, int64_t *offs_out, int32_t *tile_first)
 {
     constexpr int NT = VGL_SMALL_THREADS, NW = NT / 64, U = VGL_SMALL_UNROLL;
     __shared__ int32_t s_list[2][VGL_SMALL_F];
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(cons
         s_list[0][i] = v;
         if (list_count) atomicOr((unsigned long long *)&visited[v >> 6], 1ULL << (v & 63));
     }
-    int32_t level = level0, run = 0, last_f = 0;
-    int64_t edges = 0, later_front = 0, first_m = 0;
+    int32_t level = level0, run = 0, last_f = 0, handed = 0;
+    int64_t edges = 0, later_front = 0, first_m = 0, exit_m = 0;
     for (;;) {
         if (!usable) break;                                    // (uniform) empty or overflowed list: nothing is done
         __syncthreads();                                       // the list of this level is complete (and everyone has read the old s_cnt)
@@ -330,13 +330,50 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(cons
 #pragma unroll
         for (int w = 0; w < NW; w++) { if (w < wave) base += s_wave[w]; M += s_wave[w]; }
         if (run == 0) first_m = M;
-        if (M > cap_m) break;                                  // too many edges for one workgroup: the ordinary path takes this level
+        if (M > cap_m) {                                       // too many edges for one workgroup: the ordinary path takes this level
+            // Hand-over: the list IS what that path's count + write passes would produce, so finish their job here -- ids, exact edge
+            // offsets, tile owners, the frontier bitmap (the entry level's bits were taken out below), `next` empty again -- and the
+            // host launches the expand (or the bottom-up step) without a count / host / write round.  Not when the entry frontier
+            // came from vgl_k_bm_expand: its bits in `front` are unknown here.
+            if (run > 0 && !list_count) {
+                __shared__ int64_t s_w64[NW];
+                const int64_t inc64 = vgl_wave_incl_add(mine);
+                if (lane == 63) s_w64[wave] = inc64;
+                __syncthreads();
+                int64_t base64 = 0;
+                exit_m = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) { if (w < wave) base64 += s_w64[w]; exit_m += s_w64[w]; }
+                int64_t eoff = base64 + inc64 - mine;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int i = 2 * tid + k;
+                    const int64_t d = k ? d1 : d0;
+                    if (i < F) {
+                        const int32_t v = s_list[cur][i];
+                        const unsigned long long bit = 1ULL << (v & 63);
+                        ids_in[i] = v; offs_out[i] = eoff;
+                        const int64_t eend = eoff + d;
+                        for (int64_t t = (eoff + VGL_TILE - 1) / VGL_TILE; t < (eend + VGL_TILE - 1) / VGL_TILE; t++) tile_first[t] = i;
+                        if (eoff < eend && eend == exit_m) tile_first[(exit_m + VGL_TILE - 1) / VGL_TILE] = i;
+                        atomicOr((unsigned long long *)&front[v >> 6], bit);
+                        atomicAnd((unsigned long long *)&next[v >> 6], ~bit);
+                        eoff = eend;
+                    }
+                }
+                if (tid == 0) offs_out[F] = exit_m;
+                handed = 1;
+            }
+            break;
+        }
         const int excl = base + inc - (int)capped;
         if (i0 < F) { s_beg[i0] = b0; s_off[i0] = excl; }
         if (i1 < F) { s_beg[i1] = b1; s_off[i1] = excl + (int)d0; }
         if (tid == 0) { s_cnt = 0; s_off[F] = (int)M; }
         if (run > 0 || list_count)                             // these vertices are the frontier now, not discoveries any more
             for (int i = tid; i < F; i += NT) { const int32_t v = s_list[cur][i]; atomicAnd((unsigned long long *)&next[v >> 6], ~(1ULL << (v & 63))); }
+        else                                                   // entry level taken: its bits leave `front` (a hand-over rebuilds it from a list)
+            for (int i = tid; i < F; i += NT) { const int32_t v = s_list[cur][i]; atomicAnd((unsigned long long *)&front[v >> 6], ~(1ULL << (v & 63))); }
         __syncthreads();                                       // offsets staged; (a discovery below can share a word with a bit cleared above)
         const int m = (int)M;
         for (int e0 = 0; e0 < m; e0 += NT * U) {               // uniform trip count
@@ -382,7 +419,7 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(cons
         counters[C_FRONT] = F; counters[C_TMP0] = run; counters[C_EDGES] = edges; counters[C_TMP1] = later_front; counters[C_JUMP] = last_f;
         counters[C_NEIGH] = first_m; counters[C_BU_FOUND] = n_list; counters[C_CHANGED] = bm_edges;
         host[C_FRONT] = F; host[C_TMP0] = run; host[C_EDGES] = edges; host[C_TMP1] = later_front; host[C_JUMP] = last_f; host[C_NEIGH] = first_m;
-        host[C_BU_FOUND] = n_list; host[C_CHANGED] = bm_edges;
+        host[C_BU_FOUND] = n_list; host[C_CHANGED] = bm_edges; host[C_HEAVY] = handed; host[C_BU_EDGES] = exit_m;
         __threadfence_system();
         host[C_NSLOTS] = seq;
         __threadfence_system();
@@ -779,6 +816,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     if (mode == VGL_HIP_BFS_DIRECTION_OPT) small_m = std::min<int64_t>(small_m, (int64_t)V / VGL_DO_ALPHA - 1);
     if (small_m < 64) small_m = 0;                       // not worth a launch of its own
     bool finished = false;
+    bool precounted = false;         // F, M, ids, offs, tile_first of level cur were left by vgl_k_bfs_small_levels: no count, no write pass
     // runs the kernel on the list g->ids[0..F) of level `cur` (or on {source}); returns through C_* what it did
     unsigned long long *list_count = reinterpret_cast<unsigned long long *>(c->d_counters + C_HEAVY);      // slot unused by the fused traversal
     const unsigned bm_blocks = (unsigned)vgl_ceil_div(words, VGL_BLOCK);
@@ -797,7 +835,8 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             vgl_timed_launch tl(c, "bfs_top_down");
             hipLaunchKernelGGL(vgl_k_bfs_small_levels, dim3(1), dim3(VGL_SMALL_THREADS), 0, c->stream, g->ids, listF, src, g->out.rowptr, g->out.adj,
                                g->bm_visited, g->bm_next, d_levels, from_bitmap ? cur + 1 : cur, small_m, c->d_counters, (volatile int64_t *)c->h_counters,
-                               seq, from_bitmap ? list_count : (unsigned long long *)nullptr, (const int64_t *)g->bu_partials, from_bitmap ? (int)bm_blocks : 0);
+                               seq, from_bitmap ? list_count : (unsigned long long *)nullptr, (const int64_t *)g->bu_partials, from_bitmap ? (int)bm_blocks : 0,
+                               g->bm_front, g->offs, g->tile_first);
         }
         VGL_HIP_TRY(hipGetLastError());
         VGL_TRY(vgl_wait_counters(c, seq));
@@ -812,7 +851,10 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         if (run > 1) prevF = c->h_counters[C_JUMP];
         cur += (int32_t)run;
         if (c->h_counters[C_FRONT] == 0) finished = true;                      // the last level run discovered nothing
-        else { advance_pending = true; front_valid = true; }                   // its discoveries wait in bm_next
+        else if (c->h_counters[C_HEAVY] != 0) {                                // handed over: ids / offs / tile_first / bm_front describe level cur
+            F = c->h_counters[C_FRONT]; M = c->h_counters[C_BU_EDGES];
+            precounted = true; front_valid = true; advance_pending = false;
+        } else { advance_pending = true; front_valid = true; }                 // its discoveries wait in bm_next
     };
     if (small_m > 0) {                                                         // level 1 = {source}
         VGL_TRY(small_levels(1, source));
@@ -824,7 +866,9 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     for (;;) {
         if (finished) break;
         counted = false;
-        if (!bottom_up) VGL_TRY(count_frontier());      // after a bottom-up step F is already known (M is not needed to stay bottom-up)
+        const bool ids_ready = precounted;
+        if (precounted) { counted = true; counted_from_bitmap = true; precounted = false; }
+        else if (!bottom_up) VGL_TRY(count_frontier());      // after a bottom-up step F is already known (M is not needed to stay bottom-up)
         if (F == 0) break;
         visited_total += F;
         st.levels++; st.frontier_total += F;
@@ -855,7 +899,8 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         prevF = F;
         if (!bottom_up) {
             if (!counted) VGL_FAIL("bfs_run: internal error (frontier not counted)");
-            if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, false, true, M));
+            if (ids_ready) {}                                   // written by the list kernel
+            else if (counted_from_bitmap) VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, false, true, M));
             else {
                 vgl_pred_equal_i32 pred{d_levels, cur};
                 vgl_timed_launch tl(c, "gnf");
