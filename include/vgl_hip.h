@@ -261,6 +261,15 @@ int vgl_hip_levels_to_bitmap(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_level
 int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *ctx, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
                               uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
                               int64_t *newly_degree);
+/* Sparse exchange of tiny levels (the id-list counterpart of the bitmap exchange of common/mpi_exchange.hpp:222-271):
+ * d_out[0] = number of set bits of the bitmap (may exceed cap), d_out[1 .. 1+cap) = ids of (the first cap of) them, unordered.
+ * Asynchronous on the context's stream. */
+int vgl_hip_bitmap_to_ids(vgl_hip_ctx *ctx, int64_t words, const uint64_t *d_bits, int32_t cap, int32_t *d_out);
+/* vgl_hip_bfs_apply_bitmaps for `parts` id lists of that layout (stride 1 + cap, every count <= cap): unvisited listed vertices get
+ * d_levels = level, their visited bits are set and d_front_bits becomes exactly the set of them.  Synchronises. */
+int vgl_hip_bfs_apply_ids(vgl_hip_ctx *ctx, int32_t V, int parts, int32_t cap, const int32_t *d_lists, int32_t *d_levels, int32_t level,
+                          uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
+                          int64_t *newly_degree);
 int vgl_hip_sssp_init(vgl_hip_ctx *ctx, int32_t V, int32_t source, float *d_dist);
 /* one all-active push relaxation over the owned rows; *changed = 1 if any distance decreased. Synchronises. */
 int vgl_hip_sssp_relax_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, float *d_dist, int *changed);

@@ -60,6 +60,29 @@ class NumpyShardOps:
         self._pack(found, mine)
         return int(fr[self.lo:self.hi].sum()), int(m.sum())
 
+    def new_id_lists(self, parts, cap): return torch.zeros(parts * (1 + cap), dtype=torch.int32)
+
+    def bits_to_ids(self, bits, cap, out):
+        ids = np.nonzero(self._unpack(bits))[0].astype(np.int32)
+        o = out.numpy()
+        o[0] = len(ids)
+        o[1:1 + min(cap, len(ids))] = ids[::-1][:cap]                # any order, any subset beyond cap: take the LAST ones to prove it
+
+    def list_counts(self, lists, parts, cap): return lists.view(parts, 1 + cap)[:, 0].tolist()
+
+    def apply_ids(self, parts, cap, lists, levels, level, visited, front, degrees=None):
+        l = lists.numpy().reshape(parts, 1 + cap)
+        ids = np.unique(np.concatenate([l[p, 1:1 + l[p, 0]] for p in range(parts)])) if parts else np.zeros(0, np.int32)
+        vis = self._unpack(visited)
+        new = ids[~vis[ids]]
+        levels.numpy()[new] = level
+        vis[new] = True
+        self._pack(vis, visited)
+        fr = np.zeros(self.V, bool)
+        fr[new] = True
+        self._pack(fr, front)
+        return int(len(new)), (int(degrees.numpy()[new].sum()) if degrees is not None else 0)
+
     def or_parts(self, parts, bits_in, bits_out):
         bits_out.numpy()[:] = np.bitwise_or.reduce(bits_in.numpy().reshape(parts, -1), axis=0)
 
@@ -93,7 +116,7 @@ class NumpyShardOps:
     def _unpack(self, bits):
         return np.unpackbits(bits.numpy().view(np.uint8), bitorder="little")[:self.V].astype(bool)
 
-    def bfs_step_bu(self, levels, level, visited, front, mine):
+    def bfs_step_bu(self, levels, level, visited, front, mine, want_counts=False):
         """owned unvisited vertices with an in-neighbour in the frontier get level+1 (uses the transposed owned edges)"""
         lv = levels.numpy()
         fr, vis = self._unpack(front), self._unpack(visited)
@@ -102,6 +125,7 @@ class NumpyShardOps:
         found[self.in_dst[m]] = True
         lv[found] = level + 1
         self._pack(found, mine)
+        return (int(found.sum()), int(m.sum())) if want_counts else None
 
     def sssp_init(self, d, source):
         d.fill_(float(FLT_MAX)); d[source] = 0
@@ -197,6 +221,14 @@ def _worker(rank, world, port, results):
     assert (levels_2p.numpy() == levels.numpy()).all(), "two-phase top-down exchange != full-bitmap exchange"
     levels_2p_td, _ = vd.bfs_sharded(eq, source, equal_ranges=True, two_phase=True)          # top-down only: every level two-phase
     assert (levels_2p_td.numpy() == levels.numpy()).all()
+    # sparse exchange of small levels: off, with a bound every level fits (V <= 4096 here), and with a bound only the tiny ones fit
+    for cap in (0, 4096, 8):
+        st = {}
+        lv, _ = vd.bfs_sharded(ops, source, degrees=degrees, edges=len(adj), sparse_cap=cap, stats=st)
+        assert (lv.numpy() == levels.numpy()).all(), f"sparse exchange (cap {cap}) != bitmap exchange"
+        assert (st.get("sparse_levels", 0) > 0) == (cap > 0), (cap, st)
+        lv, _ = vd.bfs_sharded(eq, source, equal_ranges=True, two_phase=True, sparse_cap=cap)
+        assert (lv.numpy() == levels.numpy()).all()
     d, _ = vd.sssp_sharded(ops, source)
     wd, _ = vd.sswp_sharded(ops, source)
     assert (wd.numpy().view(np.int32) == O.sswp_bellman_ford(rowptr, adj, w, source)[0].view(np.int32)).all(), "sharded SSWP != oracle"

@@ -853,3 +853,54 @@ def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
                 assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap, bm)
                 seen.append((st["levels"], st["edges_examined"], st["frontier_total"], st["discovered"], st["td_steps"], st["bu_steps"]))
             assert all(x == seen[0] for x in seen), (source, mode, seen)
+
+
+@pytest.mark.gpu
+def test_sparse_exchange_primitives(ctx):
+    """vgl_hip_bitmap_to_ids / vgl_hip_bfs_apply_ids (id-list exchange of tiny multi-GPU levels) against numpy: counts beyond the
+    cap are reported, lists are a subset of the set bits, duplicates across parts and visited vertices are taken once / not at all"""
+    import torch
+    from vectorgraphlibrary_amd import distributed as vd
+
+    class G:                                        # the two calls only need V and the context
+        pass
+    V = 100003
+    g = G(); g.ctx = ctx; g.V = V
+    ops = vd.HipShardOps(g)
+    rng = np.random.default_rng(5)
+    words = (V + 63) // 64
+
+    def pack(ids):
+        b = np.zeros(words * 64, np.uint8); b[ids] = 1
+        return torch.from_numpy(np.packbits(b, bitorder="little").view(np.int64).copy()).to(ctx.device)
+
+    def unpack(t):
+        return np.nonzero(np.unpackbits(t.cpu().numpy().view(np.uint8), bitorder="little")[:V])[0]
+    for n, cap in ((0, 8), (5, 8), (8, 8), (300, 64), (3000, 4096)):
+        ids = np.sort(rng.choice(V, n, replace=False))
+        out = ops.new_id_lists(1, cap)
+        ops.bits_to_ids(pack(ids), cap, out)
+        ops.sync()
+        o = out.cpu().numpy()
+        assert o[0] == n
+        got = o[1:1 + min(n, cap)]
+        assert len(set(got.tolist())) == len(got) and set(got.tolist()) <= set(ids.tolist())
+        if n <= cap:
+            assert sorted(got.tolist()) == ids.tolist()
+    cap, parts = 64, 3
+    lists = np.zeros((parts, 1 + cap), np.int32)
+    a, b, c = rng.choice(V, 40, replace=False), rng.choice(V, 64, replace=False), np.zeros(0, np.int64)
+    b[:10] = a[:10]                                                 # reported by two ranks
+    for p, l in enumerate((a, b, c)):
+        lists[p, 0] = len(l); lists[p, 1:1 + len(l)] = l
+    already = np.concatenate([a[20:25], rng.choice(V, 1000, replace=False)])
+    visited, front = pack(np.unique(already)), pack(rng.choice(V, 50, replace=False))     # stale frontier bits must disappear
+    levels = torch.full((V,), -1, dtype=torch.int32, device=ctx.device)
+    levels[torch.from_numpy(np.unique(already)).to(ctx.device)] = 3
+    degrees = torch.from_numpy(rng.integers(0, 100, V).astype(np.int32)).to(ctx.device)
+    newly, newdeg = ops.apply_ids(parts, cap, torch.from_numpy(lists.reshape(-1)).to(ctx.device), levels, 7, visited, front, degrees)
+    expect = np.setdiff1d(np.union1d(a, b), already)
+    assert newly == len(expect) and newdeg == int(degrees.cpu().numpy()[expect].sum())
+    assert np.array_equal(unpack(front), expect) and np.array_equal(unpack(visited), np.union1d(expect, already))
+    lv = levels.cpu().numpy()
+    assert (lv[expect] == 7).all() and (lv[np.unique(already)] == 3).all() and (lv == -1).sum() == V - len(expect) - len(np.unique(already))

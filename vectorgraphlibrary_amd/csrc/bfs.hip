@@ -600,6 +600,48 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_advance(int64_t words, uin
     }
 }
 
+// ---- sparse exchange of tiny levels (multi-GPU): ids instead of V-bit bitmaps ----
+// out[0] = number of set bits (may exceed cap), out[1 .. 1+cap) = their ids in no particular order (the first `cap` to arrive)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bitmap_to_ids(int64_t words, const uint64_t *bits, int32_t cap, int32_t *out)
+{
+    const int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x;
+    if (wi >= words) return;
+    uint64_t w = bits[wi];
+    if (!w) return;
+    int pos = atomicAdd(out, (int)__popcll(w));              // one atomic per non-empty word: meant for bitmaps with few bits
+    while (w) {
+        const int b = __ffsll((long long)w) - 1;
+        w &= w - 1;
+        if (pos < cap) out[1 + pos] = (int32_t)((wi << 6) + b);
+        pos++;
+    }
+}
+// `parts` lists of that layout (stride 1 + cap): a vertex reported by several ranks is taken once (claimed on the visited bitmap)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_ids(int32_t V, int parts, int32_t cap, const int32_t *lists, int32_t *levels, int32_t level,
+                                                             uint64_t *visited, uint64_t *front, const int32_t *degrees, int64_t *partials)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    int64_t cnt = 0, deg = 0;
+    const int64_t total = (int64_t)parts * cap;
+    for (int64_t t = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * VGL_BLOCK) {
+        const int p = (int)(t / cap), i = (int)(t % cap);
+        const int32_t *list = lists + (int64_t)p * (1 + cap);
+        if (i >= list[0]) continue;
+        const int32_t v = list[1 + i];
+        if (v < 0 || v >= V) continue;
+        const unsigned long long bit = 1ULL << (v & 63);
+        const unsigned long long old = atomicOr((unsigned long long *)&visited[v >> 6], bit);
+        if (old & bit) continue;
+        levels[v] = level;
+        atomicOr((unsigned long long *)&front[v >> 6], bit);
+        cnt++;
+        if (degrees) deg += degrees[v];
+    }
+    cnt = vgl_block_reduce_add(cnt, s64);
+    deg = vgl_block_reduce_add(deg, s64);
+    if (threadIdx.x == 0) { partials[blockIdx.x * 2] = cnt; partials[blockIdx.x * 2 + 1] = deg; }
+}
+
 // bit v = (levels[v] == level), or (levels[v] != level) when NOT_EQUAL (visited bitmap: level = -1)
 template <bool NOT_EQUAL>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_levels_to_bitmap(int32_t V, const int32_t *levels, int32_t level, uint64_t *bits)
@@ -1017,6 +1059,36 @@ int vgl_hip_levels_to_bitmap(vgl_hip_ctx *c, int32_t V, const int32_t *d_levels,
     if (!c || !d_levels || !d_bits) VGL_FAIL("levels_to_bitmap: null argument");
     hipLaunchKernelGGL(vgl_k_levels_to_bitmap<false>, dim3(vgl_grid(V)), dim3(VGL_BLOCK), 0, c->stream, V, d_levels, level, d_bits);
     VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int vgl_hip_bitmap_to_ids(vgl_hip_ctx *c, int64_t words, const uint64_t *d_bits, int32_t cap, int32_t *d_out)
+{
+    if (!c || !d_bits || !d_out) VGL_FAIL("bitmap_to_ids: null argument");
+    if (words < 0 || cap < 1) VGL_FAIL("bitmap_to_ids: bad size");
+    VGL_HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(int32_t), c->stream));
+    if (words > 0)
+        hipLaunchKernelGGL(vgl_k_bitmap_to_ids, dim3((unsigned)vgl_ceil_div(words, VGL_BLOCK)), dim3(VGL_BLOCK), 0, c->stream, words, d_bits, cap, d_out);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int vgl_hip_bfs_apply_ids(vgl_hip_ctx *c, int32_t V, int parts, int32_t cap, const int32_t *d_lists, int32_t *d_levels, int32_t level,
+                          uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly, int64_t *newly_degree)
+{
+    if (!c || !d_lists || !d_levels || !d_visited_bits || !d_front_bits) VGL_FAIL("bfs_apply_ids: null argument");
+    if (parts < 1 || cap < 1) VGL_FAIL("bfs_apply_ids: parts and cap must be >= 1");
+    const int nb = (int)vgl_grid((int64_t)parts * cap, 256);
+    VGL_TRY(vgl_ensure_partials(c, (size_t)nb * 2 + 2));
+    int64_t *partials = reinterpret_cast<int64_t *>(c->d_partials);
+    VGL_HIP_TRY(hipMemsetAsync(d_front_bits, 0, sizeof(uint64_t) * (size_t)vgl_ceil_div(V, 64), c->stream));      // the new frontier is these vertices only
+    hipLaunchKernelGGL(vgl_k_apply_ids, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, V, parts, cap, d_lists, d_levels, level, d_visited_bits, d_front_bits,
+                       d_degrees, partials);
+    hipLaunchKernelGGL(vgl_k_apply_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, nb, partials, c->d_counters);
+    VGL_HIP_TRY(hipGetLastError());
+    VGL_TRY(vgl_read_counters(c, false));
+    if (newly) *newly = c->h_counters[C_TMP0];
+    if (newly_degree) *newly_degree = c->h_counters[C_TMP1];
     return 0;
 }
 

@@ -97,6 +97,22 @@ class HipShardOps:
                                                   _ptr(front), _ptr(degrees), C.byref(n), C.byref(d)))
         return n.value, d.value
 
+    def new_id_lists(self, parts, cap):
+        return torch.empty(parts * (1 + cap), dtype=torch.int32, device=self.device)
+
+    def bits_to_ids(self, bits, cap, out):
+        """out[0] = number of set bits of `bits` (V bits), out[1:1+cap] = ids of the first cap of them (unordered); asynchronous"""
+        _l.check(self.L.vgl_hip_bitmap_to_ids(self.ctx.h, (self.V + 63) // 64, _ptr(bits), int(cap), _ptr(out)))
+
+    def list_counts(self, lists, parts, cap):
+        return lists.view(parts, 1 + cap)[:, 0].tolist()             # (one small device -> host read)
+
+    def apply_ids(self, parts, cap, lists, levels, level, visited, front, degrees=None):
+        n, d = C.c_int64(), C.c_int64()
+        _l.check(self.L.vgl_hip_bfs_apply_ids(self.ctx.h, self.V, int(parts), int(cap), _ptr(lists), _ptr(levels), int(level), _ptr(visited),
+                                              _ptr(front), _ptr(degrees), C.byref(n), C.byref(d)))
+        return n.value, d.value
+
     def sssp_init(self, d, source):
         _l.check(self.L.vgl_hip_sssp_init(self.ctx.h, self.V, int(source), _ptr(d)))
 
@@ -226,7 +242,7 @@ def _allreduce(t, op, group):
 ALPHA, BETA = 15, 18          # change_state.hpp:5-6
 
 
-def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False, two_phase=None, stats=None):
+def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False, two_phase=None, stats=None, sparse_cap=None):
     """BFS over edge-cut shards; returns the replicated levels array and the number of levels.
     degrees (int32[V] out-degrees of ALL vertices, replicated) + edges (global E) enable direction optimisation: every rank
     evaluates the same switch rule (gpu_change_state, change_state.hpp:100-141) on replicated counters, bottom-up steps scan
@@ -237,6 +253,11 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
     two_phase (needs equal_ranges; default: on for P >= 4): top-down levels, whose discoveries lie anywhere, exchange in two steps
     -- all-to-all of the V/(8P)-byte slices (every rank receives the P versions of ITS slice and ORs them), then all-gather of the
     merged slices -- 2*V/8 bytes per rank instead of P*V/8.
+    sparse_cap (default 4096, env VGL_SHARD_SPARSE_CAP; 0 = off): a top-down level whose frontier has at most this many vertices
+    first tries to exchange its discoveries as id lists -- every rank all-gathers 4 * (1 + cap) bytes instead of V/8 (16 MiB at
+    scale 27), and the merge touches the listed vertices instead of P bitmaps.  When some rank found more than cap vertices (the
+    counts travel with the lists, so every rank sees the same thing) the level falls back to the bitmap exchange.  The first and the
+    last levels of a traversal are of this kind.
     stats (dict, optional): accumulates THIS shard's work -- bu_steps / bu_edges / bu_found, td_steps / td_edges / td_frontier,
     levels -- for the roofline accounting of bench.py; bottom-up steps then wait for their counters (one more host read per level)."""
     P, rank = _world(group)
@@ -258,6 +279,12 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
         raise ValueError("bfs_sharded: two_phase needs equal_ranges and more than one rank")
     if two_phase:
         slices_in, my_slice = ops.new_words(1), ops.new_words(1)[:(hi - lo) // 64]      # P received slices / their OR
+    if sparse_cap is None:
+        sparse_cap = int(os.environ.get("VGL_SHARD_SPARSE_CAP", "4096"))
+    if not (exchanging and hasattr(ops, "bits_to_ids")):
+        sparse_cap = 0
+    if sparse_cap:
+        my_list, all_lists = ops.new_id_lists(1, sparse_cap), ops.new_id_lists(P, sparse_cap)
     visited, front = ops.new_words(1), ops.new_words(1)
     ops.levels_to_bitmap(levels, 1, front)
     visited.copy_(front)
@@ -291,6 +318,21 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
         nlevels += 1
         if stats is not None:
             stats["levels"] = stats.get("levels", 0) + 1
+        merged_sparse = False
+        if exchanging and sparse_cap and not bottom_up and F <= sparse_cap:
+            ops.bits_to_ids(mine, sparse_cap, my_list)
+            ops.sync()
+            dist.all_gather_into_tensor(all_lists, my_list, group=group)
+            if max(ops.list_counts(all_lists, P, sparse_cap)) <= sparse_cap:        # the same P counts on every rank
+                F, M = ops.apply_ids(P, sparse_cap, all_lists, levels, level + 1, visited, front, degrees if direction_opt else None)
+                merged_sparse = True
+                if stats is not None:
+                    stats["sparse_levels"] = stats.get("sparse_levels", 0) + 1
+        if merged_sparse:
+            if F == 0:
+                break
+            level += 1
+            continue
         if exchanging:
             ops.sync()
             if bottom_up and merged is not None:
