@@ -396,16 +396,16 @@ def test_large_scale_properties(kind, scale, ctx):
     for delta in (3.0, 16.0, 1000.0):
         d3, s3 = api.sssp(g, w, source, api.SSSP_DELTA_STEPPING, delta=delta)
         assert torch.equal(d1.view(torch.int32), d3.view(torch.int32)), f"delta-stepping (delta={delta}) changed the distances"
-    # frontier selection of delta-stepping steps: single pass with a packed atomic cursor (steps predicted to be small) against
-    # count + scan + write; forcing either path for every step must not change a bit (VGL_DS_SMALL is read per run)
+    # frontier selection of delta-stepping steps: one pass with a packed atomic reservation per workgroup (the default), count + scan +
+    # write, and the per-tile single pass for steps predicted small; forcing each must not change a bit (the switches are read per run)
     import os
-    for small in ("0", "1000000000"):
-        os.environ["VGL_DS_SMALL"] = small
+    for wide, small in (("1", "4096"), ("0", "0"), ("0", "1000000000")):
+        os.environ["VGL_DS_WIDE"], os.environ["VGL_DS_SMALL"] = wide, small
         try:
             d4, _ = api.sssp(g, w, source, api.SSSP_DELTA_STEPPING, delta=16.0)
         finally:
-            del os.environ["VGL_DS_SMALL"]
-        assert torch.equal(d1.view(torch.int32), d4.view(torch.int32)), f"VGL_DS_SMALL={small}"
+            del os.environ["VGL_DS_SMALL"], os.environ["VGL_DS_WIDE"]
+        assert torch.equal(d1.view(torch.int32), d4.view(torch.int32)), f"VGL_DS_WIDE={wide} VGL_DS_SMALL={small}"
     assert s1["edges_relaxed"] <= s2["edges_relaxed"]
     fin = d1[csr_src] < 3.0e38
     cand = d1[csr_src][fin] + w[fin]

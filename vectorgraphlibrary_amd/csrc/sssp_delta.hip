@@ -288,9 +288,80 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_select(int32_t nrows, int3
         else for (int j = 0; j < nvalid; j++) state[v0 + j] = (uint8_t)(st_new >> (8 * j));
     }
 }
+// The same for steps of ANY size: a workgroup owns 8 consecutive vertex tiles (1024 workgroups for 2^24 vertices, so at most that
+// many same-address atomics, ~12 us even when every workgroup schedules rows), counts them, reserves once and writes ids / offs
+// and -- every scheduled row knows its own edge range -- the tile owners, which saves the tile_first launch too (the owner of the
+// last edge is found by vgl_k_ds_select_finish).  Replaces count + scan + write + tile_first: two launches instead of four and one
+// pass over state / dist instead of two.
+constexpr int VGL_DS_WIDE_TILES = 4;           // vertex tiles per workgroup: 2048 workgroups for 2^24 vertices (8: too few wavefronts in flight, 2: twice the atomics)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_select_wide(int32_t nrows, int32_t row_base, const int64_t *prow, uint8_t *state, const float *dist,
+                                                                  uint8_t bit, float T, unsigned long long *cursor, int32_t *blk_aux, int32_t *ids,
+                                                                  int64_t *offs, int32_t *tile_first, int ntiles)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    __shared__ int s32[VGL_WAVES];
+    __shared__ unsigned long long s_base;
+    // a thread takes the same 8 rows of each of the workgroup's tiles; the output order inside the workgroup is thread-major (any
+    // order will do, the order between workgroups is arbitrary anyway), so ONE scan over the workgroup places everything
+    const int t_lo = blockIdx.x * VGL_DS_WIDE_TILES;
+    uint32_t bits[VGL_DS_WIDE_TILES];
+    uint64_t st8[VGL_DS_WIDE_TILES];
+    int cnt = 0, aux_cnt = 0;
+    int64_t deg = 0;
+#pragma unroll
+    for (int k = 0; k < VGL_DS_WIDE_TILES; k++) {
+        const int32_t r0 = (t_lo + k) * VGL_TILE + threadIdx.x * VGL_EPT;
+        bits[k] = 0; st8[k] = 0;
+        if (t_lo + k < ntiles && r0 < nrows) {
+            uint32_t aux;
+            bits[k] = vgl_ds_bits8(state, dist, row_base + r0, min(VGL_EPT, nrows - r0), bit, T, &aux, &st8[k]);
+            cnt += __popc(bits[k]); aux_cnt += __popc(aux);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VGL_DS_WIDE_TILES; k++)
+        if (bits[k]) {
+            const int32_t r0 = (t_lo + k) * VGL_TILE + threadIdx.x * VGL_EPT;
+            for (int j = 0; j < VGL_EPT; j++)
+                if ((bits[k] >> j) & 1) deg += vgl_ds_degree(prow, r0 + j);
+        }
+    const int a_blk = vgl_block_reduce_add(aux_cnt, s32);
+    int c_blk; int64_t d_blk;
+    int pos = vgl_block_excl_add(cnt, s32, &c_blk);
+    int64_t eoff = vgl_block_excl_add(deg, s64, &d_blk);
+    if (threadIdx.x == 0) {
+        blk_aux[blockIdx.x] = a_blk;
+        s_base = c_blk ? atomicAdd(cursor, ((unsigned long long)c_blk << VGL_DS_EDGE_BITS) | (unsigned long long)d_blk) : 0ULL;
+    }
+    __syncthreads();
+    if (c_blk == 0) return;                                    // the same value in every thread
+    pos += (int)(s_base >> VGL_DS_EDGE_BITS);
+    eoff += (int64_t)(s_base & ((1ULL << VGL_DS_EDGE_BITS) - 1ULL));
+#pragma unroll
+    for (int k = 0; k < VGL_DS_WIDE_TILES; k++) {
+        if (!bits[k]) continue;
+        const int32_t r0 = (t_lo + k) * VGL_TILE + threadIdx.x * VGL_EPT;
+        const int nvalid = min(VGL_EPT, nrows - r0);
+        uint64_t st_new = st8[k];
+        for (int j = 0; j < VGL_EPT; j++) {
+            if ((bits[k] >> j) & 1) {
+                ids[pos] = row_base + r0 + j;
+                offs[pos] = eoff;
+                const int64_t eend = eoff + vgl_ds_degree(prow, r0 + j);
+                for (int64_t tt = (eoff + VGL_TILE - 1) / VGL_TILE; tt < (eend + VGL_TILE - 1) / VGL_TILE; tt++) tile_first[tt] = pos;
+                eoff = eend;
+                pos++;
+                st_new &= ~((uint64_t)bit << (8 * j));
+            }
+        }
+        const int32_t v0 = row_base + r0;
+        if (nvalid == 8) *reinterpret_cast<uint64_t *>(state + v0) = st_new;
+        else for (int j = 0; j < nvalid; j++) state[v0 + j] = (uint8_t)(st_new >> (8 * j));
+    }
+}
 // totals of a SMALL step where the scan kernel leaves them, and the cursor back to zero
 __global__ __launch_bounds__(VGL_DS_SCAN_THREADS) void vgl_k_ds_select_finish(int ntiles, const int32_t *vt_aux, unsigned long long *cursor, int64_t *counters,
-                                                                              int64_t *offs)
+                                                                              int64_t *offs, int32_t *tile_first)
 {
     __shared__ int s_a[VGL_DS_SCAN_THREADS / 64];
     int a = 0;
@@ -306,6 +377,11 @@ __global__ __launch_bounds__(VGL_DS_SCAN_THREADS) void vgl_k_ds_select_finish(in
         counters[C_FRONT] = F; counters[C_NEIGH] = M; counters[C_TMP1] = atot;
         offs[F] = M;
         *cursor = 0ULL;
+        if (tile_first && M > 0) {                             // owner of the last edge: the last position whose range is not empty
+            int64_t lo = 0, hi = F;                            // offs is ascending over [0, F]; largest p with offs[p] < M
+            while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (offs[mid] < M) lo = mid; else hi = mid; }
+            tile_first[(M + VGL_TILE - 1) / VGL_TILE] = (int32_t)lo;
+        }
     }
 }
 
@@ -645,6 +721,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     // dense = sweep the whole part as static tiles (rows marked in p->active) instead of walking a compacted frontier: chosen by
     // the caller from a PREDICTION of the step's size, so a wrong guess only costs time
     unsigned long long *cursor = reinterpret_cast<unsigned long long *>(p->partials + 1024 + VGL_DS_BLOCKS + 1);
+    const bool wide_select = getenv("VGL_DS_WIDE") ? atoi(getenv("VGL_DS_WIDE")) != 0 : true;     // 0: count + scan + write (+ the small-step selection)
     auto step = [&](uint8_t bit, bool dense, bool small) -> int {
         const int k = bit == 1 ? 0 : 1;                     // which part this step walks
         if (dense && p->part[k].ntiles > 0) {
@@ -656,10 +733,17 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
             hipLaunchKernelGGL(vgl_k_ds_relax_static, dim3((unsigned)p->part[k].ntiles), dim3(VGL_BLOCK), 0, st, p->prow[k], p->padj[k], p->pw[k],
                                p->part[k].tile_row, p->part[k].edges, g->row_begin, p->active, T, d_dist, p->state, near_partials);
         } else {
-            if (small) {
+            if (wide_select) {
+                const int nblk = (int)vgl_ceil_div((int64_t)nvt, VGL_DS_WIDE_TILES);
+                hipLaunchKernelGGL(vgl_k_ds_select_wide, dim3(nblk), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist, bit, T,
+                                   cursor, p->vt_aux, g->ids, g->offs, g->tile_first, (int)nvt);
+                hipLaunchKernelGGL(vgl_k_ds_select_finish, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, nblk, p->vt_aux, cursor, c->d_counters, g->offs,
+                                   g->tile_first);
+            } else if (small) {
                 hipLaunchKernelGGL(vgl_k_ds_select, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist, bit, T, cursor,
                                    p->vt_aux, g->ids, g->offs);
-                hipLaunchKernelGGL(vgl_k_ds_select_finish, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, (int)g->nvtiles, p->vt_aux, cursor, c->d_counters, g->offs);
+                hipLaunchKernelGGL(vgl_k_ds_select_finish, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, (int)g->nvtiles, p->vt_aux, cursor, c->d_counters, g->offs,
+                                   (int32_t *)nullptr);
             } else {
                 hipLaunchKernelGGL(vgl_k_ds_count, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
                                    bit, T, g->vt_cnt, g->vt_deg, p->vt_aux);
@@ -668,7 +752,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
                 hipLaunchKernelGGL(vgl_k_ds_write, dim3(nvt), dim3(VGL_BLOCK), 0, st, g->nrows, g->row_begin, p->prow[k], p->state, d_dist,
                                    bit, T, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
             }
-            hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
+            if (!wide_select) hipLaunchKernelGGL(vgl_k_ds_tile_first, dim3(1024), dim3(VGL_BLOCK), 0, st, c->d_counters, g->offs, g->tile_first);
             vgl_timed_launch tl(c, "sssp_relax");
             hipLaunchKernelGGL(vgl_k_ds_relax, dim3(VGL_DS_BLOCKS), dim3(VGL_BLOCK), 0, st, c->d_counters, g->ids, g->offs, g->tile_first,
                                p->prow[k], p->padj[k], p->pw[k], g->row_begin, T, d_dist, p->state, near_partials);
