@@ -41,7 +41,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_hits_scale(int32_t V, double 
 static int vgl_hits_half_step(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir, const double *x, double *out)
 {
     VGL_TRY(vgl_pull_find_hubs(c, g, dir));
-    const unsigned nblk = (unsigned)vgl_ceil_div(g->nrows, VGL_BLOCK);
+    const unsigned nblk = (unsigned)dir.pull_nblk;
     const int nparts = (int)nblk + dir.hub_blocks;
     VGL_TRY(vgl_ensure_partials(c, (size_t)nparts + 2));
     double *norm = c->d_partials + nparts;
@@ -50,7 +50,7 @@ static int vgl_hits_half_step(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir
         const vgl_hits_epilogue epi{out};
         hipLaunchKernelGGL((vgl_k_pull_sum<double, false, true, vgl_hits_epilogue>), dim3(nblk + dir.hub_blocks), dim3(VGL_BLOCK), 0, c->stream,
                            g->nrows, g->row_begin, dir.rowptr, dir.adj, x, epi, dir.hub_blocks, (const int32_t *)dir.hub_rows,
-                           (const int32_t *)(dir.hub_rows + dir.nhubs), c->d_partials);
+                           (const int32_t *)(dir.hub_rows + dir.nhubs), c->d_partials, (const int32_t *)dir.pull_blk_row);
     }
     hipLaunchKernelGGL(vgl_k_hits_norm, dim3(1), dim3(VGL_BLOCK), 0, c->stream, nparts, c->d_partials, norm);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, vgl_ceil_div(g->V, VGL_BLOCK)));

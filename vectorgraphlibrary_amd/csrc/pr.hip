@@ -178,6 +178,35 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
     VGL_HIP_TRY(hipFree(d_rows));
     VGL_HIP_TRY(hipFree(d_deg));
     VGL_HIP_TRY(hipFree(d_count));
+    // row blocks of the ordinary workgroups: every aligned group of 256 rows is cut into 1, 2, 4, ... 32 equal parts until a part
+    // holds about VGL_PULL_BLOCK_EDGES edges (hub rows count too: they only make their neighbourhood's parts smaller)
+    {
+        const int32_t nrows = g->nrows;
+        const int64_t ngroups = vgl_ceil_div(nrows, VGL_BLOCK);
+        std::vector<int64_t> gstart((size_t)ngroups + 1);
+        {   // row offsets at the group boundaries (one strided device -> host copy)
+            std::vector<int64_t> tmp((size_t)ngroups + 1);
+            VGL_HIP_TRY(hipMemcpy2DAsync(tmp.data(), sizeof(int64_t), dir.rowptr, sizeof(int64_t) * VGL_BLOCK, sizeof(int64_t), (size_t)ngroups,
+                                         hipMemcpyDeviceToHost, c->stream));
+            VGL_HIP_TRY(hipMemcpyAsync(tmp.data() + ngroups, dir.rowptr + nrows, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+            VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+            gstart.swap(tmp);
+        }
+        std::vector<int32_t> blk_row;
+        blk_row.reserve((size_t)ngroups + 64);
+        for (int64_t gi = 0; gi < ngroups; gi++) {
+            const int32_t r0 = (int32_t)(gi * VGL_BLOCK), r1 = (int32_t)std::min<int64_t>(nrows, (gi + 1) * VGL_BLOCK);
+            const int64_t e = gstart[(size_t)gi + 1] - gstart[(size_t)gi];
+            int parts = 1;
+            while (parts < 32 && e > VGL_PULL_BLOCK_EDGES * parts && (r1 - r0) >= 2 * parts) parts *= 2;
+            const int32_t step = (int32_t)vgl_ceil_div(r1 - r0, parts);
+            for (int32_t r = r0; r < r1; r += step) blk_row.push_back(r);
+        }
+        blk_row.push_back(nrows);
+        dir.pull_nblk = (int)blk_row.size() - 1;
+        VGL_HIP_TRY(hipMalloc((void **)&dir.pull_blk_row, sizeof(int32_t) * blk_row.size()));
+        VGL_TRY(vgl_hip_memcpy_h2d(c, dir.pull_blk_row, blk_row.data(), sizeof(int32_t) * blk_row.size()));
+    }
     return 0;
 }
 
@@ -188,8 +217,8 @@ static int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *ind
     const float d = 0.85f;
     const float k = (float)((1.0 - (double)d) / (double)((float)V));       // pr.hpp:37-38
     const int npart = (int)vgl_grid3(V, 1024);
-    const unsigned nblk = (unsigned)vgl_ceil_div(g->nrows, VGL_BLOCK);
     VGL_TRY(vgl_pull_find_hubs(c, g, g->out));
+    const unsigned nblk = (unsigned)g->out.pull_nblk;
     VGL_TRY(vgl_ensure_partials(c, (size_t)npart + 8));
     float *dangling = reinterpret_cast<float *>(c->d_partials + npart);    // one slot after the prepare partials
     hipLaunchKernelGGL(vgl_k_pr_prepare, dim3(npart), dim3(VGL_BLOCK), 0, c->stream, V, indeg, rdeg, ranks, contrib, c->d_partials);
@@ -200,7 +229,7 @@ static int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *ind
         const vgl_pr_epilogue epi{dangling, k, d, ranks_out};
         hipLaunchKernelGGL((vgl_k_pull_sum<float, true, false, vgl_pr_epilogue>), dim3(nblk + hub_blocks), dim3(VGL_BLOCK), 0, c->stream, g->nrows,
                            g->row_begin, g->out.rowptr, g->out.adj, (const float *)contrib, epi, hub_blocks, (const int32_t *)g->out.hub_rows,
-                           (const int32_t *)(g->out.hub_rows + g->out.nhubs), (double *)nullptr);
+                           (const int32_t *)(g->out.hub_rows + g->out.nhubs), (double *)nullptr, (const int32_t *)g->out.pull_blk_row);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;

@@ -20,6 +20,7 @@
 constexpr int VGL_PULL_HUB_DEGREE = 512;
 constexpr int VGL_PULL_HUB_BATCH = 512;
 constexpr int VGL_PULL_HUB_BLOCKS = 256;      // one per CU
+constexpr int64_t VGL_PULL_BLOCK_EDGES = 16384; // edges per ordinary workgroup (8 tiles) before its 256 rows are split further
 
 // lists the hubs of direction `d` (rows with >= VGL_PULL_HUB_DEGREE edges) grouped per wavefront; lazy, once per graph + direction
 int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &d);
@@ -95,11 +96,15 @@ __device__ __forceinline__ void vgl_pull_hub_waves(T *s_vals, const int32_t *hub
     }
 }
 
-// grid = hub_blocks + ceil(nrows / 256) workgroups.  SUMSQ: sumsq_partials[blockIdx.x] = sum over this workgroup's rows of sum^2 (f64)
+// Ordinary workgroups own the rows [blk_row[b], blk_row[b + 1]): at most 256 of them and -- the point -- about VGL_PULL_BLOCK_EDGES
+// edges.  A workgroup walks its rows' edges tile by tile and in every tile the longest row slice is a serial chain, so with fixed
+// 256-row workgroups the first ones of a degree-sorted graph (256 rows of just under VGL_PULL_HUB_DEGREE edges: 64 tiles, each with
+// a ~500-step chain) were the launch's critical path below ~2^21 vertices (RMAT-18: 0.7 ms degree-sorted against 0.3 ms unsorted).
+// grid = hub_blocks + (number of row blocks) workgroups.  SUMSQ: sumsq_partials[blockIdx.x] = sum over this workgroup's rows of sum^2 (f64)
 template <class T, bool SKIP_SELF, bool SUMSQ, class Epi>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj,
                                                             const T *x, Epi epi, int hub_blocks, const int32_t *hub_rows,
-                                                            const int32_t *hub_off, double *sumsq_partials)
+                                                            const int32_t *hub_off, double *sumsq_partials, const int32_t *blk_row)
 {
     __shared__ T s_val[VGL_TILE];                       // ordinary rows: staged values; hub wavefronts: 4 x 512 values
     __shared__ int32_t s_dst[VGL_TILE];
@@ -110,12 +115,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32
         vgl_pull_hub_waves<T, SKIP_SELF, SUMSQ>(s_val, hub_rows, hub_off, row_base, rowptr, adj, x, epi, sumsq);
     } else {
         const int32_t blk = (int32_t)blockIdx.x - hub_blocks;
-        const int32_t r = blk * VGL_BLOCK + threadIdx.x;
-        const int32_t r_lo = blk * VGL_BLOCK;
-        const int32_t r_hi = min(nrows, r_lo + VGL_BLOCK);
+        const int32_t r_lo = blk_row[blk];
+        const int32_t r_hi = blk_row[blk + 1];                          // <= r_lo + VGL_BLOCK
+        const int32_t r = r_lo + threadIdx.x;
         const int64_t E0 = rowptr[r_lo], E1 = rowptr[r_hi];
         int64_t seg_b = 0, seg_e = 0;
-        if (r < nrows) { seg_b = rowptr[r]; seg_e = rowptr[r + 1]; }
+        if (r < r_hi) { seg_b = rowptr[r]; seg_e = rowptr[r + 1]; }
         const bool hub = (seg_e - seg_b) >= VGL_PULL_HUB_DEGREE;      // summed by the hub wavefronts
         const int32_t self = row_base + r;
         T acc = (T)0;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32
             }
             base += n;
         }
-        if (r < nrows && !hub) {
+        if (r < r_hi && !hub) {
             epi(self, acc);
             if (SUMSQ) sumsq = (double)acc * (double)acc;
         }
