@@ -48,7 +48,41 @@
 #define __VGL_REDUCE_DBL_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->double
 #define VGL_GRAPH_ABSTRACTIONS GraphAbstractionsHIP
 #define VGL_FRONTIER VGL_Frontier
-#define VGL_SRC_ID_ADD(a, b) (atomicAdd(&(a), (b)))
+// VGL_SRC_ID_ADD (architecture_independent_api.h:48): "+= into the source vertex's slot" from an edge operator.  The edges of a row
+// sit in consecutive lanes, so when a wavefront walks a hub every lane adds to the SAME address and plain atomics serialise (~12 ns
+// each: 0.7 ms per PageRank iteration for one 60 K-edge hub).  When all active lanes agree on the address the wavefront sums its
+// values in lane order (v_readlane, a uniform loop) and issues one atomic; otherwise every lane adds on its own.
+template <class T> __device__ __forceinline__ T vgl_lane_value(T v, int l);
+template <> __device__ __forceinline__ float vgl_lane_value<float>(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+template <> __device__ __forceinline__ int vgl_lane_value<int>(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+template <> __device__ __forceinline__ double vgl_lane_value<double>(double v, int l)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <class T, class U>
+__device__ __forceinline__ void vgl_src_id_add(T &slot, U value)
+{
+    T *addr = &slot;
+    const T val = (T)value;
+    const unsigned long long active = __ballot(1);
+    const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)active) - 1);
+    const unsigned long long mine = (unsigned long long)(uintptr_t)addr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, leader), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), leader);
+    const bool same = mine == (((unsigned long long)hi << 32) | lo);
+    if (__ballot(same) == active && __popcll(active) >= 8) {
+        T sum = (T)0;
+        unsigned long long m = active;
+        while (m) {                                            // wave-uniform loop; only active lanes are read
+            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            m &= m - 1;
+            sum += vgl_lane_value<T>(val, l);
+        }
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(addr, sum);
+    } else atomicAdd(addr, val);
+}
+#define VGL_SRC_ID_ADD(a, b) (vgl_src_id_add((a), (b)))
 #define VGL_INC(a) (atomicAdd(&(a), 1))
 #define VGL_LAMBDA_CAP(a) a
 
