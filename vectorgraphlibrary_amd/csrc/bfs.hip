@@ -449,10 +449,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
     if (threadIdx.x == 0) s_nheavy = 0;
     __syncthreads();
     int64_t found_cnt = 0, probes = 0;
-    const int32_t r_begin = blockIdx.x * chunk;                      // chunk is a multiple of VGL_BLOCK
-    const int32_t r_end = min(r_begin + chunk, (nrows + 63) & ~63);
-    int32_t *my_heavy = heavy + r_begin;                             // at most `chunk` deferrals per workgroup
-    for (int32_t r = r_begin + threadIdx.x; r < r_end; r += VGL_BLOCK) {
+    // Rows are dealt to the workgroups in slices of 256 (slice s goes to workgroup s mod VGL_BU_BLOCKS): candidates cluster -- in a
+    // degree-sorted graph the unvisited vertices of the later levels are the low-degree tail -- and contiguous chunks left most
+    // workgroups idle while a few did the level.  The deferred list of a workgroup still has room for all of its rows.
+    const int32_t r_round = (nrows + 63) & ~63;
+    int32_t *my_heavy = heavy + (int64_t)blockIdx.x * chunk;         // at most `chunk` deferrals per workgroup
+    for (int32_t r = (int32_t)blockIdx.x * VGL_BLOCK + threadIdx.x; r < r_round; r += VGL_BU_BLOCKS * VGL_BLOCK) {
         const int32_t v = row_base + r;
         const uint64_t cand_word = ~visited[v >> 6] & in_nz[v >> 6];       // wave-uniform
         bool found = false, defer = false;

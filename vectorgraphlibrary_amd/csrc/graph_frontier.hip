@@ -202,10 +202,10 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_TRY(vgl_alloc(&g->vt_deg, (size_t)g->nvtiles));
     VGL_TRY(vgl_alloc(&g->vt_deg_off, (size_t)g->nvtiles));
     VGL_TRY(vgl_alloc(&g->tile_first, (size_t)g->out.ntiles + 2));
-    VGL_TRY(vgl_alloc(&g->heavy, (size_t)g->nrows + 2048 * VGL_BLOCK));
-    VGL_TRY(vgl_alloc(&g->heavy_cnt, (size_t)2048));
-    VGL_TRY(vgl_alloc(&g->heavy_off, (size_t)2049));
-    VGL_TRY(vgl_alloc(&g->bu_partials, (size_t)2048 * 4));
+    VGL_TRY(vgl_alloc(&g->heavy, (size_t)g->nrows + 4096 * VGL_BLOCK));
+    VGL_TRY(vgl_alloc(&g->heavy_cnt, (size_t)4096));
+    VGL_TRY(vgl_alloc(&g->heavy_off, (size_t)4097));
+    VGL_TRY(vgl_alloc(&g->bu_partials, (size_t)4096 * 4));
     VGL_TRY(vgl_alloc(&g->tickets, (size_t)3 * VGL_TICKET_WORDS));
     VGL_HIP_TRY(hipMemsetAsync(g->tickets, 0, 3 * VGL_TICKET_WORDS * sizeof(uint32_t), c->stream));
     VGL_TRY(vgl_alloc(&g->epoch, (size_t)V));
