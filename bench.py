@@ -127,7 +127,7 @@ def main():
         dt = time.perf_counter() - t0
         # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----
         kern = {}
-        for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "gnf"):
+        for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "bfs_small_levels", "bfs_bitmap_expand", "gnf"):
             n, ms = ctx.timing_get(name)
             kern[name] = {"launches": n, "total_ms": round(ms, 4)}
         ctx.timing(False)
@@ -336,7 +336,7 @@ def main():
             vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, stats=st)
         barrier()
         kern = {}
-        for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "gnf"):
+        for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "bfs_small_levels", "bfs_bitmap_expand", "gnf"):
             n, ms = ctx.timing_get(name)
             kern[name] = {"launches": n, "total_ms": round(ms, 4)}
         ctx.timing(False)

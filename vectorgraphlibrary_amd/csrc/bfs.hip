@@ -870,13 +870,13 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     // from_bitmap: level `cur` is expanded from bm_front by vgl_k_bm_expand first, the list kernel starts at level cur + 1
     auto small_levels = [&](int32_t listF, int32_t src, bool from_bitmap = false) -> int {
         if (from_bitmap) {
-            vgl_timed_launch tl(c, "bfs_top_down");
+            vgl_timed_launch tl(c, "bfs_bitmap_expand");
             hipLaunchKernelGGL(vgl_k_bm_expand, dim3(bm_blocks), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_front, g->out.rowptr, g->out.adj, g->bm_visited,
                                g->bm_next, d_levels, cur + 1, g->ids, list_count, (int32_t)VGL_SMALL_F, g->bu_partials);
         }
         const int64_t seq = vgl_next_seq(c);
         {
-            vgl_timed_launch tl(c, "bfs_top_down");
+            vgl_timed_launch tl(c, "bfs_small_levels");
             hipLaunchKernelGGL(vgl_k_bfs_small_levels, dim3(1), dim3(VGL_SMALL_THREADS), 0, c->stream, g->ids, listF, src, g->out.rowptr, g->out.adj,
                                g->bm_visited, g->bm_next, d_levels, from_bitmap ? cur + 1 : cur, small_m, c->d_counters, (volatile int64_t *)c->h_counters,
                                seq, from_bitmap ? list_count : (unsigned long long *)nullptr, (const int64_t *)g->bu_partials, from_bitmap ? (int)bm_blocks : 0,
