@@ -6,7 +6,8 @@
 //   hub[v]  = sum over the OUTGOING neighbours w of auth[w]       (scatter direction)
 //   hub    /= sqrt(sum_v hub[v]^2)
 // The per-vertex sums are vgl_k_pull_sum<double> (vgl_pull.h): f64 `+=` chains in adjacency order, the same order as the
-// reference's sequential checker (hits.hpp:117-160), including the hub schedule for rows with >= 512 edges.  The sum of squares
+// reference's sequential checker (hits.hpp:117-160), for rows below 512 edges; longer rows are summed in 4096-entry chunks (per-lane
+// partial sums, fixed butterfly, chunk sums added in order): deterministic, within ~1e-15 of the sequential order.  The sum of squares
 // is accumulated per workgroup by the same launch and folded in a fixed order (the reference's OpenMP reduction order is
 // unspecified), so a whole run is deterministic and agrees with seq_hits to ~1e-15 relative; the tests use 1e-12.
 // Nothing is read back by the host between steps.  Algorithmic bytes per step: 2 * (12 B/edge + 8 + 16 + 16 B/vertex).
@@ -42,15 +43,22 @@ static int vgl_hits_half_step(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir
 {
     VGL_TRY(vgl_pull_find_hubs(c, g, dir));
     const unsigned nblk = (unsigned)dir.pull_nblk;
-    const int nparts = (int)nblk + dir.hub_blocks;
+    const int nfinish = (int)vgl_ceil_div((int64_t)dir.n_hub_list, VGL_BLOCK);
+    const int hub_blocks = (int)vgl_ceil_div((int64_t)dir.n_hub_chunks, VGL_WAVES);      // unordered hub sums: one chunk per wavefront, as many workgroups as it takes
+    const int nparts = (int)nblk + hub_blocks + nfinish;
     VGL_TRY(vgl_ensure_partials(c, (size_t)nparts + 2));
     double *norm = c->d_partials + nparts;
     {
         vgl_timed_launch tl(c, "hits_pull");
         const vgl_hits_epilogue epi{out};
-        hipLaunchKernelGGL((vgl_k_pull_sum<double, false, true, vgl_hits_epilogue>), dim3(nblk + dir.hub_blocks), dim3(VGL_BLOCK), 0, c->stream,
-                           g->nrows, g->row_begin, dir.rowptr, dir.adj, x, epi, dir.hub_blocks, (const int32_t *)dir.hub_rows,
-                           (const int32_t *)(dir.hub_rows + dir.nhubs), c->d_partials, (const int32_t *)dir.pull_blk_row);
+        hipLaunchKernelGGL((vgl_k_pull_sum<double, false, true, vgl_hits_epilogue, false>), dim3(nblk + hub_blocks), dim3(VGL_BLOCK), 0, c->stream,
+                           g->nrows, g->row_begin, dir.rowptr, dir.adj, x, epi, hub_blocks, (const int32_t *)dir.hub_rows,
+                           (const int32_t *)(dir.hub_rows + dir.nhubs), c->d_partials, (const int32_t *)dir.pull_blk_row,
+                           (const int32_t *)dir.hub_chunks, dir.n_hub_chunks, dir.hub_chunk_sums);
+        if (nfinish > 0)                      // the hubs: chunk sums in order, results, their share of the sum of squares
+            hipLaunchKernelGGL((vgl_k_pull_hub_finish<double, true, vgl_hits_epilogue>), dim3(nfinish), dim3(VGL_BLOCK), 0, c->stream, dir.n_hub_list,
+                               (const int32_t *)(dir.hub_chunks + 2 * (size_t)dir.n_hub_chunks), g->row_begin, (const double *)dir.hub_chunk_sums, epi,
+                               c->d_partials + nblk + hub_blocks);
     }
     hipLaunchKernelGGL(vgl_k_hits_norm, dim3(1), dim3(VGL_BLOCK), 0, c->stream, nparts, c->d_partials, norm);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, vgl_ceil_div(g->V, VGL_BLOCK)));

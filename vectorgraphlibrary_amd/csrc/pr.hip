@@ -174,6 +174,22 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
         }
         packed[n + (size_t)W] = (int32_t)pos;
         VGL_TRY(vgl_hip_memcpy_h2d(c, dir.hub_rows, packed.data(), sizeof(int32_t) * packed.size()));
+        // chunk list of the unordered variant: hubs in row order, every hub cut into VGL_PULL_CHUNK-entry chunks
+        std::vector<int32_t> by_row(n);
+        for (size_t i = 0; i < n; i++) by_row[i] = (int32_t)i;
+        std::sort(by_row.begin(), by_row.end(), [&](int32_t x, int32_t y) { return rows[x] < rows[y]; });
+        std::vector<int32_t> chunks, hubs;
+        for (size_t i = 0; i < n; i++) {
+            const int32_t r = rows[by_row[i]], dg = deg[by_row[i]];
+            const int32_t nc = (int32_t)vgl_ceil_div((int64_t)dg, VGL_PULL_CHUNK);
+            hubs.push_back(r); hubs.push_back((int32_t)(chunks.size() / 2)); hubs.push_back(nc);
+            for (int32_t k = 0; k < nc; k++) { chunks.push_back(r); chunks.push_back(k); }
+        }
+        dir.n_hub_chunks = (int)(chunks.size() / 2); dir.n_hub_list = (int)n;
+        chunks.insert(chunks.end(), hubs.begin(), hubs.end());              // [2 * n_chunks | 3 * n_hubs]
+        VGL_HIP_TRY(hipMalloc((void **)&dir.hub_chunks, sizeof(int32_t) * chunks.size()));
+        VGL_TRY(vgl_hip_memcpy_h2d(c, dir.hub_chunks, chunks.data(), sizeof(int32_t) * chunks.size()));
+        VGL_HIP_TRY(hipMalloc((void **)&dir.hub_chunk_sums, sizeof(double) * (size_t)std::max(1, dir.n_hub_chunks)));
     }
     VGL_HIP_TRY(hipFree(d_rows));
     VGL_HIP_TRY(hipFree(d_deg));

@@ -67,6 +67,10 @@ struct vgl_dir_csr {                 // one direction of the graph (borrowed) + 
     int32_t *hub_rows = nullptr;     // pull sums (PageRank, HITS): rows with >= 512 edges grouped per wavefront + offsets (lazy)
     int32_t nhubs = 0;
     int hub_blocks = 0;              // workgroups of the pull kernel that run the hub schedule
+    int32_t *hub_chunks = nullptr;   // unordered hub sums (HITS): per chunk (row, first entry - row start in units of VGL_PULL_CHUNK); then, per hub in
+                                     // row order, (row, first chunk, chunks) triples -- see vgl_pull_find_hubs
+    int n_hub_chunks = 0, n_hub_list = 0;
+    double *hub_chunk_sums = nullptr;
     int32_t *pull_blk_row = nullptr; // pull sums: first row of every ordinary workgroup (+ end): <= 256 rows and ~16 K edges each (lazy)
     int pull_nblk = 0;
 };

@@ -20,6 +20,7 @@
 constexpr int VGL_PULL_HUB_DEGREE = 512;
 constexpr int VGL_PULL_HUB_BATCH = 512;
 constexpr int VGL_PULL_HUB_BLOCKS = 256;      // one per CU
+constexpr int VGL_PULL_CHUNK = 4096;         // unordered hub sums: entries per chunk (one wavefront, 16 trips of 4 x 64 gathers)
 constexpr int64_t VGL_PULL_BLOCK_EDGES = 16384; // edges per ordinary workgroup (8 tiles) before its 256 rows are split further
 
 // lists the hubs of direction `d` (rows with >= VGL_PULL_HUB_DEGREE edges) grouped per wavefront; lazy, once per graph + direction
@@ -100,21 +101,81 @@ __device__ __forceinline__ void vgl_pull_hub_waves(T *s_vals, const int32_t *hub
 // edges.  A workgroup walks its rows' edges tile by tile and in every tile the longest row slice is a serial chain, so with fixed
 // 256-row workgroups the first ones of a degree-sorted graph (256 rows of just under VGL_PULL_HUB_DEGREE edges: 64 tiles, each with
 // a ~500-step chain) were the launch's critical path below ~2^21 vertices (RMAT-18: 0.7 ms degree-sorted against 0.3 ms unsorted).
+// ORDERED = false (f64 HITS: the bar is 1e-12 relative, the reference's own runs differ by 4e-15): the hubs are cut into chunks of
+// VGL_PULL_CHUNK entries, the hub wavefronts take chunks round-robin, sum each per lane (lane l: entries l, l + 64, ...) and fold the
+// 64 partial sums by a fixed butterfly into chunk_sums[chunk]; vgl_k_pull_hub_finish adds a hub's chunk sums in order.  No chain over
+// a whole row (the 7.4e5-entry hub of RMAT-24 was a 4 ms f64 chain per sweep), still deterministic.
+template <class T, bool SKIP_SELF>
+__device__ __forceinline__ void vgl_pull_hub_chunks(const int32_t *chunks, int n_chunks, int32_t row_base, const int64_t *rowptr, const int32_t *adj,
+                                                    const T *x, T *chunk_sums, int ci)
+{
+    const int lane = vgl_lane();
+    if (ci < n_chunks) {                                        // one chunk per wavefront (the caller sizes the grid)
+        const int32_t r = chunks[2 * ci];
+        const int64_t b = rowptr[r] + (int64_t)chunks[2 * ci + 1] * VGL_PULL_CHUNK;
+        const uint32_t n = (uint32_t)min((int64_t)VGL_PULL_CHUNK, rowptr[r + 1] - b);
+        const int32_t *adj_h = adj + b;
+        const int32_t self = row_base + r;
+        T part[4] = {(T)0, (T)0, (T)0, (T)0};
+        for (uint32_t q = lane; q < n; q += 256) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t qq = q + u * 64;
+                int32_t t = qq < n ? adj_h[qq] : -1;
+                if (SKIP_SELF && t == self) t = -1;
+                part[u] = vgl_add_rn(part[u], t >= 0 ? x[(uint32_t)t] : (T)0);
+            }
+        }
+        T acc = vgl_add_rn(vgl_add_rn(part[0], part[1]), vgl_add_rn(part[2], part[3]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc = vgl_add_rn(acc, __shfl_xor(acc, o));
+        if (lane == 0) chunk_sums[ci] = acc;
+    }
+}
+// one thread per hub: its chunk sums in order, the epilogue, and (SUMSQ) this workgroup's share of the sum of squares
+template <class T, bool SUMSQ, class Epi>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_hub_finish(int n_hubs, const int32_t *hub_list, int32_t row_base, const T *chunk_sums, Epi epi,
+                                                                   double *sumsq_partials)
+{
+    __shared__ double s_sq[VGL_WAVES];
+    const int h = blockIdx.x * VGL_BLOCK + threadIdx.x;
+    double sumsq = 0.0;
+    if (h < n_hubs) {
+        const int32_t r = hub_list[3 * h], c0 = hub_list[3 * h + 1], nc = hub_list[3 * h + 2];
+        T acc = (T)0;
+        for (int32_t k = 0; k < nc; k++) acc = vgl_add_rn(acc, chunk_sums[c0 + k]);
+        epi(row_base + r, acc);
+        if (SUMSQ) sumsq = (double)acc * (double)acc;
+    }
+    if (SUMSQ) {
+        const double tot = vgl_block_reduce_add(sumsq, s_sq);
+        if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = tot;
+    }
+}
+
 // grid = hub_blocks + (number of row blocks) workgroups.  SUMSQ: sumsq_partials[blockIdx.x] = sum over this workgroup's rows of sum^2 (f64)
-template <class T, bool SKIP_SELF, bool SUMSQ, class Epi>
+template <class T, bool SKIP_SELF, bool SUMSQ, class Epi, bool ORDERED = true>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj,
                                                             const T *x, Epi epi, int hub_blocks, const int32_t *hub_rows,
-                                                            const int32_t *hub_off, double *sumsq_partials, const int32_t *blk_row)
+                                                            const int32_t *hub_off, double *sumsq_partials, const int32_t *blk_row,
+                                                            const int32_t *hub_chunks = nullptr, int n_hub_chunks = 0, T *hub_chunk_sums = nullptr)
 {
     __shared__ T s_val[VGL_TILE];                       // ordinary rows: staged values; hub wavefronts: 4 x 512 values
     __shared__ int32_t s_dst[VGL_TILE];
     __shared__ int64_t s_jump;
     __shared__ double s_sq[VGL_WAVES];
     double sumsq = 0.0;
-    if ((int)blockIdx.x < hub_blocks) {                 // dispatched first: one workgroup per CU runs the hub schedule
-        vgl_pull_hub_waves<T, SKIP_SELF, SUMSQ>(s_val, hub_rows, hub_off, row_base, rowptr, adj, x, epi, sumsq);
+    // ORDERED: the hub workgroups are dispatched first (one per CU runs the hub schedule: the longest chain starts at once).
+    // Unordered: the chunk workgroups come LAST -- they are short, and behind the row blocks they fill the tail of the launch.
+    const int first_hub = ORDERED ? 0 : (int)gridDim.x - hub_blocks;
+    if ((int)blockIdx.x >= first_hub && (int)blockIdx.x < first_hub + hub_blocks) {
+        if (ORDERED) vgl_pull_hub_waves<T, SKIP_SELF, SUMSQ>(s_val, hub_rows, hub_off, row_base, rowptr, adj, x, epi, sumsq);
+        else {
+            const int cw = ((int)blockIdx.x - first_hub) * VGL_WAVES + vgl_wave();
+            vgl_pull_hub_chunks<T, SKIP_SELF>(hub_chunks, n_hub_chunks, row_base, rowptr, adj, x, hub_chunk_sums, cw);
+        }
     } else {
-        const int32_t blk = (int32_t)blockIdx.x - hub_blocks;
+        const int32_t blk = ORDERED ? (int32_t)blockIdx.x - hub_blocks : (int32_t)blockIdx.x;
         const int32_t r_lo = blk_row[blk];
         const int32_t r_hi = blk_row[blk + 1];                          // <= r_lo + VGL_BLOCK
         const int32_t r = r_lo + threadIdx.x;
