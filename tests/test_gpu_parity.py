@@ -904,3 +904,20 @@ def test_sparse_exchange_primitives(ctx):
     assert np.array_equal(unpack(front), expect) and np.array_equal(unpack(visited), np.union1d(expect, already))
     lv = levels.cpu().numpy()
     assert (lv[expect] == 7).all() and (lv[np.unique(already)] == 3).all() and (lv == -1).sum() == V - len(expect) - len(np.unique(already))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("renumber", [None, "total", "out", "in"])
+def test_edgeless_graph_with_renumbering(renumber, ctx):
+    """no edges at all (the arrays of an empty edge list are null pointers): build, renumber, traverse"""
+    import torch
+    from vectorgraphlibrary_amd import api
+    V = 1000
+    e = torch.zeros(0, dtype=torch.int32, device=ctx.device)
+    g = api.Graph.from_coo(ctx, V, e, e, renumber=renumber)
+    for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+        lv, st = api.bfs(g, 7, mode)
+        assert int(lv[7]) == 1 and int((lv == -1).sum()) == V - 1 and st["levels"] == 1
+    comp, _ = api.connected_components(g)
+    assert torch.equal(comp.cpu(), torch.arange(V, dtype=torch.int32))
+    g.close()

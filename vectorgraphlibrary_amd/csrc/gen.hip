@@ -260,7 +260,7 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
 
 int vgl_hip_degree_hist_add(vgl_hip_ctx *c, int64_t count, const int32_t *d_src, const int32_t *d_dst, int degree_kind, uint32_t *d_degree)
 {
-    if (!c || !d_src || !d_dst || !d_degree) VGL_FAIL("degree_hist_add: null argument");
+    if (!c || !d_degree || (count > 0 && (!d_src || !d_dst))) VGL_FAIL("degree_hist_add: null argument");      // an empty edge list may come without arrays
     if (degree_kind < 0 || degree_kind > 2) VGL_FAIL("degree_hist_add: degree_kind must be 0 (out), 1 (in) or 2 (in+out)");
     if (count > 0) hipLaunchKernelGGL(vgl_k_degree_hist, dim3(vgl_grid_for(count)), dim3(VGL_BLOCK), 0, c->stream, count, d_src, d_dst, degree_kind, d_degree);
     VGL_HIP_TRY(hipGetLastError());
@@ -270,7 +270,7 @@ int vgl_hip_degree_hist_add(vgl_hip_ctx *c, int64_t count, const int32_t *d_src,
 int vgl_hip_degree_order(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *d_src, const int32_t *d_dst, int degree_kind,
                          int32_t *d_fwd, int32_t *d_bwd)
 {
-    if (!c || !d_src || !d_dst || !d_fwd || !d_bwd) VGL_FAIL("degree_order: null argument");
+    if (!c || !d_fwd || !d_bwd || (count > 0 && (!d_src || !d_dst))) VGL_FAIL("degree_order: null argument");
     uint32_t *deg = nullptr;
     VGL_HIP_TRY(hipMalloc((void **)&deg, sizeof(uint32_t) * (size_t)V));
     VGL_HIP_TRY(hipMemsetAsync(deg, 0, sizeof(uint32_t) * (size_t)V, c->stream));
@@ -306,7 +306,7 @@ int vgl_hip_degree_order_from_degrees(vgl_hip_ctx *c, int32_t V, const uint32_t 
 
 int vgl_hip_relabel_i32(vgl_hip_ctx *c, int64_t n, const int32_t *d_map, const int32_t *d_in, int32_t *d_out)
 {
-    if (!c || !d_map || !d_in || !d_out) VGL_FAIL("relabel_i32: null argument");
+    if (!c || !d_map || (n > 0 && (!d_in || !d_out))) VGL_FAIL("relabel_i32: null argument");
     if (n <= 0) return 0;
     hipLaunchKernelGGL(vgl_k_relabel, dim3(vgl_grid_for(n)), dim3(VGL_BLOCK), 0, c->stream, n, d_map, d_in, d_out);
     VGL_HIP_TRY(hipGetLastError());
