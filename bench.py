@@ -96,6 +96,12 @@ def main():
         shard, degrees, bounds = vd.build_generated_shard(ctx, scale, ef, seed, rank, world, kind="rmat", renumber=renumber,
                                                           chunk_edges=args.chunk_edges, placement="dealt")
         sources = pick_sources(None, args.steps + args.warmup, seed, degrees=degrees)
+    elif E > (1 << 31) - 16:
+        # more edges than one stable COO -> CSR sort takes (RMAT-26 and up): the streaming builder assembles the CSR in row-range
+        # pieces; no edge permutation comes out of it, so the weighted extras are skipped
+        g, _, _ = vd.build_generated_shard(ctx, scale, ef, seed, 0, 1, kind="rmat", renumber=renumber, chunk_edges=args.chunk_edges, placement="ranges")
+        args.no_sssp = args.no_pr_cc = True
+        sources = pick_sources(g.out_rowptr, args.steps + args.warmup, seed)
     else:
         src, dst = ctx.gen_rmat(scale, ef, seed)
         g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True, want_perm=not args.no_sssp and not sharded, renumber=renumber)

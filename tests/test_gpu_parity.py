@@ -550,6 +550,13 @@ def test_generated_shards_match_whole_graph_build(kind, renumber, placement, ctx
         assert torch.equal(degrees, (whole.out_rowptr[1:] - whole.out_rowptr[:-1]).to(torch.int32))
         if renumber or placement == "dealt":
             assert torch.equal(s.fwd, whole.fwd) and torch.equal(s.bwd, whole.bwd)
+        # the same shard built in row-range pieces (what a shard with more than 2^31 edges goes through) is the same CSR, incoming
+        # adjacency included (pieces keep the generation order inside every row)
+        sp, _, _ = vd.build_generated_shard(ctx, scale, ef, seed, p, P, kind=kind, renumber=renumber, chunk_edges=30011, placement=placement,
+                                            piece_edges=max(1000, int(s.out_adj.numel()) // 5))
+        assert torch.equal(sp.out_rowptr, s.out_rowptr) and torch.equal(sp.out_adj, s.out_adj)
+        assert torch.equal(sp.in_rowptr, s.in_rowptr) and torch.equal(sp.in_adj, s.in_adj)
+        sp.close()
         ref.close()
         shards.append(s)
     rowptr, adj = whole.out_rowptr.cpu().numpy(), whole.out_adj.cpu().numpy()

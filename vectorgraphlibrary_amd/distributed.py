@@ -154,7 +154,7 @@ class HipShardOps:
 
 
 def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat", renumber="total", chunk_edges=1 << 27,
-                          placement="ranges"):
+                          placement="ranges", piece_edges=1 << 30):
     """This rank's edge-cut shard of a synthetic graph that is too large to materialise on one GPU (RMAT-27 over 8 GPUs,
     BASELINE.json configs[2]).  Every rank streams the whole counter-based edge list in chunks twice -- once for the degree
     histograms (renumbering + partition bounds, identical on all ranks), once to keep the edges whose source (outgoing
@@ -211,25 +211,82 @@ def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat
     else:
         raise ValueError("placement must be 'ranges' or 'dealt'")
     lo, hi = bounds[rank], bounds[rank + 1]
-    keep = {"os": [], "od": [], "is": [], "id": []}
+    # The stable COO -> CSR sort takes at most 2^31 - 16 edges per call.  A shard with more (RMAT-27 on one or two GPUs) is built in
+    # row-range pieces of at most `piece_edges` edges each: the generator is streamed once per piece and the piece CSRs are
+    # concatenated (rows are independent, so the result is the same CSR).  In-degrees for the incoming direction are counted here.
+    indeg_owned = torch.zeros(V, dtype=torch.int32, device=ctx.device)
     for e0, n in chunks:
         s, d = chunk(e0, n)
         if fwd is not None:
             s, d = ctx.relabel(fwd, s), ctx.relabel(fwd, d)
-        m = (s >= lo) & (s < hi)
-        keep["os"].append(s[m])
-        keep["od"].append(d[m])
-        m = (d >= lo) & (d < hi)
-        keep["is"].append(d[m])                                 # transposed: rows of the incoming direction are destinations
-        keep["id"].append(s[m])
-        del s, d, m
-    cat = {k: (torch.cat(v) if v else torch.empty(0, dtype=torch.int32, device=ctx.device)) for k, v in keep.items()}
-    del keep
-    orp, oadj, _ = ctx.coo_to_csr(V, cat["os"], cat["od"], lo, hi)
-    del cat["os"], cat["od"]
-    irp, iadj, _ = ctx.coo_to_csr(V, cat["is"], cat["id"], lo, hi)
-    del cat
-    g = Graph(ctx, V, orp, oadj.clone(), irp, iadj.clone(), lo, hi)
+        ctx.degree_hist_add(s, d, "in", indeg_owned)
+        del s, d
+
+    def pieces(deg):
+        """row ranges [a, b) inside [lo, hi) whose rows hold at most piece_edges edges (a single row above the bound is its own piece)"""
+        pre = torch.zeros(hi - lo + 1, dtype=torch.int64, device=ctx.device)
+        torch.cumsum(deg[lo:hi], 0, dtype=torch.int64, out=pre[1:])
+        total = int(pre[-1])
+        if total <= piece_edges:
+            return [(lo, hi)]
+        cuts, a = [], 0
+        while a < hi - lo:
+            b = int(torch.searchsorted(pre, pre[a] + piece_edges, right=True)) - 1
+            b = max(b, a + 1)
+            cuts.append((lo + a, lo + min(b, hi - lo)))
+            a = min(b, hi - lo)
+        return cuts
+
+    def build(direction, ranges):
+        rps, adjs, base = [], [], 0
+        for a, b in ranges:
+            ks, kd = [], []
+            for e0, n in chunks:
+                s, d = chunk(e0, n)
+                if fwd is not None:
+                    s, d = ctx.relabel(fwd, s), ctx.relabel(fwd, d)
+                if direction == "in":
+                    s, d = d, s                                  # transposed: rows of the incoming direction are destinations
+                m = (s >= a) & (s < b)
+                ks.append(s[m]); kd.append(d[m])
+                del s, d, m
+            cs = torch.cat(ks) if ks else torch.empty(0, dtype=torch.int32, device=ctx.device)
+            cd = torch.cat(kd) if kd else torch.empty(0, dtype=torch.int32, device=ctx.device)
+            del ks, kd
+            rp, adj, _ = ctx.coo_to_csr(V, cs, cd, a, b)
+            del cs, cd
+            rps.append(rp[:-1] + base)
+            adjs.append(adj)
+            base += int(rp[-1])
+            del rp
+        rowptr = torch.cat(rps + [torch.tensor([base], dtype=torch.int64, device=ctx.device)])
+        adj = adjs[0].clone() if len(adjs) == 1 else torch.cat(adjs)
+        return rowptr, adj
+
+    out_pieces, in_pieces = pieces(outdeg), pieces(indeg_owned)
+    del indeg_owned
+    if len(out_pieces) == 1 and len(in_pieces) == 1:             # the usual case: both directions in ONE pass over the generator
+        keep = {"os": [], "od": [], "is": [], "id": []}
+        for e0, n in chunks:
+            s, d = chunk(e0, n)
+            if fwd is not None:
+                s, d = ctx.relabel(fwd, s), ctx.relabel(fwd, d)
+            m = (s >= lo) & (s < hi)
+            keep["os"].append(s[m]); keep["od"].append(d[m])
+            m = (d >= lo) & (d < hi)
+            keep["is"].append(d[m]); keep["id"].append(s[m])     # transposed: rows of the incoming direction are destinations
+            del s, d, m
+        cat = {k: (torch.cat(v) if v else torch.empty(0, dtype=torch.int32, device=ctx.device)) for k, v in keep.items()}
+        del keep
+        orp, oadj, _ = ctx.coo_to_csr(V, cat["os"], cat["od"], lo, hi)
+        del cat["os"], cat["od"]
+        irp, iadj, _ = ctx.coo_to_csr(V, cat["is"], cat["id"], lo, hi)
+        del cat
+        oadj, iadj = oadj.clone(), iadj.clone()
+    else:
+        orp, oadj = build("out", out_pieces)
+        irp, iadj = build("in", in_pieces)
+    g = Graph(ctx, V, orp, oadj, irp, iadj, lo, hi)
     g.fwd, g.bwd = fwd, bwd
     return g, outdeg, bounds
 
