@@ -323,11 +323,11 @@ def main():
                 g.out_adj = g.in_adj = None                                   # keep only the shard resident
         ops = vd.HipShardOps(shard)
         for s in sources[:args.warmup]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1)
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, owned_levels=True)
         barrier()
         t0 = time.perf_counter()
         for s in sources[args.warmup:]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1)
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, owned_levels=True)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -339,7 +339,7 @@ def main():
         ctx.timing(True)
         st = {}
         for s in sources[args.warmup:]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, stats=st)
+            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, stats=st, owned_levels=True)
         barrier()
         kern = {}
         for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "bfs_small_levels", "bfs_bitmap_expand", "gnf"):

@@ -261,6 +261,12 @@ int vgl_hip_levels_to_bitmap(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_level
 int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *ctx, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
                               uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
                               int64_t *newly_degree);
+/* vgl_hip_bfs_apply_bitmaps for a rank that keeps levels only for the rows it owns: the replicated bitmaps are updated for every vertex
+ * (any rank may probe any vertex), d_levels / the two results only for [own_begin, own_end) (multiples of 64) -- the per-vertex part
+ * of the merge no longer grows with the whole graph on every rank; the caller adds the two results over the ranks. */
+int vgl_hip_bfs_apply_bitmaps_owned(vgl_hip_ctx *ctx, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
+                                    uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int32_t own_begin,
+                                    int32_t own_end, int64_t *newly_owned, int64_t *newly_owned_degree);
 /* Sparse exchange of tiny levels (the id-list counterpart of the bitmap exchange of common/mpi_exchange.hpp:222-271):
  * d_out[0] = number of set bits of the bitmap (may exceed cap), d_out[1 .. 1+cap) = ids of (the first cap of) them, unordered.
  * Asynchronous on the context's stream. */

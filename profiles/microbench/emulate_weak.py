@@ -10,6 +10,7 @@ S, P = int(sys.argv[1]), int(sys.argv[2])
 PLACEMENT = sys.argv[3] if len(sys.argv) > 3 else "dealt"
 ef, seed = 32, 1
 VERBOSE = len(sys.argv) > 4
+OWNED = len(sys.argv) > 5 and sys.argv[5] == "owned"      # levels kept per owner (bfs_sharded(owned_levels=True))
 ctx = api.Context(0)
 V, E = 1 << S, (1 << S) * ef
 shards = []
@@ -65,16 +66,25 @@ def run(source, direction_opt):
             parts, bits = 1, torch.cat([everyone[p * words + lo[p]:p * words + lo[p + 1]] for p in range(P)])
         for p, (o, r) in enumerate(zip(ops, reps)):
             ctx.sync(); t0 = time.perf_counter()
-            res.append(o.apply_bitmaps(parts, bits, r, level + 1, vis[p], fr[p], degrees))
+            res.append((o.apply_bitmaps_owned if OWNED else o.apply_bitmaps)(parts, bits, r, level + 1, vis[p], fr[p], degrees))
             ctx.sync(); tap.append(round((time.perf_counter() - t0) * 1e3, 2))
         if VERBOSE:
             print(f"  level {level} {'BU' if bottom_up else 'TD'} F={F}: step {tstep} bitmap {tbm} apply {tap}", flush=True)
-        assert len(set(res)) == 1
-        F, M = res[0]
+        if OWNED:                                   # per-owner counts: what the ranks would all-reduce
+            F, M = sum(x[0] for x in res), sum(x[1] for x in res)
+        else:
+            assert len(set(res)) == 1
+            F, M = res[0]
         trace.append(("BU" if bottom_up else "TD", F))
         if F == 0:
             break
         level += 1
+    if OWNED:                                       # assemble the owners' slices (what a final all-gather would return)
+        full = reps[0].clone()
+        for p in range(1, P):
+            a, b = bounds[p], bounds[p + 1]
+            full[a:b] = reps[p][a:b]
+        return full, trace
     for r in reps[1:]:
         assert torch.equal(r, reps[0])
     return reps[0], trace

@@ -28,7 +28,8 @@ def main():
     source = int(torch.argmax(degrees))
     ref, _ = api.bfs(shard, source, api.BFS_DIRECTION_OPT, raw=True)
     for kw in (dict(equal_ranges=True), dict(equal_ranges=True, two_phase=True), dict(equal_ranges=False), dict(degrees=None, edges=None),
-               dict(equal_ranges=True, sparse_cap=0), dict(equal_ranges=True, sparse_cap=16), dict(sparse_cap=100000)):
+               dict(equal_ranges=True, sparse_cap=0), dict(equal_ranges=True, sparse_cap=16), dict(sparse_cap=100000),
+               dict(equal_ranges=True, owned_levels=True), dict(equal_ranges=True, owned_levels=True, sparse_cap=0, two_phase=True)):
         args = dict(degrees=degrees, edges=E)
         args.update(kw)
         levels, nlevels = vd.bfs_sharded(ops, source, **args)

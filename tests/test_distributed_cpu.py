@@ -105,6 +105,19 @@ class NumpyShardOps:
             visited.numpy()[:] |= self._packed(new)
         return int(new.sum()), (int(degrees.numpy()[new].sum()) if degrees is not None else 0)
 
+    def apply_bitmaps_owned(self, parts, bits_all, levels, level, visited, front, degrees=None):
+        words = (self.V + 63) // 64
+        merged = np.bitwise_or.reduce(bits_all.numpy().reshape(parts, words), axis=0)
+        on = np.unpackbits(merged.view(np.uint8), bitorder="little")[:self.V].astype(bool)
+        vis = self._unpack(visited)
+        new = on & ~vis
+        self._pack(vis | new, visited)
+        self._pack(new, front)
+        own = np.zeros(self.V, bool); own[self.lo:self.hi] = True
+        mine = new & own
+        levels.numpy()[mine] = level
+        return int(mine.sum()), (int(degrees.numpy()[mine].sum()) if degrees is not None else 0)
+
     def _packed(self, mask):
         b = np.zeros(((self.V + 63) // 64) * 64, np.uint8)
         b[:self.V] = mask
@@ -221,6 +234,13 @@ def _worker(rank, world, port, results):
     assert (levels_2p.numpy() == levels.numpy()).all(), "two-phase top-down exchange != full-bitmap exchange"
     levels_2p_td, _ = vd.bfs_sharded(eq, source, equal_ranges=True, two_phase=True)          # top-down only: every level two-phase
     assert (levels_2p_td.numpy() == levels.numpy()).all()
+    # levels kept per owner: complete on the owned range, frontier size / degree sum all-reduced
+    for kw in (dict(), dict(equal_ranges=True), dict(equal_ranges=True, two_phase=True)):
+        o = eq if kw else ops
+        for cap in (0, 4096):
+            lv, _ = vd.bfs_sharded(o, source, degrees=degrees, edges=len(adj), owned_levels=True, sparse_cap=cap, **kw)
+            lo_, hi_ = o.row_range()
+            assert (lv.numpy()[lo_:hi_] == levels.numpy()[lo_:hi_]).all(), f"owned levels {kw} sparse {cap}"
     # sparse exchange of small levels: off, with a bound every level fits (V <= 4096 here), and with a bound only the tiny ones fit
     for cap in (0, 4096, 8):
         st = {}

@@ -928,3 +928,38 @@ def test_edgeless_graph_with_renumbering(renumber, ctx):
     comp, _ = api.connected_components(g)
     assert torch.equal(comp.cpu(), torch.arange(V, dtype=torch.int32))
     g.close()
+
+
+@pytest.mark.gpu
+def test_apply_bitmaps_owned(ctx):
+    """vgl_hip_bfs_apply_bitmaps_owned: bitmaps updated for every vertex, levels / counts / degree sums for the owned range only"""
+    import torch
+    from vectorgraphlibrary_amd import distributed as vd
+
+    class G:
+        pass
+    V, lo, hi = 100000, 12800, 51200
+    g = G(); g.ctx = ctx; g.V = V; g.row_begin = lo; g.row_end = hi
+    ops = vd.HipShardOps(g)
+    rng = np.random.default_rng(11)
+    words = (V + 63) // 64
+
+    def pack(mask):
+        b = np.zeros(words * 64, np.uint8); b[:V] = mask
+        return torch.from_numpy(np.packbits(b, bitorder="little").view(np.int64).copy()).to(ctx.device)
+
+    def unpack(t):
+        return np.unpackbits(t.cpu().numpy().view(np.uint8), bitorder="little")[:V].astype(bool)
+    parts = [rng.random(V) < 0.05 for _ in range(3)]
+    visited0 = rng.random(V) < 0.3
+    bits_all = torch.cat([pack(p) for p in parts])
+    visited, front = pack(visited0), pack(rng.random(V) < 0.5)
+    levels = torch.full((V,), -1, dtype=torch.int32, device=ctx.device)
+    degrees = torch.from_numpy(rng.integers(0, 50, V).astype(np.int32)).to(ctx.device)
+    n, d = ops.apply_bitmaps_owned(3, bits_all, levels, 9, visited, front, degrees)
+    new = (parts[0] | parts[1] | parts[2]) & ~visited0
+    own = np.zeros(V, bool); own[lo:hi] = True
+    assert n == int((new & own).sum()) and d == int(degrees.cpu().numpy()[new & own].sum())
+    assert np.array_equal(unpack(front), new) and np.array_equal(unpack(visited), visited0 | new)
+    lv = levels.cpu().numpy()
+    assert (lv[new & own] == 9).all() and (lv[~(new & own)] == -1).all()

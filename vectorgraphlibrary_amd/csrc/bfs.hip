@@ -669,8 +669,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bitmap_or_parts(int64_t words
 // visited / frontier bitmaps and the frontier's out-degree sum up to date for the direction decision of the next level
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_bitmaps(int32_t V, int parts, int64_t words, const uint64_t *bits_all,
                                                                  int32_t *levels, int32_t level, uint64_t *visited, uint64_t *front,
-                                                                 const int32_t *degrees, int64_t *partials)
+                                                                 const int32_t *degrees, int64_t *partials, int32_t own_begin, int32_t own_end)
 {
+    // own_begin .. own_end (visited bitmap given): the bitmaps are updated for ALL vertices -- every rank probes any vertex's bits --
+    // but levels / counts / degree sums only for the owned ones: that per-vertex part is the bulk of the pass and, done for all
+    // vertices on every rank, it was the serial fraction of the sharded traversal (0.35 - 0.4 ms per large level at scale 27 whatever
+    // the number of ranks).  The caller adds the counts over the ranks.
     // one bitmap word per lane (coalesced OR over the parts; almost all words are zero on small levels), then the wavefront
     // walks its non-zero words together so that the levels / degrees accesses of a word are one coalesced 256-byte row
     __shared__ int64_t s64[VGL_WAVES];
@@ -687,7 +691,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_bitmaps(int32_t V, int 
                 if (w) visited[wi] = vis | w;
             }
         }
-        unsigned long long todo = __ballot(w != 0);
+        // (words wholly outside the owned range need no per-vertex walk: own ranges are multiples of 64)
+        const bool walk = w != 0 && (!visited || (((wi << 6) + 63) >= own_begin && (wi << 6) < own_end));
+        unsigned long long todo = __ballot(walk);
         uint64_t mine_new = visited ? w : 0;
         while (todo) {
             const int l = __ffsll((long long)todo) - 1;
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_bitmaps(int32_t V, int 
             const uint64_t ww = __shfl(w, l);
             const int64_t v = ((wi - lane + l) << 6) + lane;
             bool is_new = false;
-            if (v < V && ((ww >> lane) & 1ULL)) {
+            if (v < V && ((ww >> lane) & 1ULL) && (!visited || (v >= own_begin && v < own_end))) {
                 if (visited) { levels[v] = level; is_new = true; }
                 else {                            // no bitmap: levels decides (vertices of this level were marked by their finder)
                     const int32_t lv = levels[v];
@@ -703,12 +709,13 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_bitmaps(int32_t V, int 
                     is_new = (lv == -1) || (lv == level);
                 }
                 if (is_new && degrees) deg += degrees[v];
+                if (is_new && visited) cnt++;
             }
             if (!visited) { const unsigned long long nm = __ballot(is_new); if (lane == l) mine_new = nm; }
         }
         if (wi < words) {
             if (front) front[wi] = mine_new;
-            cnt += __popcll(mine_new);
+            if (!visited) cnt += __popcll(mine_new);
         }
     }
     cnt = vgl_block_reduce_add(cnt, s64);
@@ -1094,9 +1101,31 @@ int vgl_hip_bfs_apply_ids(vgl_hip_ctx *c, int32_t V, int parts, int32_t cap, con
     return 0;
 }
 
+static int vgl_bfs_apply_bitmaps_range(vgl_hip_ctx *c, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
+                                       uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
+                                       int64_t *newly_degree, int32_t own_begin, int32_t own_end);
+
 int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *c, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
                               uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
                               int64_t *newly_degree)
+{
+    return vgl_bfs_apply_bitmaps_range(c, V, parts, d_bits_all, d_levels, level, d_visited_bits, d_front_bits, d_degrees, newly, newly_degree, 0, V);
+}
+
+int vgl_hip_bfs_apply_bitmaps_owned(vgl_hip_ctx *c, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
+                                    uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int32_t own_begin,
+                                    int32_t own_end, int64_t *newly_owned, int64_t *newly_owned_degree)
+{
+    if (!d_visited_bits) VGL_FAIL("bfs_apply_bitmaps_owned: the replicated visited bitmap is required");
+    if (own_begin < 0 || own_end > V || own_begin > own_end || (own_begin & 63) || (own_end != V && (own_end & 63)))
+        VGL_FAIL("bfs_apply_bitmaps_owned: the owned range must lie in [0, V] and start / end on multiples of 64");
+    return vgl_bfs_apply_bitmaps_range(c, V, parts, d_bits_all, d_levels, level, d_visited_bits, d_front_bits, d_degrees, newly_owned,
+                                       newly_owned_degree, own_begin, own_end);
+}
+
+static int vgl_bfs_apply_bitmaps_range(vgl_hip_ctx *c, int32_t V, int parts, const uint64_t *d_bits_all, int32_t *d_levels, int32_t level,
+                                       uint64_t *d_visited_bits, uint64_t *d_front_bits, const int32_t *d_degrees, int64_t *newly,
+                                       int64_t *newly_degree, int32_t own_begin, int32_t own_end)
 {
     if (!c || !d_bits_all || !d_levels) VGL_FAIL("bfs_apply_bitmaps: null argument");
     if (parts < 1) VGL_FAIL("bfs_apply_bitmaps: parts must be >= 1");
@@ -1104,7 +1133,7 @@ int vgl_hip_bfs_apply_bitmaps(vgl_hip_ctx *c, int32_t V, int parts, const uint64
     VGL_TRY(vgl_ensure_partials(c, (size_t)nb * 2 + 2));
     int64_t *partials = reinterpret_cast<int64_t *>(c->d_partials);
     hipLaunchKernelGGL(vgl_k_apply_bitmaps, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, V, parts, vgl_ceil_div(V, 64), d_bits_all,
-                       d_levels, level, d_visited_bits, d_front_bits, d_degrees, partials);
+                       d_levels, level, d_visited_bits, d_front_bits, d_degrees, partials, own_begin, own_end);
     hipLaunchKernelGGL(vgl_k_apply_fold, dim3(1), dim3(VGL_BLOCK), 0, c->stream, nb, partials, c->d_counters);
     VGL_HIP_TRY(hipGetLastError());
     VGL_TRY(vgl_read_counters(c, false));

@@ -113,6 +113,13 @@ class HipShardOps:
                                               _ptr(front), _ptr(degrees), C.byref(n), C.byref(d)))
         return n.value, d.value
 
+    def apply_bitmaps_owned(self, parts, bits_all, levels, level, visited, front, degrees=None):
+        """apply_bitmaps with the per-vertex part (levels, counts) restricted to the owned rows; returns the OWNED (newly, degree sum)"""
+        n, d = C.c_int64(), C.c_int64()
+        _l.check(self.L.vgl_hip_bfs_apply_bitmaps_owned(self.ctx.h, self.V, parts, _ptr(bits_all), _ptr(levels), int(level), _ptr(visited), _ptr(front),
+                                                        _ptr(degrees), self.g.row_begin, self.g.row_end, C.byref(n), C.byref(d)))
+        return n.value, d.value
+
     def sssp_init(self, d, source):
         _l.check(self.L.vgl_hip_sssp_init(self.ctx.h, self.V, int(source), _ptr(d)))
 
@@ -299,7 +306,8 @@ def _allreduce(t, op, group):
 ALPHA, BETA = 15, 18          # change_state.hpp:5-6
 
 
-def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False, two_phase=None, stats=None, sparse_cap=None):
+def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=False, two_phase=None, stats=None, sparse_cap=None,
+                owned_levels=False):
     """BFS over edge-cut shards; returns the replicated levels array and the number of levels.
     degrees (int32[V] out-degrees of ALL vertices, replicated) + edges (global E) enable direction optimisation: every rank
     evaluates the same switch rule (gpu_change_state, change_state.hpp:100-141) on replicated counters, bottom-up steps scan
@@ -315,6 +323,9 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
     scale 27), and the merge touches the listed vertices instead of P bitmaps.  When some rank found more than cap vertices (the
     counts travel with the lists, so every rank sees the same thing) the level falls back to the bitmap exchange.  The first and the
     last levels of a traversal are of this kind.
+    owned_levels=True: every rank keeps `levels` for the rows it owns only (the returned array is complete on the owned range; other
+    entries are unspecified) -- the merge of a level then touches V/P vertices per rank instead of V, and the frontier size / degree
+    sum are all-reduced (two scalars).  False (default): replicated levels, as the tests compare them.
     stats (dict, optional): accumulates THIS shard's work -- bu_steps / bu_edges / bu_found, td_steps / td_edges / td_frontier,
     levels -- for the roofline accounting of bench.py; bottom-up steps then wait for their counters (one more host read per level)."""
     P, rank = _world(group)
@@ -403,7 +414,13 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
                 parts, bits = 1, merged
             else:
                 dist.all_gather_into_tensor(everyone, mine, group=group)
-        F, M = ops.apply_bitmaps(parts, bits, levels, level + 1, visited, front, degrees if direction_opt else None)
+        if owned_levels and exchanging and hasattr(ops, "apply_bitmaps_owned"):
+            f_own, m_own = ops.apply_bitmaps_owned(parts, bits, levels, level + 1, visited, front, degrees if direction_opt else None)
+            fm = ops.scalar([f_own, m_own])
+            dist.all_reduce(fm, op=dist.ReduceOp.SUM, group=group)
+            F, M = (int(x) for x in fm.tolist())
+        else:
+            F, M = ops.apply_bitmaps(parts, bits, levels, level + 1, visited, front, degrees if direction_opt else None)
         if F == 0:
             break
         level += 1

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "vgl_hip_bfs_step_bottom_up": [_p, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_levels_to_bitmap": [_p, _i32, _p, _i32, _p],
     "vgl_hip_bfs_apply_bitmaps": [_p, _i32, _int, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
+    "vgl_hip_bfs_apply_bitmaps_owned": [_p, _i32, _int, _p, _p, _i32, _p, _p, _p, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_bitmap_to_ids": [_p, _i64, _p, _i32, _p],
     "vgl_hip_bfs_apply_ids": [_p, _i32, _int, _i32, _p, _p, _i32, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_sssp_init": [_p, _i32, _i32, _p],
