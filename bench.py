@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sssp", action="store_true")
     ap.add_argument("--no-pr-cc", action="store_true", help="skip the PageRank (uniform-25) and CC (symmetrised RMAT-24x16) extras")
-    ap.add_argument("--cpu-sources", type=int, default=3)
+    ap.add_argument("--cpu-sources", type=int, default=10)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU super-step path even with one rank (debug)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = RMAT scale+log2(N) built shard-by-shard (default), strong = the scale-24 graph cut N ways")
@@ -68,6 +68,22 @@ def main():
     ap.add_argument("--renumber", default="total", choices=["none", "out", "in", "total"],
                     help="VectCSR-style degree renumbering of the stored graph (vect_csr/import.hpp:61-99)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start one rank per GPU under torch.distributed.run as a CHILD process (nothing has
+    # touched the GPU yet) and hand its exit code back; under a launcher the world size must be the one asked for
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29531"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}")
+    if args.gpus & (args.gpus - 1):
+        sys.exit("bench.py: --gpus must be a power of two (weak scaling adds log2(N) to the scale; blocks are dealt round-robin)")
+    # the CPU baseline's OpenMP runtime reads these when it is first loaded (scripts/helpers.py:147-153)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
     import torch
     import torch.distributed as dist
@@ -128,7 +144,8 @@ def main():
         t0 = time.perf_counter()
         stats = []
         for s in sources[args.warmup:]:
-            stats.append(api.bfs(g, s, api.BFS_DIRECTION_OPT, raw=True)[1])
+            lv_do, st_one = api.bfs(g, s, api.BFS_DIRECTION_OPT, raw=True)
+            stats.append(st_one)
         barrier()
         dt = time.perf_counter() - t0
         # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----
@@ -137,6 +154,14 @@ def main():
             n, ms = ctx.timing_get(name)
             kern[name] = {"launches": n, "total_ms": round(ms, 4)}
         ctx.timing(False)
+        # ---- check what was timed (apps/bfs/bfs.cpp:41-46, -check): the levels of the LAST timed traversal must equal the reference
+        #      algorithm's (pure top-down) levels of the same source; a mismatch fails the run ----
+        check_source = sources[-1]                                    # lv_do: the levels the last TIMED traversal left behind
+        lv_td = api.bfs(g, check_source, api.BFS_TOP_DOWN, raw=True)[0]
+        bad = api.count_not_equal(ctx, lv_do, lv_td)
+        if bad:
+            sys.exit(f"bench.py: direction-optimising BFS levels differ from the top-down levels at {bad} vertices (source {check_source})")
+        extra["verified"] = {"bfs_do_equals_top_down": True, "source": check_source}
         bu_edges = sum(s["bu_edges"] for s in stats)
         bu_found = sum(s["bu_found"] for s in stats)
         bu_steps = sum(s["bu_steps"] for s in stats)
@@ -249,19 +274,25 @@ def main():
         # ---- CPU baseline: the oracle's OpenMP port of the reference top-down BFS, same graph, host cores ----
         if not args.no_cpu_baseline:
             from oracle import oracle as O
+            threads = O.set_threads()                                    # the CPUs this box grants (affinity / cgroup quota), not every core it shows
             rp = g.out_rowptr.cpu().numpy()
             adj = g.out_adj.cpu().numpy()
-            O.bfs_top_down(rp, adj, sources[0], parallel=True)           # warm-up / page-in
+            ref_lv, _ = O.bfs_top_down(rp, adj, check_source, parallel=True)           # warm-up / page-in, and the checker of the timed path
+            if not (lv_do.cpu().numpy() == ref_lv).all():
+                sys.exit(f"bench.py: BFS levels differ from the CPU oracle's (source {check_source})")
+            extra["verified"]["bfs_equals_cpu_oracle"] = True
             tc = time.perf_counter()
             n_cpu = 0
             for s in sources[args.warmup:args.warmup + args.cpu_sources]:
                 O.bfs_top_down(rp, adj, s, parallel=True)
                 n_cpu += 1
-                if time.perf_counter() - tc > 30:
+                if time.perf_counter() - tc > 20:
                     break
             dtc = time.perf_counter() - tc
-            cpu_baseline = {"value": round(n_cpu * E / dtc, 1), "unit": "edges/s", "cores": O.max_threads(), "kind": "port",
-                            "sample": f"{n_cpu} top-down BFS traversals (oracle/vgl_oracle.c, OpenMP) of the same RMAT-{scale} graph"}
+            cpu_baseline = {"value": round(n_cpu * E / dtc, 1), "unit": "edges/s", "cores": threads, "kind": "port",
+                            "sample": f"{n_cpu} top-down BFS traversals after 1 warm-up (oracle/vgl_oracle.c, OpenMP, OMP_PROC_BIND="
+                                      f"{os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}) of the same RMAT-{scale} graph",
+                            "host": O.host_description()}
             del rp, adj
 
         # ---- PageRank (BASELINE configs[3]: uniform-random scale 25) and CC (configs[4] stand-in on one GPU: symmetrised
@@ -311,7 +342,7 @@ def main():
             cg.close()
             del cg
         workload = f"BFS direction-optimising on RMAT scale-{scale} (edge factor {ef}), 1xMI355X"
-        scaling = "weak"
+        scaling = "none"
     else:
         # edge-cut shards, direction-optimising super-steps with a bitmap all-gather per level
         if not weak:

@@ -68,6 +68,7 @@ def lib():
         L.vgo_fnv1a64.restype = u64
         L.vgo_fnv1a64.argtypes = [p, i64]
         L.vgo_max_threads.restype = C.c_int
+        L.vgo_set_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -242,6 +243,52 @@ def fnv1a64(a):
 
 def max_threads():
     return int(lib().vgo_max_threads())
+
+
+def host_cpus():
+    """CPUs this process may really use: the affinity mask, cut down by a cgroup CPU quota where one is set (a GPU box shows every
+    core of the host but grants a share of them; an OpenMP team of all visible cores is then heavily over-subscribed)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def host_description():
+    """model name / sockets / cores of the host the CPU baseline ran on (for the bench line)"""
+    model, sockets, cores = "unknown", set(), set()
+    try:
+        phys = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+                sockets.add(phys)
+            elif line.startswith("core id"):
+                cores.add((phys, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return {"model": model, "sockets": len(sockets) or None, "physical_cores": len(cores) or None,
+            "logical_cpus_visible": os.cpu_count(), "cpus_granted": host_cpus()}
+
+
+def set_threads(n=None):
+    """size of the OpenMP team of the parallel=True runs; default = host_cpus()"""
+    n = host_cpus() if n is None else int(n)
+    lib().vgo_set_threads(n)
+    return n
 
 
 def pick_source(rowptr, seed, k=0):

@@ -251,7 +251,17 @@ int32_t vgo_sssp_bellman_ford(int32_t V, const int64_t *rowptr, const int32_t *a
                 const float weight = w[p];
                 const float src_weight = dist[u];
                 const int32_t v = adj[p];
-                if (dist[v] > src_weight + weight) dist[v] = src_weight + weight;
+                const float cand = src_weight + weight;
+                if (!parallel) {
+                    if (dist[v] > cand) dist[v] = cand;
+                } else {
+                    /* same relaxation, made race-free for the multi-threaded run: compare-and-swap minimum (distances are
+                     * non-negative, so the f32 order is the order of the bit patterns); the fixed point is the same */
+                    int32_t *slot = (int32_t *)&dist[v];
+                    int32_t seen = __atomic_load_n(slot, __ATOMIC_RELAXED), want;
+                    memcpy(&want, &cand, sizeof(want));
+                    while (want < seen && !__atomic_compare_exchange_n(slot, &seen, want, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+                }
             }
         }
         changes = 0;
@@ -586,5 +596,14 @@ int vgo_max_threads(void)
     return omp_get_max_threads();
 #else
     return 1;
+#endif
+}
+
+void vgo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
 #endif
 }

@@ -87,6 +87,7 @@ void vgo_cc_seq_bfs(int32_t V, const int64_t *rowptr, const int32_t *adj, int32_
 /* FNV-1a 64 over raw bytes (fixture hashing) */
 uint64_t vgo_fnv1a64(const void *data, int64_t nbytes);
 int vgo_max_threads(void);
+void vgo_set_threads(int n);   /* OpenMP team size of the parallel=1 runs (the GPU box grants fewer CPUs than it shows) */
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""PageRank pull: exact-order kernel vs the blocked (LDS-window) pass, per-kernel HIP-event times.
+usage: blocked_bench.py [uniform|rmat] [scale] [edge factor]   (run on the GPU box: gpurun -- python profiles/microbench/blocked_bench.py)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+from vectorgraphlibrary_amd import api
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
+scale = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+ef = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+ctx = api.Context(0)
+V, E = 1 << scale, (1 << scale) * ef
+s, d = (ctx.gen_uniform if kind == "uniform" else ctx.gen_rmat)(scale, ef, 1)
+g = api.Graph.from_coo(ctx, V, s, d, with_incoming=True, renumber=None if kind == "uniform" else "total")
+del s, d
+t0 = time.perf_counter()
+api.page_rank(g, 1, raw=True, mode=api.PR_BLOCKED)
+torch.cuda.synchronize()
+print(f"{kind}-{scale}x{ef}: first blocked iteration incl. plan build {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+for mode, name in ((api.PR_BLOCKED, "blocked"), (api.PR_EXACT_ORDER, "exact-order")):
+    api.page_rank(g, 2, raw=True, mode=mode)
+    ctx.timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 10
+    r, st = api.page_rank(g, iters, raw=True, mode=mode)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    parts = {k: ctx.timing_get(k) for k in ("pr_pull", "pr_blk_gather", "pr_blk_accumulate")}
+    ctx.timing(False)
+    alg = 8 * E + 28 * V
+    print(f"  {name:12s} {dt * 1e3:7.3f} ms/iteration  {E / dt / 1e9:7.1f} GTEPS  {alg / dt / 1e9:7.1f} GB/s algorithmic ({alg / dt / 8e12:.3f} of 8 TB/s)  "
+          + "  ".join(f"{k} {v[1] / max(v[0], 1):.3f} ms x{v[0]}" for k, v in parts.items() if v[0]), flush=True)
+    if mode == api.PR_BLOCKED:
+        rb = r.clone()
+    else:
+        rel = ((rb - r).abs() / r).max().item()
+        print(f"  max relative difference blocked vs exact-order: {rel:.3e}")
+g.close()

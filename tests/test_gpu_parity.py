@@ -963,3 +963,38 @@ def test_apply_bitmaps_owned(ctx):
     assert np.array_equal(unpack(front), new) and np.array_equal(unpack(visited), visited0 | new)
     lv = levels.cpu().numpy()
     assert (lv[new & own] == 9).all() and (lv[~(new & own)] == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef,renumber", [("rmat", 12, 16, None), ("ru", 16, 8, None), ("rmat", 17, 16, "total"), ("rmat", 17, 16, None),
+                                                    ("ru", 18, 4, None), ("ru", 15, 1, None)])
+def test_pagerank_blocked_pull(kind, scale, ef, renumber, ctx, oracle):
+    """PR_BLOCKED (LDS-window gather + LDS float-atomic sums, vgl_blocked.h) against the oracle's adjacency-order f32 sums: <= 1e-6
+    relative (north star); one block (V <= 32768), several blocks, blocks cut into several units (forced small units: slabs),
+    self loops dropped at plan build time, zero iterations."""
+    import os
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    V, seed = 1 << scale, 21
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, renumber=renumber)
+    rowptr, adj = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy()
+    assert int((adj == np.repeat(np.arange(V), np.diff(rowptr))).sum()) > 0 or kind == "ru"      # RMAT inputs hold self loops
+    for it in (0, 1, 4):
+        ref = O.pagerank(rowptr, adj, it, 1)
+        for unit in ("", "64"):
+            if unit:
+                os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = unit
+            try:
+                g2 = api.Graph(ctx, V, g.out_rowptr, g.out_adj, g.in_rowptr, g.in_adj) if unit else g      # a fresh handle builds a fresh plan
+                ranks, st = api.page_rank(g2, it, raw=True, mode=api.PR_BLOCKED)
+            finally:
+                os.environ.pop("VGL_BLK_GATHER_UNIT", None), os.environ.pop("VGL_BLK_ACCUM_UNIT", None)
+            rk = ranks.cpu().numpy()
+            assert relerr(rk, ref) <= PR_RTOL, (it, unit, relerr(rk, ref))
+            assert abs(st["ranks_sum"] - float(rk.astype(np.float64).sum())) < 1e-9
+            if unit:
+                g2.close()
+    exact, _ = api.page_rank(g, 4, raw=True, mode=api.PR_EXACT_ORDER)
+    assert (exact.cpu().numpy().view(np.int32) == O.pagerank(rowptr, adj, 4, 1).view(np.int32)).all()
+    g.close()

@@ -17,6 +17,7 @@ RMAT_ABCD = (57, 19, 19, 5)            # vgl_runtime.hpp:36
 BFS_TOP_DOWN, BFS_DIRECTION_OPT = 0, 1
 SSSP_ALL_ACTIVE, SSSP_ACTIVE_TILES, SSSP_DELTA_STEPPING = 0, 1, 2
 DENSE, SPARSE, ALL_ACTIVE = 0, 1, 2    # framework_types.h:156-160
+PR_EXACT_ORDER, PR_BLOCKED, PR_AUTO = 0, 1, 2
 
 
 def _ptr(t):
@@ -314,12 +315,13 @@ def sswp(graph, capacities, source, mode=SSSP_ACTIVE_TILES, widths=None, raw=Fal
     return (widths if raw else graph.to_original(widths)), _stats(st)
 
 
-def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False):
-    """indeg_noloops (optional) is indexed in the graph's own numbering."""
+def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False, mode=PR_AUTO):
+    """indeg_noloops (optional) is indexed in the graph's own numbering.  mode: PR_EXACT_ORDER (adjacency-order f32 sums, bit-identical
+    to seq_page_rank), PR_BLOCKED (LDS-window gather / sum, within a few ulp) or PR_AUTO (blocked from 2^25 edges)."""
     ctx = graph.ctx
     ranks = ctx.empty(graph.V, torch.float32) if ranks is None else ranks
     st = _l.PrStats()
-    _l.check(ctx.L.vgl_hip_pr_run(ctx.h, graph.h, _ptr(indeg_noloops), int(iterations), _ptr(ranks), C.byref(st)))
+    _l.check(ctx.L.vgl_hip_pr_run_mode(ctx.h, graph.h, _ptr(indeg_noloops), int(iterations), int(mode), _ptr(ranks), C.byref(st)))
     return (ranks if raw else graph.to_original(ranks)), _stats(st)
 
 

@@ -1,0 +1,277 @@
+// blocked.hip -- builds the layout of the blocked advance (vgl_blocked.h) from one CSR direction.  Offline, like the reference's
+// graph import (vgl_graph.hpp:57-68): the edge keys (accumulate block, gather block) are sorted with rocPRIM's stable radix sort,
+// segments are padded to 64-entry chunks and laid out twice (gather order / accumulate order).
+#include "vgl_blocked.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+struct dev_bufs {                                   // frees whatever the build still holds when it leaves, error or not
+    std::vector<void *> ptrs;
+    template <class T> hipError_t alloc(T **p, size_t n)
+    {
+        hipError_t e = hipMalloc((void **)p, sizeof(T) * std::max<size_t>(n, 1));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+    void release(void *p)
+    {
+        for (auto &q : ptrs) if (q == p) { hipFree(q); q = nullptr; }
+    }
+    ~dev_bufs() { for (void *q : ptrs) if (q) hipFree(q); }
+};
+
+// key = ab * nG + gb (sentinel nseg for dropped self loops), value = g_lo | a_lo << 16
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_keys(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E,
+                                                            int32_t row_base, int gather_rows, int skip_self, uint32_t nG, uint32_t nseg,
+                                                            uint32_t *keys, uint32_t *packed)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, E - e0);
+    const int r_first = tile_row[blockIdx.x], r_last = tile_row[blockIdx.x + 1];
+    vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;
+        if (i < n) {
+            const uint32_t r = (uint32_t)(r_first + s_map[i]), col = (uint32_t)adj[e0 + i];
+            const uint32_t g = gather_rows ? r : col, a = gather_rows ? col : r;
+            const bool drop = skip_self && (uint32_t)row_base + r == col;
+            keys[e0 + i] = drop ? nseg : (a >> VGL_BLK_BITS) * nG + (g >> VGL_BLK_BITS);
+            packed[e0 + i] = (g & (VGL_BLK - 1)) | ((a & (VGL_BLK - 1)) << 16);
+        }
+    }
+}
+
+// first / one-past-last position of every key present in the sorted key array (absent keys keep 0 / 0)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_runs(int64_t E, const uint32_t *keys, uint32_t *seg_first, uint32_t *seg_end)
+{
+    for (int64_t i = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; i < E; i += (int64_t)gridDim.x * VGL_BLOCK) {
+        const uint32_t k = keys[i];
+        if (i == 0 || keys[i - 1] != k) seg_first[k] = (uint32_t)i;
+        if (i == E - 1 || keys[i + 1] != k) seg_end[k] = (uint32_t)(i + 1);
+    }
+}
+
+// chunks per segment in both orders (index nseg = 0: the scans below then leave the totals there)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_nchunks(uint32_t nG, uint32_t nA, const uint32_t *seg_first, const uint32_t *seg_end,
+                                                               uint32_t *nch_a, uint32_t *nch_m)
+{
+    const uint32_t nseg = nG * nA;
+    for (uint32_t k = blockIdx.x * VGL_BLOCK + threadIdx.x; k <= nseg; k += gridDim.x * VGL_BLOCK) {
+        if (k == nseg) { nch_a[k] = 0; nch_m[k] = 0; continue; }
+        const uint32_t n = (seg_end[k] - seg_first[k] + VGL_CHUNK - 1) / VGL_CHUNK;
+        const uint32_t ab = k / nG, gb = k % nG;
+        nch_a[k] = n;
+        nch_m[gb * nA + ab] = n;
+    }
+}
+
+// one wavefront per A-order chunk: find its segment, place the chunk in both orders
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill(uint32_t nchunks, uint32_t nG, uint32_t nA, const uint32_t *a_start, const uint32_t *m_start,
+                                                            const uint32_t *seg_first, const uint32_t *seg_end, const uint32_t *packed_sorted,
+                                                            const float *w_sorted, uint16_t *g_lo, uint16_t *a_lo, float *w_mid, uint32_t *mid_to_a)
+{
+    const uint32_t nseg = nG * nA;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t j = blockIdx.x * VGL_WAVES + (threadIdx.x >> 6); j < nchunks; j += gridDim.x * VGL_WAVES) {
+        uint32_t lo = 0, hi = nseg;                                 // last k with a_start[k] <= j (a_start[nseg] = nchunks > j)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a_start[mid] <= j) lo = mid; else hi = mid;
+        }
+        // empty segments share their start with the next one: upper_bound - 1 lands on the LAST of equal starts, which is the non-empty one
+        const uint32_t k = lo, ab = k / nG, gb = k % nG;
+        const uint32_t within = j - a_start[k];
+        const uint32_t m = m_start[gb * nA + ab] + within;
+        const uint32_t pos = within * VGL_CHUNK + lane, cnt = seg_end[k] - seg_first[k];
+        uint16_t gl = 0, al = (uint16_t)(VGL_BLK_PAD + lane);
+        float w = 0.0f;
+        if (pos < cnt) {
+            const uint32_t pk = packed_sorted[seg_first[k] + pos];
+            gl = (uint16_t)(pk & 0xFFFFu);
+            al = (uint16_t)(pk >> 16);
+            if (w_sorted) w = w_sorted[seg_first[k] + pos];
+        }
+        g_lo[(size_t)m * VGL_CHUNK + lane] = gl;
+        a_lo[(size_t)j * VGL_CHUNK + lane] = al;
+        if (w_mid) w_mid[(size_t)m * VGL_CHUNK + lane] = w;
+        if (lane == 0) mid_to_a[m] = j;
+    }
+}
+
+__global__ void vgl_k_blk_pick(int n, uint32_t stride, const uint32_t *in, uint32_t *out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[(size_t)i * stride];
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// cut blocks into units of at most `cap` chunks; bounds[b] .. bounds[b+1] = chunk range of block b
+void make_units(const std::vector<uint32_t> &bounds, uint32_t cap, bool keep_empty, bool want_slabs, std::vector<vgl_blk_unit> &units,
+                std::vector<vgl_blk_multi> &multi, int &n_slabs)
+{
+    n_slabs = 0;
+    for (size_t b = 0; b + 1 < bounds.size(); b++) {
+        const uint32_t c0 = bounds[b], c1 = bounds[b + 1], n = c1 - c0;
+        if (n == 0 && !keep_empty) continue;
+        const uint32_t parts = std::max<uint32_t>(1, (n + cap - 1) / cap);
+        const uint32_t step = (n + parts - 1) / parts;
+        if (parts > 1 && want_slabs) multi.push_back(vgl_blk_multi{(int32_t)b, n_slabs, (int32_t)parts, 0});
+        for (uint32_t p = 0; p < parts; p++) {
+            const uint32_t lo = c0 + p * step, hi = std::min(c1, lo + step);
+            units.push_back(vgl_blk_unit{(int32_t)b, parts > 1 ? (want_slabs ? n_slabs++ : 0) : -1, lo, hi});
+        }
+    }
+    // long units first: the tail of the launch is then made of short ones
+    std::stable_sort(units.begin(), units.end(), [](const vgl_blk_unit &x, const vgl_blk_unit &y) { return x.chunk1 - x.chunk0 > y.chunk1 - y.chunk0; });
+}
+
+}  // namespace
+
+void vgl_blocked_plan_destroy(vgl_blocked_plan *p)
+{
+    if (!p) return;
+    void *ptrs[] = {p->g_lo, p->a_lo, p->w_mid, p->mid_to_a, p->vals, p->g_units, p->a_units, p->multi, p->slabs, p->g_dirty};
+    for (void *q : ptrs) if (q) hipFree(q);
+    delete p;
+}
+
+int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                           int skip_self, const float *d_weights, vgl_blocked_plan **out)
+{
+    if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
+    if (dir.edges > 0 && (!dir.rowptr || !dir.adj || !dir.tile_row)) VGL_FAIL("blocked_plan_build: CSR direction is missing");
+    if (dir.edges >= (1LL << 32) - VGL_TILE) VGL_FAIL("blocked_plan_build: at most 2^32 edges per plan");
+    hipStream_t st = c->stream;
+    const int64_t E = dir.edges;
+    vgl_blocked_plan *p = new vgl_blocked_plan();
+    struct guard { vgl_blocked_plan *p; ~guard() { if (p) vgl_blocked_plan_destroy(p); } } own{p};
+    p->g_count = gather_rows ? nrows : ncols;
+    p->a_count = gather_rows ? ncols : nrows;
+    p->nG = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->g_count, VGL_BLK));
+    p->nA = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->a_count, VGL_BLK));
+    const uint32_t nG = (uint32_t)p->nG, nA = (uint32_t)p->nA, nseg = nG * nA;
+    if ((int64_t)nG * nA >= (1LL << 31)) VGL_FAIL("blocked_plan_build: too many block pairs");
+
+    dev_bufs tmp;
+    uint32_t *keys = nullptr, *keys2 = nullptr, *packed = nullptr, *packed2 = nullptr, *seg_first = nullptr, *seg_end = nullptr;
+    uint32_t *nch_a = nullptr, *nch_m = nullptr, *a_start = nullptr, *m_start = nullptr, *picked = nullptr;
+    float *w2 = nullptr;
+    void *sort_tmp = nullptr;
+    VGL_HIP_TRY(tmp.alloc(&seg_first, (size_t)nseg + 1));
+    VGL_HIP_TRY(tmp.alloc(&seg_end, (size_t)nseg + 1));
+    VGL_HIP_TRY(tmp.alloc(&nch_a, (size_t)nseg + 1));
+    VGL_HIP_TRY(tmp.alloc(&nch_m, (size_t)nseg + 1));
+    VGL_HIP_TRY(tmp.alloc(&a_start, (size_t)nseg + 1));
+    VGL_HIP_TRY(tmp.alloc(&m_start, (size_t)nseg + 1));
+    VGL_HIP_TRY(tmp.alloc(&picked, (size_t)nG + nA + 2));
+    VGL_HIP_TRY(hipMemsetAsync(seg_first, 0, sizeof(uint32_t) * ((size_t)nseg + 1), st));
+    VGL_HIP_TRY(hipMemsetAsync(seg_end, 0, sizeof(uint32_t) * ((size_t)nseg + 1), st));
+    if (E > 0) {
+        VGL_HIP_TRY(tmp.alloc(&keys, (size_t)E));
+        VGL_HIP_TRY(tmp.alloc(&keys2, (size_t)E));
+        VGL_HIP_TRY(tmp.alloc(&packed, (size_t)E));
+        VGL_HIP_TRY(tmp.alloc(&packed2, (size_t)E));
+        hipLaunchKernelGGL(vgl_k_blk_keys, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E,
+                           row_base, gather_rows, skip_self, nG, nseg, keys, packed);
+        VGL_HIP_TRY(hipGetLastError());
+        int bits = 1;
+        while ((1u << bits) <= nseg) bits++;                       // the sentinel nseg must sort last
+        size_t need = 0;
+        VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys2, packed, packed2, (size_t)E, 0, bits, st));
+        VGL_HIP_TRY(hipMalloc(&sort_tmp, std::max<size_t>(need, 16)));
+        tmp.ptrs.push_back(sort_tmp);
+        VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need, keys, keys2, packed, packed2, (size_t)E, 0, bits, st));
+        if (d_weights) {                                            // same keys, same stable sort: the weights land in the same order
+            VGL_HIP_TRY(hipStreamSynchronize(st));
+            tmp.release(packed);
+            packed = nullptr;
+            VGL_HIP_TRY(tmp.alloc(&w2, (size_t)E));
+            size_t need2 = 0;
+            uint32_t *keys3 = nullptr;
+            VGL_HIP_TRY(tmp.alloc(&keys3, (size_t)E));
+            VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need2, keys, keys3, d_weights, w2, (size_t)E, 0, bits, st));
+            if (need2 > need) VGL_FAIL("blocked_plan_build: radix sort scratch grew between two calls of the same size");
+            VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need2, keys, keys3, d_weights, w2, (size_t)E, 0, bits, st));
+            VGL_HIP_TRY(hipStreamSynchronize(st));
+            tmp.release(keys3);
+        }
+        hipLaunchKernelGGL(vgl_k_blk_runs, dim3((unsigned)std::min<int64_t>(16384, vgl_ceil_div(E, VGL_BLOCK))), dim3(VGL_BLOCK), 0, st, E,
+                           (const uint32_t *)keys2, seg_first, seg_end);
+        VGL_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(vgl_k_blk_nchunks, dim3((unsigned)std::min<int64_t>(4096, vgl_ceil_div((int64_t)nseg + 1, VGL_BLOCK))), dim3(VGL_BLOCK), 0, st, nG, nA,
+                       (const uint32_t *)seg_first, (const uint32_t *)seg_end, nch_a, nch_m);
+    VGL_HIP_TRY(hipGetLastError());
+    {
+        size_t need = 0;
+        void *scan_tmp = nullptr;
+        VGL_HIP_TRY(rocprim::exclusive_scan(nullptr, need, nch_a, a_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
+        VGL_HIP_TRY(hipMalloc(&scan_tmp, std::max<size_t>(need, 16)));
+        tmp.ptrs.push_back(scan_tmp);
+        VGL_HIP_TRY(rocprim::exclusive_scan(scan_tmp, need, nch_a, a_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
+        VGL_HIP_TRY(rocprim::exclusive_scan(scan_tmp, need, nch_m, m_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
+    }
+    // chunk ranges of the blocks on both sides -> host
+    hipLaunchKernelGGL(vgl_k_blk_pick, dim3(8), dim3(256), 0, st, (int)nA + 1, nG, (const uint32_t *)a_start, picked);
+    hipLaunchKernelGGL(vgl_k_blk_pick, dim3(8), dim3(256), 0, st, (int)nG + 1, nA, (const uint32_t *)m_start, picked + nA + 1);
+    VGL_HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> h((size_t)nA + nG + 2);
+    VGL_TRY(vgl_hip_memcpy_d2h(c, h.data(), picked, sizeof(uint32_t) * h.size()));
+    std::vector<uint32_t> a_bounds(h.begin(), h.begin() + nA + 1), g_bounds(h.begin() + nA + 1, h.end());
+    p->nchunks = a_bounds[nA];
+    if (g_bounds[nG] != p->nchunks) VGL_FAIL("blocked_plan_build: the two chunk orders disagree");
+    if (E > 0) {
+        uint32_t kept_end = 0;                                      // edges kept = end of the last real segment's run = start of the sentinel run
+        std::vector<uint32_t> sent(2);
+        VGL_TRY(vgl_hip_memcpy_d2h(c, &sent[0], seg_first + nseg, sizeof(uint32_t)));
+        VGL_TRY(vgl_hip_memcpy_d2h(c, &sent[1], seg_end + nseg, sizeof(uint32_t)));
+        kept_end = sent[1] > sent[0] ? sent[0] : (uint32_t)E;
+        p->edges = kept_end;
+    }
+    const size_t slots = (size_t)p->nchunks * VGL_CHUNK;
+    VGL_HIP_TRY(hipMalloc((void **)&p->g_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->a_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->vals, sizeof(uint32_t) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->mid_to_a, sizeof(uint32_t) * std::max<size_t>(p->nchunks, 1)));
+    if (d_weights) VGL_HIP_TRY(hipMalloc((void **)&p->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->g_dirty, (size_t)nG));
+    VGL_HIP_TRY(hipMemsetAsync(p->g_dirty, 1, (size_t)nG, st));
+    if (p->nchunks > 0) {
+        hipLaunchKernelGGL(vgl_k_blk_fill, dim3((unsigned)std::min<int64_t>(65536, vgl_ceil_div(p->nchunks, VGL_WAVES))), dim3(VGL_BLOCK), 0, st, p->nchunks, nG, nA,
+                           (const uint32_t *)a_start, (const uint32_t *)m_start, (const uint32_t *)seg_first, (const uint32_t *)seg_end,
+                           (const uint32_t *)packed2, (const float *)w2, p->g_lo, p->a_lo, p->w_mid, p->mid_to_a);
+        VGL_HIP_TRY(hipGetLastError());
+    }
+    // work units.  Gather units: >= 4 per CU when the graph allows (each reloads its 128 KiB window, so not below ~256 K edges);
+    // accumulate units larger (a block cut in several units costs a slab or a round of global atomics per unit)
+    const uint32_t g_cap = (uint32_t)std::max(64, env_int("VGL_BLK_GATHER_UNIT", 4096));
+    const uint32_t a_cap = (uint32_t)std::max(64, env_int("VGL_BLK_ACCUM_UNIT", 8192));
+    std::vector<vgl_blk_unit> gu, au;
+    std::vector<vgl_blk_multi> multi, none;
+    int dummy = 0;
+    make_units(g_bounds, g_cap, false, false, gu, none, dummy);
+    make_units(a_bounds, a_cap, true, true, au, multi, p->n_slabs);
+    p->n_g_units = (int)gu.size(); p->n_a_units = (int)au.size(); p->n_multi = (int)multi.size();
+    VGL_HIP_TRY(hipMalloc((void **)&p->g_units, sizeof(vgl_blk_unit) * std::max<size_t>(gu.size(), 1)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->a_units, sizeof(vgl_blk_unit) * std::max<size_t>(au.size(), 1)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->multi, sizeof(vgl_blk_multi) * std::max<size_t>(multi.size(), 1)));
+    if (!gu.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->g_units, gu.data(), sizeof(vgl_blk_unit) * gu.size()));
+    if (!au.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->a_units, au.data(), sizeof(vgl_blk_unit) * au.size()));
+    if (!multi.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->multi, multi.data(), sizeof(vgl_blk_multi) * multi.size()));
+    VGL_HIP_TRY(hipMalloc((void **)&p->slabs, sizeof(uint32_t) * VGL_BLK * (size_t)std::max(p->n_slabs, 1)));
+    VGL_HIP_TRY(hipStreamSynchronize(st));
+    own.p = nullptr;
+    *out = p;
+    return 0;
+}

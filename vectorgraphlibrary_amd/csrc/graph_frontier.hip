@@ -2,6 +2,7 @@
 // generate_new_frontier entry points and the reduce primitive.
 #include "vgl_hip_internal.h"
 #include "vgl_gnf.h"
+#include "vgl_blocked.h"
 
 // tile_row[t] = local row containing edge t*VGL_TILE: row r covers tiles [ceil(start/T), ceil(end/T))
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_rows(int32_t nrows, const int64_t *rowptr, int32_t *tile_row, int64_t ntiles)
@@ -237,6 +238,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     if (!g) return 0;
     if (c) hipStreamSynchronize(c->stream);
     if (g->transposed) { vgl_hip_graph_destroy(c, g->transposed); g->transposed = nullptr; }
+    if (g->blk_pr) { vgl_blocked_plan_destroy(g->blk_pr); g->blk_pr = nullptr; }
     void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
                     g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->out.hub_rows, g->in.hub_rows, g->out.pull_blk_row,

@@ -11,7 +11,11 @@
 //             edges staged through LDS; rows with >= 512 edges go through the hub schedule of the same launch).
 // Algorithmic bytes per iteration: 8*E + 28*V.
 #include "vgl_pull.h"
+#include "vgl_blocked.h"
 #include <queue>
+#include <cstdlib>
+
+static inline unsigned vgl_grid3(int64_t n, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
 
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pr_sum_partial(int32_t V, const float *ranks, double *partials)
 {
@@ -128,7 +132,6 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_indeg_sub_loops(const int64_t
     }
 }
 
-static inline unsigned vgl_grid3(int64_t n, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
 
 int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
 {
@@ -226,9 +229,56 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
     return 0;
 }
 
-static int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *indeg, const float *rdeg, float *ranks, float *contrib,
-                            float *ranks_out)
+// Blocked pull (vgl_blocked.h): contrib[dst] is read from a 128 KiB LDS window instead of one L2 line per edge, the per-row sums are
+// LDS float atomics -- the adjacency-order f32 chain of the kernel above is given up (results within a few ulp of it, inside the
+// 1e-6 bar of the north star, but not bit-identical to seq_page_rank and not bit-reproducible from run to run).
+struct vgl_pr_blk_op {
+    const float *contrib;
+    const float *dangling;
+    float k, d;
+    float *ranks_out;
+    int32_t a_base;
+    __device__ __forceinline__ uint32_t load(int32_t i) const { return __float_as_uint(contrib[i]); }
+    __device__ __forceinline__ uint32_t edge(uint32_t x, float) const { return x; }
+    __device__ __forceinline__ uint32_t identity() const { return 0u; }
+    __device__ __forceinline__ void accumulate(uint32_t *p, uint32_t v) const
+    {
+        __hip_atomic_fetch_add(reinterpret_cast<float *>(p), __uint_as_float(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return __float_as_uint(__fadd_rn(__uint_as_float(a), __uint_as_float(b))); }
+    __device__ __forceinline__ bool partial(int32_t, uint32_t) const { return false; }
+    __device__ __forceinline__ void finish(int32_t i, uint32_t acc) const
+    {
+        ranks_out[a_base + i] = __fadd_rn(k, __fmul_rn(d, __fadd_rn(__uint_as_float(acc), *dangling)));
+    }
+};
+
+static int vgl_pr_mode_resolve(const vgl_hip_graph *g, int mode)
 {
+    if (mode == VGL_HIP_PR_AUTO) {
+        const char *s = getenv("VGL_PR_MODE");
+        if (s && *s) mode = atoi(s);
+    }
+    if (mode == VGL_HIP_PR_AUTO) mode = g->out.edges >= (1LL << 25) ? VGL_HIP_PR_BLOCKED : VGL_HIP_PR_EXACT_ORDER;
+    return mode;
+}
+
+static int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *indeg, const float *rdeg, float *ranks, float *contrib,
+                            float *ranks_out, int mode)
+{
+    if (vgl_pr_mode_resolve(g, mode) == VGL_HIP_PR_BLOCKED) {
+        const int32_t V = g->V;
+        const float d = 0.85f;
+        const float k = (float)((1.0 - (double)d) / (double)((float)V));
+        const int npart = (int)vgl_grid3(V, 1024);
+        if (!g->blk_pr) VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, V, 0, 1, nullptr, &g->blk_pr));
+        VGL_TRY(vgl_ensure_partials(c, (size_t)npart + 8));
+        float *dangling = reinterpret_cast<float *>(c->d_partials + npart);
+        hipLaunchKernelGGL(vgl_k_pr_prepare, dim3(npart), dim3(VGL_BLOCK), 0, c->stream, V, indeg, rdeg, ranks, contrib, c->d_partials);
+        hipLaunchKernelGGL(vgl_k_pr_dangling, dim3(1), dim3(VGL_BLOCK), 0, c->stream, npart, c->d_partials, dangling);
+        const vgl_pr_blk_op op{contrib, dangling, k, d, ranks_out, g->row_begin};
+        return vgl_blocked_pass<vgl_pr_blk_op, false, true>(c, g->blk_pr, op, "pr_blk_gather", "pr_blk_accumulate");
+    }
     const int32_t V = g->V;
     const float d = 0.85f;
     const float k = (float)((1.0 - (double)d) / (double)((float)V));       // pr.hpp:37-38
@@ -276,13 +326,20 @@ int vgl_hip_pr_iteration_owned(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *
 {
     if (!c || !g || !d_indeg || !d_rdeg || !d_ranks || !d_contrib_scratch) VGL_FAIL("pr_iteration_owned: null argument");
     // in place is safe: the pull kernel reads only contrib/dangling (both produced from the old ranks) and writes owned rows
-    return vgl_pr_iteration(c, g, d_indeg, d_rdeg, d_ranks, d_contrib_scratch, d_ranks);
+    return vgl_pr_iteration(c, g, d_indeg, d_rdeg, d_ranks, d_contrib_scratch, d_ranks, VGL_HIP_PR_AUTO);
 }
 
 int vgl_hip_pr_run(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *d_indeg_noloops, int iterations, float *d_ranks,
                    vgl_hip_pr_stats *stats)
 {
+    return vgl_hip_pr_run_mode(c, g, d_indeg_noloops, iterations, VGL_HIP_PR_AUTO, d_ranks, stats);
+}
+
+int vgl_hip_pr_run_mode(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *d_indeg_noloops, int iterations, int mode, float *d_ranks,
+                        vgl_hip_pr_stats *stats)
+{
     if (!c || !g || !d_ranks) VGL_FAIL("pr_run: null argument");
+    if (mode < VGL_HIP_PR_EXACT_ORDER || mode > VGL_HIP_PR_AUTO) VGL_FAIL("pr_run: unknown mode");
     if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("pr_run: graph handle must own all rows (use the step API for shards)");
     if (iterations < 0) VGL_FAIL("pr_run: negative iteration count");
     const int32_t V = g->V;
@@ -304,7 +361,7 @@ int vgl_hip_pr_run(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *d_indeg_nolo
     VGL_TRY(vgl_hip_pr_setup(c, V, indeg, d_ranks, rdeg));
     vgl_hip_pr_stats st = {0, 0.0, 0};
     for (int it = 0; it < iterations; it++)
-        VGL_TRY(vgl_pr_iteration(c, g, indeg, rdeg, d_ranks, contrib, d_ranks));
+        VGL_TRY(vgl_pr_iteration(c, g, indeg, rdeg, d_ranks, contrib, d_ranks, mode));
     st.iterations = iterations;
     {   // reduce_ranks_sum (pr.hpp:130-134): deterministic two-stage f64 sum of the final ranks
         const int nb = (int)vgl_grid3(V, 1024);

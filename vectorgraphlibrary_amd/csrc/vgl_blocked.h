@@ -1,0 +1,193 @@
+// vgl_blocked.h -- "blocked advance": an all-edges gather/accumulate pass whose per-edge random accesses stay inside a CU.
+//
+// What it replaces: the all-active advance of the reference (multicore/advance_worker.hpp:62-149) with an edge operator of the
+// form   y[a] (+)= f(x[g], w)   -- PageRank's pull (pr.hpp:105-124), the Bellman-Ford relax (shortest_paths.hpp:123-133), the
+// Shiloach-Vishkin hook (shiloach_vishkin.hpp:37-50).  On MI355X a 4-byte gather x[adj[e]] from a table that does not fit the
+// 32 KiB L1 costs one 128-byte L2 -> L1 line whatever the L2 hit rate: ~2.1e11 gathers/s for the whole chip (measured,
+// profiles/README.md "gather floor"), i.e. 1.7 TB/s of algorithmic bytes -- the ceiling every all-edges kernel of round 1 sat on.
+// LDS serves random 4-byte reads ~20x faster, so the pass is split in two streaming kernels around 128 KiB LDS windows
+// (propagation blocking, adapted to a static graph so that only VALUES travel through memory):
+//
+//   blocks     vertices are cut into blocks of VGL_BLK = 32768 ids (128 KiB of 4-byte values: one LDS window, 1024-thread workgroup)
+//   segments   the edges with gather-side block gb and accumulate-side block ab form segment (gb, ab); a segment is padded to
+//              whole 64-entry CHUNKS (one wavefront-width; pad entries point at dummy accumulators)
+//   mid order  chunks sorted by (gb, ab): arrays g_lo (uint16 index of x inside block gb), w_mid (optional f32 edge values)
+//   A order    chunks sorted by (ab, gb): arrays a_lo (uint16 index of y inside block ab) and the scratch `vals`
+//   mid_to_a   chunk m of the mid order is chunk mid_to_a[m] of the A order
+//
+//   gather kernel      per unit (gb, chunk range): x[block gb] -> LDS; per edge vals[A position] = f(lds[g_lo], w)
+//                      reads 2 (+4) B/edge, writes 4 B/edge, all in >= 256-byte contiguous runs
+//   accumulate kernel  per unit (ab, chunk range): acc[block ab] in LDS; per edge acc[a_lo] (+)= vals; epilogue per vertex
+//                      reads 6 B/edge
+// HBM traffic 12 (16 with edge values) B/edge instead of 8 (12) B/edge + one 64-128-byte line per gather.
+//
+// Within a segment the edges keep CSR order (stable sort), so the layout is a pure function of the graph.
+#pragma once
+#include "vgl_hip_internal.h"
+
+constexpr int VGL_BLK_BITS = 15;
+constexpr int VGL_BLK = 1 << VGL_BLK_BITS;       // vertices per block
+constexpr int VGL_CHUNK = 64;                    // entries per chunk
+constexpr int VGL_BTHREADS = 1024;               // workgroup of the two kernels (16 wavefronts, one workgroup per CU: 128 KiB LDS)
+constexpr int VGL_BWAVES = VGL_BTHREADS / 64;
+constexpr int VGL_BGROUP = 8;                    // chunks per wavefront step (16 bytes of uint16 indices per lane)
+constexpr uint16_t VGL_BLK_PAD = 0x8000;          // a_lo of pad entry i of a chunk = VGL_BLK_PAD + i: 64 dummy accumulators behind the window, no branch per entry
+
+struct vgl_blk_unit {                            // one workgroup's share: chunks [chunk0, chunk1) of block `block`
+    int32_t block;
+    int32_t slab;                                // accumulate units of a block cut into several units: partial-result slab, else -1
+    uint32_t chunk0, chunk1;
+};
+struct vgl_blk_multi {                           // a block whose accumulation is spread over several units
+    int32_t block, first_slab, nslabs, pad;
+};
+
+struct vgl_blocked_plan {
+    int32_t g_count = 0, a_count = 0;            // index ranges of the gather / accumulate side
+    int32_t nG = 0, nA = 0;
+    int64_t edges = 0;                           // edges kept (self loops may be dropped at build time)
+    uint32_t nchunks = 0;
+    uint16_t *g_lo = nullptr, *a_lo = nullptr;
+    float *w_mid = nullptr;
+    uint32_t *mid_to_a = nullptr;
+    uint32_t *vals = nullptr;
+    vgl_blk_unit *g_units = nullptr, *a_units = nullptr;
+    int n_g_units = 0, n_a_units = 0;
+    vgl_blk_multi *multi = nullptr;
+    int n_multi = 0, n_slabs = 0;
+    uint32_t *slabs = nullptr;                   // n_slabs * VGL_BLK
+    uint8_t *g_dirty = nullptr;                  // nG: gather blocks whose x changed since the last pass (filtered passes)
+};
+
+// Build the plan from one CSR direction.  gather_rows = 0: x is indexed by the adjacency ids (range `ncols`), y by the local rows;
+// gather_rows = 1: x by the local rows, y by the adjacency ids.  skip_self: edges whose adjacency id equals row_base + row are left
+// out (PageRank, pr.hpp:111).  d_weights (optional): f32 per CSR position, carried to the mid order.  Synchronises; offline cost
+// (a 3-pass radix sort of the edges), like the reference's graph import.
+int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                           int skip_self, const float *d_weights, vgl_blocked_plan **out);
+void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------------------------------------
+// kernels (templates over the edge operator; instantiated by pr.hip / sssp.hip / cc.hip)
+//   OP::load(i)            -> uint32 bits of x[i] (i = index on the gather side, < g_count)
+//   OP::edge(xbits, w)     -> uint32 bits of the value that travels to the accumulate side (w = 0 without edge values)
+//   OP::identity()         -> uint32 bits the accumulators start from
+//   OP::accumulate(p, v)   LDS atomic that folds v into *p
+//   OP::finish(i, acc)     epilogue of vertex i of the accumulate side when its block was handled by ONE unit
+//   OP::partial(i, acc)    a block cut into several units: fold this unit's result into memory (min-type operators: a global
+//                          atomic), or return false to have the unit write its accumulators to a slab (sum-type operators);
+//                          vgl_k_blk_finish_slabs then adds the slabs in unit order and calls finish
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class OP, bool WEIGHTED>
+__global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_gather(const vgl_blk_unit *units, const uint16_t *g_lo, const float *w_mid,
+                                                                 const uint32_t *mid_to_a, uint32_t *vals, int32_t g_count,
+                                                                 const uint8_t *g_dirty, OP op)
+{
+    __shared__ uint32_t s_x[VGL_BLK];
+    const vgl_blk_unit u = units[blockIdx.x];
+    if (g_dirty && !g_dirty[u.block]) return;                       // nothing in this block changed: its values in `vals` still stand
+    const int32_t base = u.block << VGL_BLK_BITS;
+    const int n = min(VGL_BLK, g_count - base);
+    for (int i = threadIdx.x; i < n; i += VGL_BTHREADS) s_x[i] = op.load(base + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, off = (lane & 7) * 8;                // this lane: entries off..off+7 of chunk m0 + sub
+    for (uint32_t m0 = u.chunk0 + wave * VGL_BGROUP; m0 < u.chunk1; m0 += VGL_BWAVES * VGL_BGROUP) {
+        const uint32_t m = m0 + sub;
+        if (m >= u.chunk1) continue;
+        const size_t e = (size_t)m * VGL_CHUNK + off;
+        const uint4 gl = *reinterpret_cast<const uint4 *>(g_lo + e);
+        const uint32_t a = mid_to_a[m];
+        float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (WEIGHTED) {
+            const float4 w0 = *reinterpret_cast<const float4 *>(w_mid + e), w1 = *reinterpret_cast<const float4 *>(w_mid + e + 4);
+            w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+        }
+        const uint32_t g[4] = {gl.x, gl.y, gl.z, gl.w};
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[2 * k] = op.edge(s_x[g[k] & 0xFFFFu], w[2 * k]);
+            v[2 * k + 1] = op.edge(s_x[g[k] >> 16], w[2 * k + 1]);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(vals + (size_t)a * VGL_CHUNK + off);
+        dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+template <class OP>
+__global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_accumulate(const vgl_blk_unit *units, const uint16_t *a_lo, const uint32_t *vals,
+                                                                     int32_t a_count, uint32_t *slabs, OP op)
+{
+    __shared__ uint32_t s_acc[VGL_BLK + VGL_CHUNK];
+    const vgl_blk_unit u = units[blockIdx.x];
+    const int32_t base = u.block << VGL_BLK_BITS;
+    const int n = min(VGL_BLK, a_count - base);
+    const uint32_t ident = op.identity();
+    for (int i = threadIdx.x; i < VGL_BLK + VGL_CHUNK; i += VGL_BTHREADS) s_acc[i] = ident;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, off = (lane & 7) * 8;
+    for (uint32_t j0 = u.chunk0 + wave * VGL_BGROUP; j0 < u.chunk1; j0 += VGL_BWAVES * VGL_BGROUP) {
+        const uint32_t j = j0 + sub;
+        if (j >= u.chunk1) continue;
+        const size_t e = (size_t)j * VGL_CHUNK + off;
+        const uint4 al = *reinterpret_cast<const uint4 *>(a_lo + e);
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(vals + e), v1 = *reinterpret_cast<const uint4 *>(vals + e + 4);
+        const uint32_t a[4] = {al.x, al.y, al.z, al.w};
+        const uint32_t v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            op.accumulate(&s_acc[a[k] & 0xFFFFu], v[2 * k]);
+            op.accumulate(&s_acc[a[k] >> 16], v[2 * k + 1]);
+        }
+    }
+    __syncthreads();
+    if (u.slab < 0) {
+        for (int i = threadIdx.x; i < n; i += VGL_BTHREADS) op.finish(base + i, s_acc[i]);
+    } else {
+        uint32_t *slab = slabs + (size_t)u.slab * VGL_BLK;
+        for (int i = threadIdx.x; i < n; i += VGL_BTHREADS)
+            if (!op.partial(base + i, s_acc[i])) slab[i] = s_acc[i];
+    }
+}
+
+// sum-type operators: add the slabs of a multi-unit block in unit order (OP::combine), then the epilogue
+template <class OP>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_finish_slabs(const vgl_blk_multi *multi, const uint32_t *slabs, int32_t a_count, OP op)
+{
+    const vgl_blk_multi mb = multi[blockIdx.x];
+    const int32_t base = mb.block << VGL_BLK_BITS;
+    const int n = min(VGL_BLK, a_count - base);
+    for (int i = blockIdx.y * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.y * VGL_BLOCK) {
+        uint32_t acc = op.identity();
+        for (int s = 0; s < mb.nslabs; s++) acc = op.combine(acc, slabs[(size_t)(mb.first_slab + s) * VGL_BLK + i]);
+        op.finish(base + i, acc);
+    }
+}
+
+// one blocked pass: gather kernel, accumulate kernel and (sum-type operators) the slab epilogue, enqueued on the context stream
+template <class OP, bool WEIGHTED, bool SLABS>
+static inline int vgl_blocked_pass(vgl_hip_ctx *c, const vgl_blocked_plan *p, const OP &op, const char *gather_name, const char *accum_name,
+                                   bool filtered = false)
+{
+    if (p->n_g_units > 0) {
+        vgl_timed_launch tl(c, gather_name);
+        hipLaunchKernelGGL((vgl_k_blk_gather<OP, WEIGHTED>), dim3((unsigned)p->n_g_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_unit *)p->g_units,
+                           (const uint16_t *)p->g_lo, (const float *)p->w_mid, (const uint32_t *)p->mid_to_a, p->vals, p->g_count,
+                           (const uint8_t *)(filtered ? p->g_dirty : nullptr), op);
+    }
+    if (p->n_a_units > 0) {
+        vgl_timed_launch tl(c, accum_name);
+        hipLaunchKernelGGL((vgl_k_blk_accumulate<OP>), dim3((unsigned)p->n_a_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_unit *)p->a_units,
+                           (const uint16_t *)p->a_lo, (const uint32_t *)p->vals, p->a_count, p->slabs, op);
+    }
+    if (SLABS && p->n_multi > 0)
+        hipLaunchKernelGGL((vgl_k_blk_finish_slabs<OP>), dim3((unsigned)p->n_multi, 16), dim3(VGL_BLOCK), 0, c->stream, (const vgl_blk_multi *)p->multi,
+                           (const uint32_t *)p->slabs, p->a_count, op);
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+#endif  // __HIPCC__

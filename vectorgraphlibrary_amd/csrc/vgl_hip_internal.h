@@ -102,6 +102,7 @@ struct vgl_hip_graph {
     uint8_t *ds_tile_active = nullptr;   // delta-stepping SSSP: one byte per out-edge tile (lazy)
     vgl_hip_graph *transposed = nullptr; // SCC: handle with the two directions swapped (backward reach = BFS on it), lazy, owned
     int64_t *ds_partials = nullptr;
+    struct vgl_blocked_plan *blk_pr = nullptr;  // PageRank's blocked pull over the outgoing CSR (lazy, owned; vgl_blocked.h)
 };
 
 struct vgl_hip_frontier {
