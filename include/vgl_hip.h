@@ -159,9 +159,15 @@ typedef struct {
     int32_t iterations;
     int64_t edges_relaxed;     /* edges streamed by relax kernels */
     int64_t algorithmic_bytes; /* 12*edges_relaxed + 28*V*iterations */
+    int32_t push_steps, pull_steps;   /* super-steps by direction (iterations = their sum) */
 } vgl_hip_sssp_stats;
 #define VGL_HIP_SSSP_ALL_ACTIVE 0        /* vgl_dijkstra_all_active_push, shortest_paths.hpp:85-163: every iteration streams all edges */
 #define VGL_HIP_SSSP_ACTIVE_TILES 1      /* same fixed point, skips edge tiles whose sources did not change */
+/* 2 is the bucketed schedule (vgl_hip_sssp_run_delta below; the Python harness uses the number for it) */
+#define VGL_HIP_SSSP_PULL 3              /* vgl_dijkstra_all_active_pull, shortest_paths.hpp:169-292: every vertex takes the minimum over its
+                                            incoming edges; here a blocked gather / LDS-minimum pass, no scattered stores, no per-edge L2 line */
+#define VGL_HIP_SSSP_DIRECTION_OPT 4     /* push (rows that changed, atomic minima) while few rows change, pull while many do; the switch is
+                                            on the share of edges whose source changed in the last super-step (VGL_SSSP_PULL_SHARE, 0.35) */
 int vgl_hip_sssp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode,
                      float *d_dist, vgl_hip_sssp_stats *stats);
 /* SSWP::vgl_dijkstra, algorithms/sswp/widest_paths.hpp:5-76 (single-source widest paths): widths[source] = FLT_MAX, others 0;
@@ -173,6 +179,16 @@ int vgl_hip_sswp_init(vgl_hip_ctx *ctx, int32_t V, int32_t source, float *d_widt
 int vgl_hip_sswp_relax_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capacities, float *d_widths, int *changed);
 int vgl_hip_sswp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capacities, int32_t source, int mode,
                      float *d_widths, vgl_hip_sssp_stats *stats);
+/* The pull steps work on a blocked copy of (outgoing adjacency, edge values) -- vgl_blocked.h -- built once per (graph, weights)
+ * like the reference's graph import and reusable for any number of sources; vgl_hip_sssp_run / vgl_hip_sswp_run with mode PULL or
+ * DIRECTION_OPT = create + run + destroy.  mode: VGL_HIP_SSSP_PULL or VGL_HIP_SSSP_DIRECTION_OPT. */
+typedef struct vgl_hip_sssp_pull_plan vgl_hip_sssp_pull_plan;
+int vgl_hip_sssp_pull_plan_create(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan **out);
+int vgl_hip_sssp_pull_plan_destroy(vgl_hip_ctx *ctx, vgl_hip_sssp_pull_plan *plan);
+int vgl_hip_sssp_run_pull(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan *plan, int32_t source,
+                          int mode, float *d_dist, vgl_hip_sssp_stats *stats);
+int vgl_hip_sswp_run_pull(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capacities, vgl_hip_sssp_pull_plan *plan, int32_t source,
+                          int mode, float *d_widths, vgl_hip_sssp_stats *stats);
 
 /* Same operators and bit-identical distances, bucketed schedule (delta-stepping with a light/heavy edge split): light
  * edges (w < delta) of a vertex are relaxed whenever it improves inside the current distance bucket, heavy edges once the

@@ -41,3 +41,43 @@ for mode, name in ((api.PR_BLOCKED, "blocked"), (api.PR_EXACT_ORDER, "exact-orde
         rel = ((rb - r).abs() / r).max().item()
         print(f"  max relative difference blocked vs exact-order: {rel:.3e}")
 g.close()
+
+if kind == "rmat":
+    # SSSP on the same kind of graph: push (active tiles), pull (blocked, every step), direction-optimising
+    s, d = ctx.gen_rmat(scale, ef, 1)
+    g = api.Graph.from_coo(ctx, V, s, d, with_incoming=True, want_perm=True, renumber="total")
+    w = ctx.gather_u32(g.perm, ctx.gen_weights(E, 1))
+    del s, d
+    deg = g.out_rowptr[1:] - g.out_rowptr[:-1]
+    srcs = [int(x) for x in torch.nonzero(deg > 0).flatten()[torch.randint(0, int((deg > 0).sum()), (3,), generator=torch.Generator().manual_seed(5))]]
+    t0 = time.perf_counter()
+    plan = api.SsspPullPlan(g, w)
+    torch.cuda.synchronize()
+    print(f"SSSP pull plan build {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+    ref = None
+    for name, kw in (("push all-active", dict(mode=api.SSSP_ALL_ACTIVE)), ("push active tiles", dict(mode=api.SSSP_ACTIVE_TILES)),
+                     ("pull (blocked)", dict(mode=api.SSSP_PULL, plan=plan)), ("direction-opt 0.35", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan)),
+                     ("direction-opt 0.2", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.2")),
+                     ("direction-opt 0.5", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.5")),
+                     ("direction-opt 0.7", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.7"))):
+        share = kw.pop("share", None)
+        if share:
+            os.environ["VGL_SSSP_PULL_SHARE"] = share
+        api.sssp(g, w, srcs[0], raw=True, **kw)
+        ctx.timing(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sts = []
+        for sx in srcs:
+            dd, st = api.sssp(g, w, sx, raw=True, **kw)
+            sts.append(st)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / len(srcs)
+        parts = {k: ctx.timing_get(k) for k in ("sssp_relax", "sssp_pull_gather", "sssp_pull_accumulate")}
+        ctx.timing(False)
+        os.environ.pop("VGL_SSSP_PULL_SHARE", None)
+        if ref is None:
+            ref = dd.clone()
+        same = bool((dd.view(torch.int32) == ref.view(torch.int32)).all())
+        print(f"  {name:20s} {dt * 1e3:8.3f} ms  {E / dt / 1e9:6.1f} GTEPS  steps {sts[-1]['iterations']} (push {sts[-1]['push_steps']} pull {sts[-1]['pull_steps']})  same bits {same}  "
+              + "  ".join(f"{k} {v[1] / max(v[0], 1):.3f} ms x{v[0]}" for k, v in parts.items() if v[0]), flush=True)

@@ -71,17 +71,19 @@ def test_algorithms_match_oracle_and_golden(path, ctx, oracle):
 
     # ---- SSSP: both schedules reach the same bit-exact fixed point ----
     ref_dist, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
-    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING, api.SSSP_PULL, api.SSSP_DIRECTION_OPT):
         dist, st = api.sssp(g, w_d, source, mode)
         dv = dist.cpu().numpy()
         assert (dv.view(np.int32) == ref_dist.view(np.int32)).all(), f"SSSP mode {mode}: distances differ from the oracle"
         assert O.fnv1a64(dv) == int(z["sssp_fnv"])
+        if mode == api.SSSP_PULL:
+            assert st["pull_steps"] == st["iterations"] and st["push_steps"] == 0
     if full:
         assert (dv.view(np.int32) == z["dist"].view(np.int32)).all()
 
     # ---- SSWP (f1 widening): widest paths on the same capacities, both schedules, bit-exact (only min / max of the inputs) ----
     ref_width, _ = O.sswp_bellman_ford(rowptr, adj, w, source)
-    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES):
+    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_PULL, api.SSSP_DIRECTION_OPT):
         width, st = api.sswp(g, w_d, source, mode)
         wv = width.cpu().numpy()
         assert (wv.view(np.int32) == ref_width.view(np.int32)).all(), f"SSWP mode {mode}: widths differ from the oracle"
@@ -997,4 +999,47 @@ def test_pagerank_blocked_pull(kind, scale, ef, renumber, ctx, oracle):
                 g2.close()
     exact, _ = api.page_rank(g, 4, raw=True, mode=api.PR_EXACT_ORDER)
     assert (exact.cpu().numpy().view(np.int32) == O.pagerank(rowptr, adj, 4, 1).view(np.int32)).all()
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef,renumber", [("rmat", 17, 16, "total"), ("rmat", 17, 16, None), ("ru", 17, 8, None), ("ru", 16, 2, None)])
+def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, oracle):
+    """pull (blocked gather / LDS minimum) and push <-> pull switching SSSP / SSWP on graphs of several blocks: f32 bits equal to the
+    oracle's Bellman-Ford for every switch point (share 0: always pull after the first step; 2: never), reusable plan, small units
+    (blocks cut into several units fold their minima with global atomics), several sources."""
+    import os
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    V, seed = 1 << scale, 33
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True, renumber=renumber)
+    w_d = ctx.gather_u32(g.perm, ctx.gen_weights(src.numel(), seed))
+    rowptr, adj, w = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy(), w_d.cpu().numpy()
+    for unit in ("", "64"):
+        if unit:
+            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = unit
+        try:
+            plan = api.SsspPullPlan(g, w_d)
+        finally:
+            os.environ.pop("VGL_BLK_GATHER_UNIT", None), os.environ.pop("VGL_BLK_ACCUM_UNIT", None)
+        for k in range(2):
+            s = O.pick_source(rowptr, seed, k)
+            ref, _ = O.sssp_bellman_ford(rowptr, adj, w, s)
+            refw, _ = O.sswp_bellman_ford(rowptr, adj, w, s)
+            for share in ("0", "0.35", "2"):
+                os.environ["VGL_SSSP_PULL_SHARE"] = share
+                try:
+                    d, st = api.sssp(g, w_d, s, api.SSSP_DIRECTION_OPT, raw=True, plan=plan)
+                    wd, wst = api.sswp(g, w_d, s, api.SSSP_DIRECTION_OPT, raw=True, plan=plan)
+                finally:
+                    del os.environ["VGL_SSSP_PULL_SHARE"]
+                assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all(), (unit, k, share)
+                assert (wd.cpu().numpy().view(np.int32) == refw.view(np.int32)).all(), (unit, k, share)
+                assert st["push_steps"] + st["pull_steps"] == st["iterations"]
+                if share == "2":
+                    assert st["pull_steps"] == 0
+            d, st = api.sssp(g, w_d, s, api.SSSP_PULL, raw=True, plan=plan)
+            assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all() and st["push_steps"] == 0
+        plan.close()
     g.close()

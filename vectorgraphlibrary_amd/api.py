@@ -15,7 +15,7 @@ from . import lib as _l
 
 RMAT_ABCD = (57, 19, 19, 5)            # vgl_runtime.hpp:36
 BFS_TOP_DOWN, BFS_DIRECTION_OPT = 0, 1
-SSSP_ALL_ACTIVE, SSSP_ACTIVE_TILES, SSSP_DELTA_STEPPING = 0, 1, 2
+SSSP_ALL_ACTIVE, SSSP_ACTIVE_TILES, SSSP_DELTA_STEPPING, SSSP_PULL, SSSP_DIRECTION_OPT = 0, 1, 2, 3, 4
 DENSE, SPARSE, ALL_ACTIVE = 0, 1, 2    # framework_types.h:156-160
 PR_EXACT_ORDER, PR_BLOCKED, PR_AUTO = 0, 1, 2
 
@@ -290,12 +290,32 @@ class SsspPlan:
             self.h = None
 
 
+class SsspPullPlan:
+    """blocked copy of (outgoing adjacency, edge values) for the pull steps of SSSP / SSWP (vgl_blocked.h); reusable across sources."""
+
+    def __init__(self, graph, weights):
+        self.g, self.ctx, self.weights = graph, graph.ctx, weights
+        h = C.c_void_p()
+        _l.check(self.ctx.L.vgl_hip_sssp_pull_plan_create(self.ctx.h, graph.h, _ptr(weights), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.L.vgl_hip_sssp_pull_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
 def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False, delta=16.0, plan=None):
+    """mode: SSSP_ALL_ACTIVE / SSSP_ACTIVE_TILES (push), SSSP_DELTA_STEPPING, SSSP_PULL, SSSP_DIRECTION_OPT (push <-> pull).
+    plan: an SsspPlan (bucketed schedule) or an SsspPullPlan (with mode SSSP_PULL or SSSP_DIRECTION_OPT)."""
     ctx = graph.ctx
     dist = ctx.empty(graph.V, torch.float32) if dist is None else dist
     st = _l.SsspStats()
     s = int(source) if raw else graph.vertex_id(source)
-    if plan is not None:
+    if isinstance(plan, SsspPullPlan):
+        m = mode if mode in (SSSP_PULL, SSSP_DIRECTION_OPT) else SSSP_DIRECTION_OPT
+        _l.check(ctx.L.vgl_hip_sssp_run_pull(ctx.h, graph.h, _ptr(weights), plan.h, s, int(m), _ptr(dist), C.byref(st)))
+    elif plan is not None:
         _l.check(ctx.L.vgl_hip_sssp_run_plan(ctx.h, graph.h, plan.h, s, _ptr(dist), C.byref(st)))
     elif mode == SSSP_DELTA_STEPPING:
         _l.check(ctx.L.vgl_hip_sssp_run_delta(ctx.h, graph.h, _ptr(weights), s, float(delta), _ptr(dist), C.byref(st)))
@@ -304,14 +324,18 @@ def sssp(graph, weights, source, mode=SSSP_ACTIVE_TILES, dist=None, raw=False, d
     return (dist if raw else graph.to_original(dist)), _stats(st)
 
 
-def sswp(graph, capacities, source, mode=SSSP_ACTIVE_TILES, widths=None, raw=False):
+def sswp(graph, capacities, source, mode=SSSP_ACTIVE_TILES, widths=None, raw=False, plan=None):
     """single-source widest paths (SSWP::vgl_dijkstra): widths[source] = FLT_MAX, unreachable vertices 0; capacities in the
     order of the outgoing CSR.  source / result in ORIGINAL numbering unless raw=True."""
     ctx = graph.ctx
     widths = ctx.empty(graph.V, torch.float32) if widths is None else widths
     st = _l.SsspStats()
     src = int(source) if raw else graph.vertex_id(source)
-    _l.check(ctx.L.vgl_hip_sswp_run(ctx.h, graph.h, _ptr(capacities), src, int(mode), _ptr(widths), C.byref(st)))
+    if isinstance(plan, SsspPullPlan):
+        m = mode if mode in (SSSP_PULL, SSSP_DIRECTION_OPT) else SSSP_DIRECTION_OPT
+        _l.check(ctx.L.vgl_hip_sswp_run_pull(ctx.h, graph.h, _ptr(capacities), plan.h, src, int(m), _ptr(widths), C.byref(st)))
+    else:
+        _l.check(ctx.L.vgl_hip_sswp_run(ctx.h, graph.h, _ptr(capacities), src, int(mode), _ptr(widths), C.byref(st)))
     return (widths if raw else graph.to_original(widths)), _stats(st)
 
 

@@ -16,7 +16,9 @@
 // is a template parameter -- (min, +) with "smaller is better" for SSSP, (max, min) with "larger is better" for SSWP.  Widths
 // are non-negative too, so the integer atomic-max on the f32 bits is exact; only min / max of inputs occur (no rounding).
 #include "vgl_hip_internal.h"
+#include "vgl_blocked.h"
 #include <cfloat>
+#include <cstdlib>
 #include <string>
 
 struct vgl_path_shortest {                        // shortest_paths.hpp:99-133
@@ -147,6 +149,128 @@ static int vgl_sssp_launch(vgl_hip_ctx *c, vgl_hip_graph *g, const float *w, flo
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pull steps (SSSP::vgl_dijkstra_all_active_pull, shortest_paths.hpp:169-292: every vertex takes the minimum over its incoming
+// edges, no scattered stores) as a blocked pass (vgl_blocked.h) over the OUTGOING CSR with the rows as the gather side: dist[src]
+// is read from a 128 KiB LDS window, dist[src] (+) w travels to the destination's block, where the minimum is an LDS integer
+// atomic; one plain compare + store per vertex ends the step (blocks cut into several units: one global atomic per improved
+// vertex and unit).  No random L2 line per edge and no global atomics per edge.  A pull step sees the distances as they were
+// when it started (Jacobi), so it moves information one hop per step; the push kernel above (asynchronous, work proportional to
+// the rows that changed) is better when few rows changed.  DIRECTION_OPT switches between the two per super-step on the share
+// of the edges whose source changed in the step before -- the fixed point, hence every bit of the result, is the same.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class Path>
+struct vgl_path_blk_op {
+    float *dist;
+    int32_t *epoch;
+    int32_t iter, g_base;
+    int64_t *counters;
+    __device__ __forceinline__ uint32_t load(int32_t i) const { return __float_as_uint(dist[g_base + i]); }
+    __device__ __forceinline__ uint32_t edge(uint32_t x, float w) const
+    {
+        const float d = __uint_as_float(x);
+        return __float_as_uint(Path::live(d) ? Path::extend(d, w) : Path::dead_value());
+    }
+    __device__ __forceinline__ uint32_t identity() const { return __float_as_uint(Path::other_value()); }
+    __device__ __forceinline__ void accumulate(uint32_t *p, uint32_t v) const
+    {
+        if (Path::better(1.0f, 2.0f)) __hip_atomic_fetch_min(reinterpret_cast<int *>(p), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_max(reinterpret_cast<int *>(p), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return Path::better(__uint_as_float(b), __uint_as_float(a)) ? b : a; }
+    __device__ __forceinline__ void finish(int32_t v, uint32_t acc) const
+    {
+        const float cand = __uint_as_float(acc);
+        if (Path::better(cand, dist[v])) { dist[v] = cand; epoch[v] = iter; counters[C_CHANGED] = 1; }
+    }
+    __device__ __forceinline__ bool partial(int32_t v, uint32_t acc) const
+    {
+        const float cand = __uint_as_float(acc);
+        if (Path::better(cand, dist[v])) {
+            const int before = Path::update(dist + v, cand);
+            if (Path::improved(before, cand)) { epoch[v] = iter; counters[C_CHANGED] = 1; }
+        }
+        return true;
+    }
+};
+
+// rows that changed in super-step `iter` and the number of their outgoing edges (what the next push step would relax)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_active_count(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *epoch,
+                                                                     int32_t iter, int64_t *counters)
+{
+    __shared__ unsigned long long s[VGL_WAVES];
+    unsigned long long rows = 0, edges = 0;
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK)
+        if (epoch[row_base + r] == iter) { rows++; edges += (unsigned long long)(rowptr[r + 1] - rowptr[r]); }
+    rows = vgl_block_reduce_add(rows, s);
+    edges = vgl_block_reduce_add(edges, s);
+    if (threadIdx.x == 0 && rows) {
+        atomicAdd((unsigned long long *)&counters[C_FRONT], rows);
+        atomicAdd((unsigned long long *)&counters[C_NEIGH], edges);
+    }
+}
+
+struct vgl_hip_sssp_pull_plan {
+    vgl_blocked_plan *blk = nullptr;
+    const float *weights = nullptr;
+    vgl_hip_graph *g = nullptr;
+};
+
+template <class Path>
+static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan *plan, int32_t source, int mode,
+                             float *d_dist, vgl_hip_sssp_stats *stats, const char *who)
+{
+    auto fail = [&](const char *what) { return vgl_set_error(__FILE__, __LINE__, (std::string(who) + ": " + what).c_str()); };
+    if (!c || !g || !d_weights || !d_dist || !plan || !plan->blk) return fail("null argument");
+    if (plan->g != g || plan->weights != d_weights) return fail("the pull plan was built for another graph or weight array");
+    if (g->row_begin != 0 || g->row_end != g->V) return fail("graph handle must own all rows");
+    if (source < 0 || source >= g->V) return fail("source vertex out of range");
+    if (mode != VGL_HIP_SSSP_PULL && mode != VGL_HIP_SSSP_DIRECTION_OPT) return fail("unknown mode");
+    const char *env = getenv("VGL_SSSP_PULL_SHARE");
+    const double share = (env && *env) ? atof(env) : 0.35;      // pull when the rows that changed own more than this share of the edges
+    hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, g->epoch);
+    VGL_TRY(vgl_zero_counters(c, C_EDGES, 1));
+    vgl_hip_sssp_stats st = {0, 0, 0, 0, 0};
+    int64_t active_edges = 0;                                   // out-edges of the rows that changed in the last step (the source: unknown, small)
+    int64_t pull_edges = 0;
+    for (int32_t iter = 1;; iter++) {
+        const bool pull = mode == VGL_HIP_SSSP_PULL || (double)active_edges > share * (double)g->out.edges;
+        VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
+        VGL_TRY(vgl_zero_counters(c, C_FRONT, 2));
+        if (pull) {
+            const vgl_path_blk_op<Path> op{d_dist, g->epoch, iter, g->row_begin, c->d_counters};
+            VGL_TRY((vgl_blocked_pass<vgl_path_blk_op<Path>, true, false>(c, plan->blk, op, "sssp_pull_gather", "sssp_pull_accumulate")));
+            pull_edges += plan->blk->edges;
+            st.pull_steps++;
+        } else {
+            VGL_TRY(vgl_sssp_launch<Path>(c, g, d_weights, d_dist, true, iter));
+            st.push_steps++;
+        }
+        if (mode == VGL_HIP_SSSP_DIRECTION_OPT && g->nrows > 0)
+            hipLaunchKernelGGL(vgl_k_sssp_active_count, dim3(vgl_grid1(g->nrows) > 1024 ? 1024 : vgl_grid1(g->nrows)), dim3(VGL_BLOCK), 0, c->stream, g->nrows,
+                               g->row_begin, g->out.rowptr, (const int32_t *)g->epoch, iter, c->d_counters);
+        VGL_TRY(vgl_read_counters(c));
+        st.iterations = iter;
+        if (!c->h_counters[C_CHANGED]) break;
+        active_edges = c->h_counters[C_NEIGH];
+    }
+    st.edges_relaxed = c->h_counters[C_EDGES] + pull_edges;
+    st.algorithmic_bytes = 12 * st.edges_relaxed + 28 * (int64_t)g->V * st.iterations;
+    if (stats) *stats = st;
+    return 0;
+}
+
+static int vgl_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan **out)
+{
+    if (!c || !g || !d_weights || !out) VGL_FAIL("sssp_pull_plan_create: null argument");
+    vgl_hip_sssp_pull_plan *p = new vgl_hip_sssp_pull_plan();
+    p->g = g; p->weights = d_weights;
+    const int rc = vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, d_weights, &p->blk);
+    if (rc) { delete p; return rc; }
+    *out = p;
+    return 0;
+}
+
 // shared driver of vgl_hip_sssp_run / vgl_hip_sswp_run: super-steps until a pass changes nothing
 template <class Path>
 static int vgl_path_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode, float *d_dist, vgl_hip_sssp_stats *stats,
@@ -156,14 +280,24 @@ static int vgl_path_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights
     if (!c || !g || !d_weights || !d_dist) return fail("null argument");
     if (g->row_begin != 0 || g->row_end != g->V) return fail("graph handle must own all rows (use the *_relax_owned step for shards)");
     if (source < 0 || source >= g->V) return fail("source vertex out of range");
+    if (mode == VGL_HIP_SSSP_PULL || mode == VGL_HIP_SSSP_DIRECTION_OPT) {      // one-off: build the blocked layout, run, drop it
+        vgl_hip_sssp_pull_plan *plan = nullptr;
+        VGL_TRY(vgl_pull_plan_create(c, g, d_weights, &plan));
+        const int rc = vgl_path_run_pull<Path>(c, g, d_weights, plan, source, mode, d_dist, stats, who);
+        hipStreamSynchronize(c->stream);
+        vgl_blocked_plan_destroy(plan->blk);
+        delete plan;
+        return rc;
+    }
     if (mode != VGL_HIP_SSSP_ALL_ACTIVE && mode != VGL_HIP_SSSP_ACTIVE_TILES) return fail("unknown mode");
     const bool filter = mode == VGL_HIP_SSSP_ACTIVE_TILES;
     hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, g->epoch);
     VGL_TRY(vgl_zero_counters(c, C_EDGES, 1));
-    vgl_hip_sssp_stats st = {0, 0, 0};
+    vgl_hip_sssp_stats st = {0, 0, 0, 0, 0};
     for (int32_t iter = 1;; iter++) {
         VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
         VGL_TRY(vgl_sssp_launch<Path>(c, g, d_weights, d_dist, filter, iter));
+        st.push_steps++;
         VGL_TRY(vgl_read_counters(c));
         st.iterations = iter;
         if (!c->h_counters[C_CHANGED]) break;      // do { ... } while(changes)  (shortest_paths.hpp:112-154, widest_paths.hpp:34-64)
@@ -175,6 +309,29 @@ static int vgl_path_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights
 }
 
 extern "C" {
+
+int vgl_hip_sssp_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan **out)
+{
+    return vgl_pull_plan_create(c, g, d_weights, out);
+}
+int vgl_hip_sssp_pull_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_pull_plan *p)
+{
+    if (!p) return 0;
+    if (c) hipStreamSynchronize(c->stream);
+    vgl_blocked_plan_destroy(p->blk);
+    delete p;
+    return 0;
+}
+int vgl_hip_sssp_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan *plan, int32_t source, int mode,
+                          float *d_dist, vgl_hip_sssp_stats *stats)
+{
+    return vgl_path_run_pull<vgl_path_shortest>(c, g, d_weights, plan, source, mode, d_dist, stats, "sssp_run_pull");
+}
+int vgl_hip_sswp_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_capacities, vgl_hip_sssp_pull_plan *plan, int32_t source, int mode,
+                          float *d_widths, vgl_hip_sssp_stats *stats)
+{
+    return vgl_path_run_pull<vgl_path_widest>(c, g, d_capacities, plan, source, mode, d_widths, stats, "sswp_run_pull");
+}
 
 int vgl_hip_sssp_init(vgl_hip_ctx *c, int32_t V, int32_t source, float *d_dist)
 {

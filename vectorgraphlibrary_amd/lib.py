@@ -23,7 +23,8 @@ class BfsStats(C.Structure):
 
 
 class SsspStats(C.Structure):
-    _fields_ = [("iterations", C.c_int32), ("edges_relaxed", C.c_int64), ("algorithmic_bytes", C.c_int64)]
+    _fields_ = [("iterations", C.c_int32), ("edges_relaxed", C.c_int64), ("algorithmic_bytes", C.c_int64),
+                ("push_steps", C.c_int32), ("pull_steps", C.c_int32)]
 
 
 class PrStats(C.Structure):
@@ -85,6 +86,10 @@ _SIGNATURES = {
     "vgl_hip_sssp_run": [_p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
     "vgl_hip_sswp_run": [_p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
     "vgl_hip_sssp_run_delta": [_p, _p, _p, _i32, C.c_float, _p, C.POINTER(SsspStats)],
+    "vgl_hip_sssp_pull_plan_create": [_p, _p, _p, _pp],
+    "vgl_hip_sssp_pull_plan_destroy": [_p, _p],
+    "vgl_hip_sssp_run_pull": [_p, _p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
+    "vgl_hip_sswp_run_pull": [_p, _p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
     "vgl_hip_sssp_plan_create": [_p, _p, _p, C.c_float, _pp],
     "vgl_hip_sssp_plan_destroy": [_p, _p],
     "vgl_hip_sssp_run_plan": [_p, _p, _p, _i32, _p, C.POINTER(SsspStats)],
