@@ -214,11 +214,13 @@ typedef struct {
  * d_indeg_noloops: int32[V] = in-degree minus self loops (pr.hpp:31-65), or NULL to have it computed. */
 int vgl_hip_pr_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_indeg_noloops, int iterations,
                    float *d_ranks, vgl_hip_pr_stats *stats);
-/* Two evaluation orders of the per-vertex sum (both inside the 1e-6 bar of the north star):
+/* Two evaluations of the per-vertex sum (north star: within 1e-6 relative of the reference):
  *   EXACT_ORDER  f32 `+=` chain in adjacency order, bit-identical to seq_page_rank (seq_pr.hpp:81-96); one random L2 line per edge
  *   BLOCKED      contributions gathered from and summed in 128 KiB LDS windows (vgl_blocked.h): 12 B/edge of streamed HBM traffic, no
- *                random line per edge; sums are LDS float atomics (a few ulp from the chain, not bit-reproducible run to run)
- *   AUTO         BLOCKED from 2^25 stored edges, EXACT_ORDER below (what vgl_hip_pr_run uses; VGL_PR_MODE=0|1 overrides) */
+ *                random line per edge; the sums are exact (64-bit fixed point, rounded to f32 once) and therefore independent of any
+ *                order -- they differ from the chain by the CHAIN's rounding error, ~sqrt(n) * 3e-8 for a row of n entries
+ *   AUTO         BLOCKED when the graph stores >= 2^25 edges and no row is longer than 256 entries (uniform-random inputs), else
+ *                EXACT_ORDER; what vgl_hip_pr_run uses (VGL_PR_MODE=0|1 overrides) */
 #define VGL_HIP_PR_EXACT_ORDER 0
 #define VGL_HIP_PR_BLOCKED 1
 #define VGL_HIP_PR_AUTO 2

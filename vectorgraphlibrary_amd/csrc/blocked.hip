@@ -27,7 +27,7 @@ struct dev_bufs {                                   // frees whatever the build 
 // key = ab * nG + gb (sentinel nseg for dropped self loops), value = g_lo | a_lo << 16
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_keys(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E,
                                                             int32_t row_base, int gather_rows, int skip_self, uint32_t nG, uint32_t nseg,
-                                                            uint32_t *keys, uint32_t *packed)
+                                                            int a_bits, uint32_t *keys, uint32_t *packed)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int s_w[VGL_WAVES];
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_keys(const int64_t *rowpt
             const uint32_t r = (uint32_t)(r_first + s_map[i]), col = (uint32_t)adj[e0 + i];
             const uint32_t g = gather_rows ? r : col, a = gather_rows ? col : r;
             const bool drop = skip_self && (uint32_t)row_base + r == col;
-            keys[e0 + i] = drop ? nseg : (a >> VGL_BLK_BITS) * nG + (g >> VGL_BLK_BITS);
-            packed[e0 + i] = (g & (VGL_BLK - 1)) | ((a & (VGL_BLK - 1)) << 16);
+            keys[e0 + i] = drop ? nseg : (a >> a_bits) * nG + (g >> VGL_BLK_BITS);
+            packed[e0 + i] = (g & (VGL_BLK - 1)) | ((a & ((1u << a_bits) - 1)) << 16);
         }
     }
 }
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_nchunks(uint32_t nG, uint
 // one wavefront per A-order chunk: find its segment, place the chunk in both orders
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill(uint32_t nchunks, uint32_t nG, uint32_t nA, const uint32_t *a_start, const uint32_t *m_start,
                                                             const uint32_t *seg_first, const uint32_t *seg_end, const uint32_t *packed_sorted,
-                                                            const float *w_sorted, uint16_t *g_lo, uint16_t *a_lo, float *w_mid, uint32_t *mid_to_a)
+                                                            const float *w_sorted, int a_bits, uint16_t *g_lo, uint16_t *a_lo, float *w_mid, uint32_t *mid_to_a)
 {
     const uint32_t nseg = nG * nA;
     const int lane = threadIdx.x & 63;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill(uint32_t nchunks, ui
         const uint32_t within = j - a_start[k];
         const uint32_t m = m_start[gb * nA + ab] + within;
         const uint32_t pos = within * VGL_CHUNK + lane, cnt = seg_end[k] - seg_first[k];
-        uint16_t gl = 0, al = (uint16_t)(VGL_BLK_PAD + lane);
+        uint16_t gl = 0, al = (uint16_t)((1u << a_bits) + lane);
         float w = 0.0f;
         if (pos < cnt) {
             const uint32_t pk = packed_sorted[seg_first[k] + pos];
@@ -147,9 +147,10 @@ void vgl_blocked_plan_destroy(vgl_blocked_plan *p)
 }
 
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
-                           int skip_self, const float *d_weights, vgl_blocked_plan **out)
+                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out)
 {
     if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
+    if (a_bits != VGL_BLK_BITS && a_bits != VGL_BLK_BITS - 1) VGL_FAIL("blocked_plan_build: accumulate blocks hold 2^15 (4-byte) or 2^14 (8-byte) accumulators");
     if (dir.edges > 0 && (!dir.rowptr || !dir.adj || !dir.tile_row)) VGL_FAIL("blocked_plan_build: CSR direction is missing");
     if (dir.edges >= (1LL << 32) - VGL_TILE) VGL_FAIL("blocked_plan_build: at most 2^32 edges per plan");
     hipStream_t st = c->stream;
@@ -159,7 +160,8 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     p->g_count = gather_rows ? nrows : ncols;
     p->a_count = gather_rows ? ncols : nrows;
     p->nG = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->g_count, VGL_BLK));
-    p->nA = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->a_count, VGL_BLK));
+    p->a_bits = a_bits;
+    p->nA = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->a_count, 1 << a_bits));
     const uint32_t nG = (uint32_t)p->nG, nA = (uint32_t)p->nA, nseg = nG * nA;
     if ((int64_t)nG * nA >= (1LL << 31)) VGL_FAIL("blocked_plan_build: too many block pairs");
 
@@ -183,7 +185,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         VGL_HIP_TRY(tmp.alloc(&packed, (size_t)E));
         VGL_HIP_TRY(tmp.alloc(&packed2, (size_t)E));
         hipLaunchKernelGGL(vgl_k_blk_keys, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E,
-                           row_base, gather_rows, skip_self, nG, nseg, keys, packed);
+                           row_base, gather_rows, skip_self, nG, nseg, a_bits, keys, packed);
         VGL_HIP_TRY(hipGetLastError());
         int bits = 1;
         while ((1u << bits) <= nseg) bits++;                       // the sentinel nseg must sort last
@@ -250,7 +252,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     if (p->nchunks > 0) {
         hipLaunchKernelGGL(vgl_k_blk_fill, dim3((unsigned)std::min<int64_t>(65536, vgl_ceil_div(p->nchunks, VGL_WAVES))), dim3(VGL_BLOCK), 0, st, p->nchunks, nG, nA,
                            (const uint32_t *)a_start, (const uint32_t *)m_start, (const uint32_t *)seg_first, (const uint32_t *)seg_end,
-                           (const uint32_t *)packed2, (const float *)w2, p->g_lo, p->a_lo, p->w_mid, p->mid_to_a);
+                           (const uint32_t *)packed2, (const float *)w2, a_bits, p->g_lo, p->a_lo, p->w_mid, p->mid_to_a);
         VGL_HIP_TRY(hipGetLastError());
     }
     // work units.  Gather units: >= 4 per CU when the graph allows (each reloads its 128 KiB window, so not below ~256 K edges);
@@ -269,7 +271,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     if (!gu.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->g_units, gu.data(), sizeof(vgl_blk_unit) * gu.size()));
     if (!au.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->a_units, au.data(), sizeof(vgl_blk_unit) * au.size()));
     if (!multi.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->multi, multi.data(), sizeof(vgl_blk_multi) * multi.size()));
-    VGL_HIP_TRY(hipMalloc((void **)&p->slabs, sizeof(uint32_t) * VGL_BLK * (size_t)std::max(p->n_slabs, 1)));
+    VGL_HIP_TRY(hipMalloc(&p->slabs, sizeof(uint32_t) * VGL_BLK * (size_t)std::max(p->n_slabs, 1)));
     VGL_HIP_TRY(hipStreamSynchronize(st));
     own.p = nullptr;
     *out = p;

@@ -229,10 +229,15 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
     return 0;
 }
 
-// Blocked pull (vgl_blocked.h): contrib[dst] is read from a 128 KiB LDS window instead of one L2 line per edge, the per-row sums are
-// LDS float atomics -- the adjacency-order f32 chain of the kernel above is given up (results within a few ulp of it, inside the
-// 1e-6 bar of the north star, but not bit-identical to seq_page_rank and not bit-reproducible from run to run).
+// Blocked pull (vgl_blocked.h): contrib[dst] is read from a 128 KiB LDS window instead of one L2 line per edge and the per-row sums
+// are kept in 64-bit FIXED POINT (unit 2^-62; LDS float atomics are ~30x slower than integer ones on this chip): every contribution
+// of at least 2^-39 converts exactly, smaller ones lose less than 2^-62 each, integer addition is associative -- so the sum is the
+// exact sum of the f32 products (rounded to f32 once at the end), the same bits whatever the order of arrival, from run to run and
+// for any cut into units.  It is NOT the reference's f32 `+=` chain in adjacency order: the two differ by the chain's own rounding
+// error (~sqrt(n) * 3e-8 for a row of n entries: 2-6e-7 on uniform-25, 1e-4 on the largest RMAT-24 hub), which is why AUTO keeps the
+// ordered kernel whenever a row is long enough for that to approach the 1e-6 bar of the north star.
 struct vgl_pr_blk_op {
+    typedef unsigned long long acc_t;
     const float *contrib;
     const float *dangling;
     float k, d;
@@ -240,16 +245,25 @@ struct vgl_pr_blk_op {
     int32_t a_base;
     __device__ __forceinline__ uint32_t load(int32_t i) const { return __float_as_uint(contrib[i]); }
     __device__ __forceinline__ uint32_t edge(uint32_t x, float) const { return x; }
-    __device__ __forceinline__ uint32_t identity() const { return 0u; }
-    __device__ __forceinline__ void accumulate(uint32_t *p, uint32_t v) const
+    __device__ __forceinline__ acc_t identity() const { return 0ull; }
+    // f32 (non-negative, < 2) -> fixed point with 62 fraction bits, by the bits: mantissa << (exponent - 150 + 62)
+    static __device__ __forceinline__ acc_t to_fixed(uint32_t bits)
     {
-        __hip_atomic_fetch_add(reinterpret_cast<float *>(p), __uint_as_float(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int ex = (int)(bits >> 23) & 0xFF;
+        const unsigned long long m = (unsigned long long)((bits & 0x7FFFFFu) | (ex ? 0x800000u : 0u));
+        const int sh = (ex ? ex : 1) - 150 + 62;
+        return sh >= 0 ? m << sh : (sh > -24 ? m >> -sh : 0ull);
     }
-    __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return __float_as_uint(__fadd_rn(__uint_as_float(a), __uint_as_float(b))); }
-    __device__ __forceinline__ bool partial(int32_t, uint32_t) const { return false; }
-    __device__ __forceinline__ void finish(int32_t i, uint32_t acc) const
+    __device__ __forceinline__ void accumulate(acc_t *p, uint32_t v) const
     {
-        ranks_out[a_base + i] = __fadd_rn(k, __fmul_rn(d, __fadd_rn(__uint_as_float(acc), *dangling)));
+        __hip_atomic_fetch_add(p, to_fixed(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ acc_t combine(acc_t a, acc_t b) const { return a + b; }
+    __device__ __forceinline__ bool partial(int32_t, acc_t) const { return false; }
+    __device__ __forceinline__ void finish(int32_t i, acc_t acc) const
+    {
+        const float sum = (float)((double)acc * 0x1p-62);           // 53 of the 64 bits, then f32: the double rounding is below 2^-53 relative
+        ranks_out[a_base + i] = __fadd_rn(k, __fmul_rn(d, __fadd_rn(sum, *dangling)));
     }
 };
 
@@ -259,19 +273,49 @@ static int vgl_pr_mode_resolve(const vgl_hip_graph *g, int mode)
         const char *s = getenv("VGL_PR_MODE");
         if (s && *s) mode = atoi(s);
     }
-    if (mode == VGL_HIP_PR_AUTO) mode = g->out.edges >= (1LL << 25) ? VGL_HIP_PR_BLOCKED : VGL_HIP_PR_EXACT_ORDER;
     return mode;
+}
+
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_max_row(int32_t nrows, const int64_t *rowptr, unsigned long long *out)
+{
+    __shared__ unsigned long long s[VGL_WAVES];
+    unsigned long long m = 0;
+    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK) m = max(m, (unsigned long long)(rowptr[r + 1] - rowptr[r]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned long long)__shfl_xor(m, o));
+    if (vgl_lane() == 0) s[vgl_wave()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(s[0], s[1]), max(s[2], s[3])));
+}
+
+// AUTO: blocked for large graphs whose rows are all short (the exact sum then stays well inside 1e-6 of the ordered chain)
+static int vgl_pr_mode_auto(vgl_hip_ctx *c, vgl_hip_graph *g, int *mode)
+{
+    *mode = vgl_pr_mode_resolve(g, *mode);
+    if (*mode != VGL_HIP_PR_AUTO) return 0;
+    *mode = VGL_HIP_PR_EXACT_ORDER;
+    if (g->out.edges < (1LL << 25)) return 0;
+    if (g->out.max_row < 0) {
+        VGL_TRY(vgl_zero_counters(c, C_TMP0, 1));
+        hipLaunchKernelGGL(vgl_k_max_row, dim3(vgl_grid3(g->nrows, 1024)), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->out.rowptr,
+                           (unsigned long long *)(c->d_counters + C_TMP0));
+        VGL_TRY(vgl_read_counters(c, false));
+        g->out.max_row = c->h_counters[C_TMP0];
+    }
+    if (g->out.max_row <= 256) *mode = VGL_HIP_PR_BLOCKED;
+    return 0;
 }
 
 static int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *indeg, const float *rdeg, float *ranks, float *contrib,
                             float *ranks_out, int mode)
 {
-    if (vgl_pr_mode_resolve(g, mode) == VGL_HIP_PR_BLOCKED) {
+    VGL_TRY(vgl_pr_mode_auto(c, g, &mode));
+    if (mode == VGL_HIP_PR_BLOCKED) {
         const int32_t V = g->V;
         const float d = 0.85f;
         const float k = (float)((1.0 - (double)d) / (double)((float)V));
         const int npart = (int)vgl_grid3(V, 1024);
-        if (!g->blk_pr) VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, V, 0, 1, nullptr, &g->blk_pr));
+        if (!g->blk_pr) VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, V, 0, 1, nullptr, VGL_BLK_BITS - 1, &g->blk_pr));
         VGL_TRY(vgl_ensure_partials(c, (size_t)npart + 8));
         float *dangling = reinterpret_cast<float *>(c->d_partials + npart);
         hipLaunchKernelGGL(vgl_k_pr_prepare, dim3(npart), dim3(VGL_BLOCK), 0, c->stream, V, indeg, rdeg, ranks, contrib, c->d_partials);

@@ -161,6 +161,7 @@ static int vgl_sssp_launch(vgl_hip_ctx *c, vgl_hip_graph *g, const float *w, flo
 // ---------------------------------------------------------------------------------------------------------------------------
 template <class Path>
 struct vgl_path_blk_op {
+    typedef uint32_t acc_t;
     float *dist;
     int32_t *epoch;
     int32_t iter, g_base;
@@ -265,7 +266,7 @@ static int vgl_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d
     if (!c || !g || !d_weights || !out) VGL_FAIL("sssp_pull_plan_create: null argument");
     vgl_hip_sssp_pull_plan *p = new vgl_hip_sssp_pull_plan();
     p->g = g; p->weights = d_weights;
-    const int rc = vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, d_weights, &p->blk);
+    const int rc = vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, d_weights, VGL_BLK_BITS, &p->blk);
     if (rc) { delete p; return rc; }
     *out = p;
     return 0;

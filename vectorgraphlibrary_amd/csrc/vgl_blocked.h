@@ -8,7 +8,8 @@
 // LDS serves random 4-byte reads ~20x faster, so the pass is split in two streaming kernels around 128 KiB LDS windows
 // (propagation blocking, adapted to a static graph so that only VALUES travel through memory):
 //
-//   blocks     vertices are cut into blocks of VGL_BLK = 32768 ids (128 KiB of 4-byte values: one LDS window, 1024-thread workgroup)
+//   blocks     vertices are cut into blocks of VGL_BLK = 32768 ids (128 KiB of 4-byte values: one LDS window, 1024-thread workgroup);
+//              operators with 8-byte accumulators (PageRank's exact fixed-point sums) use 16384-id blocks on the accumulate side
 //   segments   the edges with gather-side block gb and accumulate-side block ab form segment (gb, ab); a segment is padded to
 //              whole 64-entry CHUNKS (one wavefront-width; pad entries point at dummy accumulators)
 //   mid order  chunks sorted by (gb, ab): arrays g_lo (uint16 index of x inside block gb), w_mid (optional f32 edge values)
@@ -22,6 +23,11 @@
 // HBM traffic 12 (16 with edge values) B/edge instead of 8 (12) B/edge + one 64-128-byte line per gather.
 //
 // Within a segment the edges keep CSR order (stable sort), so the layout is a pure function of the graph.
+//
+// LDS atomics (profiles/microbench/lds_atomic_bench.hip, one 1024-thread workgroup per CU, random addresses in the window):
+// ds_add_u32 / ds_min_i32 / ds_add_rtn_u32 6.3-6.4 clocks per wavefront instruction (a plain ds_read_b32: 6.0), ds_add_u64 10.8,
+// ds_add_f32 193 -- float atomics are ~30x slower than integer ones, so sums are kept in 64-bit fixed point (which also makes them
+// exact and independent of the order of arrival) and minima / maxima work on the integer order of non-negative floats.
 #pragma once
 #include "vgl_hip_internal.h"
 
@@ -31,7 +37,7 @@ constexpr int VGL_CHUNK = 64;                    // entries per chunk
 constexpr int VGL_BTHREADS = 1024;               // workgroup of the two kernels (16 wavefronts, one workgroup per CU: 128 KiB LDS)
 constexpr int VGL_BWAVES = VGL_BTHREADS / 64;
 constexpr int VGL_BGROUP = 8;                    // chunks per wavefront step (16 bytes of uint16 indices per lane)
-constexpr uint16_t VGL_BLK_PAD = 0x8000;          // a_lo of pad entry i of a chunk = VGL_BLK_PAD + i: 64 dummy accumulators behind the window, no branch per entry
+// a_lo of pad entry i of a chunk = (accumulate block size) + i: 64 dummy accumulators behind the window, no branch per entry
 
 struct vgl_blk_unit {                            // one workgroup's share: chunks [chunk0, chunk1) of block `block`
     int32_t block;
@@ -45,6 +51,7 @@ struct vgl_blk_multi {                           // a block whose accumulation i
 struct vgl_blocked_plan {
     int32_t g_count = 0, a_count = 0;            // index ranges of the gather / accumulate side
     int32_t nG = 0, nA = 0;
+    int a_bits = VGL_BLK_BITS;                   // log2 of the accumulate-side block (15: 4-byte accumulators, 14: 8-byte)
     int64_t edges = 0;                           // edges kept (self loops may be dropped at build time)
     uint32_t nchunks = 0;
     uint16_t *g_lo = nullptr, *a_lo = nullptr;
@@ -55,7 +62,7 @@ struct vgl_blocked_plan {
     int n_g_units = 0, n_a_units = 0;
     vgl_blk_multi *multi = nullptr;
     int n_multi = 0, n_slabs = 0;
-    uint32_t *slabs = nullptr;                   // n_slabs * VGL_BLK
+    void *slabs = nullptr;                       // n_slabs * 128 KiB (one window of accumulators each)
     uint8_t *g_dirty = nullptr;                  // nG: gather blocks whose x changed since the last pass (filtered passes)
 };
 
@@ -64,7 +71,7 @@ struct vgl_blocked_plan {
 // out (PageRank, pr.hpp:111).  d_weights (optional): f32 per CSR position, carried to the mid order.  Synchronises; offline cost
 // (a 3-pass radix sort of the edges), like the reference's graph import.
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
-                           int skip_self, const float *d_weights, vgl_blocked_plan **out);
+                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out);
 void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
 
 #ifdef __HIPCC__
@@ -72,8 +79,9 @@ void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
 // kernels (templates over the edge operator; instantiated by pr.hip / sssp.hip / cc.hip)
 //   OP::load(i)            -> uint32 bits of x[i] (i = index on the gather side, < g_count)
 //   OP::edge(xbits, w)     -> uint32 bits of the value that travels to the accumulate side (w = 0 without edge values)
-//   OP::identity()         -> uint32 bits the accumulators start from
-//   OP::accumulate(p, v)   LDS atomic that folds v into *p
+//   OP::acc_t              accumulator type in LDS: uint32_t (blocks of 32768 on the accumulate side) or uint64_t (16384)
+//   OP::identity()         -> value the accumulators start from
+//   OP::accumulate(p, v)   LDS atomic that folds the travelling uint32 v into *p
 //   OP::finish(i, acc)     epilogue of vertex i of the accumulate side when its block was handled by ONE unit
 //   OP::partial(i, acc)    a block cut into several units: fold this unit's result into memory (min-type operators: a global
 //                          atomic), or return false to have the unit write its accumulators to a slab (sum-type operators);
@@ -119,14 +127,16 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_gather(const vgl_blk_u
 
 template <class OP>
 __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_accumulate(const vgl_blk_unit *units, const uint16_t *a_lo, const uint32_t *vals,
-                                                                     int32_t a_count, uint32_t *slabs, OP op)
+                                                                     int32_t a_count, typename OP::acc_t *slabs, OP op)
 {
-    __shared__ uint32_t s_acc[VGL_BLK + VGL_CHUNK];
+    typedef typename OP::acc_t acc_t;
+    constexpr int ABITS = sizeof(acc_t) == 8 ? VGL_BLK_BITS - 1 : VGL_BLK_BITS, AN = 1 << ABITS;
+    __shared__ acc_t s_acc[AN + VGL_CHUNK];
     const vgl_blk_unit u = units[blockIdx.x];
-    const int32_t base = u.block << VGL_BLK_BITS;
-    const int n = min(VGL_BLK, a_count - base);
-    const uint32_t ident = op.identity();
-    for (int i = threadIdx.x; i < VGL_BLK + VGL_CHUNK; i += VGL_BTHREADS) s_acc[i] = ident;
+    const int32_t base = u.block << ABITS;
+    const int n = min(AN, a_count - base);
+    const acc_t ident = op.identity();
+    for (int i = threadIdx.x; i < AN + VGL_CHUNK; i += VGL_BTHREADS) s_acc[i] = ident;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 3, off = (lane & 7) * 8;
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_accumulate(const vgl_b
     if (u.slab < 0) {
         for (int i = threadIdx.x; i < n; i += VGL_BTHREADS) op.finish(base + i, s_acc[i]);
     } else {
-        uint32_t *slab = slabs + (size_t)u.slab * VGL_BLK;
+        acc_t *slab = slabs + (size_t)u.slab * AN;
         for (int i = threadIdx.x; i < n; i += VGL_BTHREADS)
             if (!op.partial(base + i, s_acc[i])) slab[i] = s_acc[i];
     }
@@ -156,14 +166,16 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_accumulate(const vgl_b
 
 // sum-type operators: add the slabs of a multi-unit block in unit order (OP::combine), then the epilogue
 template <class OP>
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_finish_slabs(const vgl_blk_multi *multi, const uint32_t *slabs, int32_t a_count, OP op)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_finish_slabs(const vgl_blk_multi *multi, const typename OP::acc_t *slabs, int32_t a_count, OP op)
 {
+    typedef typename OP::acc_t acc_t;
+    constexpr int ABITS = sizeof(acc_t) == 8 ? VGL_BLK_BITS - 1 : VGL_BLK_BITS, AN = 1 << ABITS;
     const vgl_blk_multi mb = multi[blockIdx.x];
-    const int32_t base = mb.block << VGL_BLK_BITS;
-    const int n = min(VGL_BLK, a_count - base);
+    const int32_t base = mb.block << ABITS;
+    const int n = min(AN, a_count - base);
     for (int i = blockIdx.y * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.y * VGL_BLOCK) {
-        uint32_t acc = op.identity();
-        for (int s = 0; s < mb.nslabs; s++) acc = op.combine(acc, slabs[(size_t)(mb.first_slab + s) * VGL_BLK + i]);
+        acc_t acc = op.identity();
+        for (int s = 0; s < mb.nslabs; s++) acc = op.combine(acc, slabs[(size_t)(mb.first_slab + s) * AN + i]);
         op.finish(base + i, acc);
     }
 }
@@ -179,14 +191,17 @@ static inline int vgl_blocked_pass(vgl_hip_ctx *c, const vgl_blocked_plan *p, co
                            (const uint16_t *)p->g_lo, (const float *)p->w_mid, (const uint32_t *)p->mid_to_a, p->vals, p->g_count,
                            (const uint8_t *)(filtered ? p->g_dirty : nullptr), op);
     }
+    if (p->a_bits != (sizeof(typename OP::acc_t) == 8 ? VGL_BLK_BITS - 1 : VGL_BLK_BITS)) VGL_FAIL("blocked pass: the plan's accumulate blocks do not fit the operator's accumulators");
     if (p->n_a_units > 0) {
         vgl_timed_launch tl(c, accum_name);
         hipLaunchKernelGGL((vgl_k_blk_accumulate<OP>), dim3((unsigned)p->n_a_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_unit *)p->a_units,
-                           (const uint16_t *)p->a_lo, (const uint32_t *)p->vals, p->a_count, p->slabs, op);
+                           (const uint16_t *)p->a_lo, (const uint32_t *)p->vals, p->a_count, (typename OP::acc_t *)p->slabs, op);
     }
-    if (SLABS && p->n_multi > 0)
-        hipLaunchKernelGGL((vgl_k_blk_finish_slabs<OP>), dim3((unsigned)p->n_multi, 16), dim3(VGL_BLOCK), 0, c->stream, (const vgl_blk_multi *)p->multi,
-                           (const uint32_t *)p->slabs, p->a_count, op);
+    if constexpr (SLABS) {
+        if (p->n_multi > 0)
+            hipLaunchKernelGGL((vgl_k_blk_finish_slabs<OP>), dim3((unsigned)p->n_multi, 16), dim3(VGL_BLOCK), 0, c->stream, (const vgl_blk_multi *)p->multi,
+                               (const typename OP::acc_t *)p->slabs, p->a_count, op);
+    }
     VGL_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -73,6 +73,7 @@ struct vgl_dir_csr {                 // one direction of the graph (borrowed) + 
     double *hub_chunk_sums = nullptr;
     int32_t *pull_blk_row = nullptr; // pull sums: first row of every ordinary workgroup (+ end): <= 256 rows and ~16 K edges each (lazy)
     int pull_nblk = 0;
+    int64_t max_row = -1;            // longest row (lazy; PageRank's choice between the ordered and the blocked pull)
 };
 
 struct vgl_hip_graph {
