@@ -43,6 +43,74 @@ struct ShortestPaths {
         return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
     }
 
+    // All-active pull (call sequence of SSSP::vgl_dijkstra_all_active_pull, shortest_paths.hpp:169-292): every vertex takes the minimum
+    // over its INCOMING edges; the weights are read from the incoming half of the EdgesArray through global_edge_pos.  The reference
+    // keeps a per-thread register array between pre / edge / post operators; a device lambda folds into the vertex's own slot with an
+    // integer atomic-min instead (only lanes of the same row meet there), which needs neither pre nor post operator.
+    template <typename _T>
+    static double vgl_dijkstra_all_active_pull(VGL_Graph &graph, EdgesArray<_T> &weights, VerticesArray<_T> &distances, int source_vertex)
+    {
+        VGL_GRAPH_ABSTRACTIONS graph_API(graph, GATHER);
+        VGL_FRONTIER frontier(graph, GATHER);
+        graph_API.change_traversal_direction(GATHER, distances, frontier);
+        Timer tm;
+        tm.start();
+        const _T inf_val = std::numeric_limits<_T>::max() - MAX_WEIGHT;
+        auto init_distances = [distances, source_vertex, inf_val] __VGL_COMPUTE_ARGS__ {
+            distances[src_id] = (src_id == source_vertex) ? (_T)0 : inf_val;
+        };
+        frontier.set_all_active();
+        graph_API.compute(graph, frontier, init_distances);
+        int *changes;
+        MemoryAPI::allocate_array(&changes, 1);
+        do {
+            changes[0] = 0;
+            auto edge_op_pull = [distances, weights, changes, inf_val] __VGL_GATHER_ARGS__ {
+                const _T dst_weight = distances[dst_id];
+                if (dst_weight < inf_val) {
+                    const _T candidate = __fadd_rn(dst_weight, weights[global_edge_pos]);
+                    if (distances[src_id] > candidate) {
+                        atomicMin(reinterpret_cast<int *>(&distances[src_id]), __float_as_int(candidate));
+                        changes[0] = 1;
+                    }
+                }
+            };
+            graph_API.gather(graph, frontier, edge_op_pull);
+        } while (changes[0]);
+        MemoryAPI::free_array(changes);
+        tm.end();
+        graph_API.change_traversal_direction(SCATTER, distances, frontier);
+        performance_stats.print_algorithm_performance_stats("SSSP (Bellman-Ford, all-active, pull, operator API)", tm.get_time(), graph.get_edges_count());
+        return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
+    }
+
+    // fused pull / direction-optimising schedule of libvgl_hip.so (blocked pull steps, vgl_hip_sssp_run_pull): the blocked copy of
+    // (adjacency, weights) is built once per EdgesArray, its build time is printed, not charged to the traversals
+    static double hip_fused_pull(VGL_Graph &graph, EdgesArray<float> &weights, VerticesArray<float> &distances, int source_vertex, bool direction_optimising)
+    {
+        static vgl_hip_sssp_pull_plan *plan = nullptr;
+        static const void *plan_graph = nullptr, *plan_weights = nullptr;
+        vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+        if (!plan || plan_graph != (const void *)graph.get_handle() || plan_weights != (const void *)weights.get_ptr()) {
+            if (plan) vgl_hip_sssp_pull_plan_destroy(c, plan);
+            plan = nullptr;
+            Timer tp;
+            tp.start();
+            VGL_HIP_CALL(vgl_hip_sssp_pull_plan_create(c, graph.get_handle(), weights.get_ptr(), &plan));
+            tp.end();
+            tp.print_time_stats("SSSP pull plan (blocked adjacency + weights, once per weights)");
+            plan_graph = graph.get_handle(); plan_weights = weights.get_ptr();
+        }
+        Timer tm;
+        tm.start();
+        vgl_hip_sssp_stats st;
+        VGL_HIP_CALL(vgl_hip_sssp_run_pull(c, graph.get_handle(), weights.get_ptr(), plan, source_vertex,
+                                           direction_optimising ? VGL_HIP_SSSP_DIRECTION_OPT : VGL_HIP_SSSP_PULL, distances.get_ptr(), &st));
+        tm.end();
+        performance_stats.print_algorithm_performance_stats(direction_optimising ? "SSSP (fused, push <-> pull)" : "SSSP (fused, pull)", tm.get_time(), graph.get_edges_count());
+        return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
+    }
+
     // fused fast path of libvgl_hip.so: delta-stepping over a light / heavy split of the adjacency (same distances bit for bit).  The
     // split ("plan") depends on the weights only, so it is built once per EdgesArray and reused by every source; its build time is
     // printed, not charged to the traversals.

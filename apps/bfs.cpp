@@ -14,7 +14,7 @@ int main(int argc, char **argv)
         double avg_perf = 0;
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {
             // -source and select_random_nz_vertex speak ORIGINAL ids; algorithms and checkers work in the stored numbering
-            const int source_vertex = graph.reorder(parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
+            const int source_vertex = graph.reorder(parser.source >= 0 ? checked_vertex(graph, parser.source, "source") : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
             const double perf = parser.fused ? BFS::hip_fused(graph, levels, source_vertex, parser.direction_optimising)
                                              : BFS::vgl_top_down(graph, levels, source_vertex);
             avg_perf += perf / parser.get_number_of_rounds();

@@ -14,6 +14,8 @@
 struct Parser {
     int scale = 10, avg_degree = 5, rounds = 1, source = -1, sink = -1, walk_vertices_percent = 1;
     bool rmat = true, check = false, direction_optimising = false, fused = false, undirected = false, bfs_based = false;
+    enum Traversal { PUSH_TRAVERSAL, PULL_TRAVERSAL } traversal = PUSH_TRAVERSAL;                   // cmd_parser.hpp (-push / -pull)
+    enum FrontierKind { ALL_ACTIVE_KIND, PARTIAL_ACTIVE_KIND } frontier_kind = ALL_ACTIVE_KIND;     // (-all-active / -partial-active)
     GraphStorageFormat format = CSR_GRAPH;      // -format csr | vcsr (VECTOR_CSR_GRAPH: degree-renumbered, the reference's default)
     unsigned long long seed = 1;
     std::string dump, graph_file_name;
@@ -47,7 +49,11 @@ struct Parser {
             else if (a == "-bfs-based") bfs_based = true;            // tc: one BFS per source instead of Purdom's; cc: accepted
             else if (a == "-directed") undirected = false;
             // algorithm selectors of the reference's harness (apps/scripts/settings.py:15-25) that name what this backend does anyway
-            else if (a == "-push" || a == "-pull" || a == "-all-active" || a == "-partial-active" || a == "-top-down" || a == "-cv" || a == "-purdoms") {}
+            else if (a == "-push") traversal = PUSH_TRAVERSAL;              // honoured by sssp (the other apps have one traversal, as in the reference)
+            else if (a == "-pull") traversal = PULL_TRAVERSAL;
+            else if (a == "-all-active") frontier_kind = ALL_ACTIVE_KIND;
+            else if (a == "-partial-active") frontier_kind = PARTIAL_ACTIVE_KIND;
+            else if (a == "-top-down" || a == "-cv" || a == "-purdoms") {}  // name what the app does anyway
             else throw "unknown command line option";
         }
     }
@@ -73,6 +79,13 @@ inline void prepare_graph(VGL_Graph &graph, const Parser &p, DirectionType dir =
     if (p.rmat) GraphGenerationAPI::R_MAT(ec, v, e, 57, 19, 19, 5, dir);      // vgl_runtime.hpp:36
     else GraphGenerationAPI::random_uniform(ec, v, e, dir);
     graph.import(ec);
+}
+
+// -source / -sink are ORIGINAL vertex ids: refuse ids outside the graph before they index anything (host conversion tables, checkers)
+inline int checked_vertex(const VGL_Graph &graph, int v, const char *what)
+{
+    if (v < 0 || v >= graph.get_vertices_count()) throw (std::string("Error: ") + what + " vertex id is outside [0, vertices count)");
+    return v;
 }
 
 struct HostCSR {

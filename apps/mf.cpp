@@ -17,8 +17,8 @@ int main(int argc, char **argv)
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {
             flows.set_all_constant(MAX_WEIGHT);                  // clear flows before each round (mf.cpp:36)
             int max_flow_val = 0;
-            const int source_original = parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(ORIGINAL, 2 * i);
-            const int sink_original = parser.sink >= 0 ? parser.sink : graph.select_random_nz_vertex(ORIGINAL, 2 * i + 1);
+            const int source_original = parser.source >= 0 ? checked_vertex(graph, parser.source, "source") : graph.select_random_nz_vertex(ORIGINAL, 2 * i);
+            const int sink_original = parser.sink >= 0 ? checked_vertex(graph, parser.sink, "sink") : graph.select_random_nz_vertex(ORIGINAL, 2 * i + 1);
             const int source = graph.reorder(source_original, ORIGINAL, SCATTER), sink = graph.reorder(sink_original, ORIGINAL, SCATTER);
             avg_perf += MF::vgl_ford_fulkerson(graph, flows, source, sink, max_flow_val) / parser.get_number_of_rounds();
             std::cout << "Result: " << max_flow_val << " (source " << source_original << ", sink " << sink_original << ")" << std::endl;

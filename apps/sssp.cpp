@@ -15,9 +15,14 @@ int main(int argc, char **argv)
         weights.set_all_random(MAX_WEIGHT);
         double avg_perf = 0;
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {
-            const int source_vertex = graph.reorder(parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
-            const double perf = parser.fused ? ShortestPaths::hip_fused(graph, weights, distances, source_vertex)
-                                             : ShortestPaths::vgl_dijkstra_all_active_push(graph, weights, distances, source_vertex);
+            const int source_vertex = graph.reorder(parser.source >= 0 ? checked_vertex(graph, parser.source, "source") : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
+            // SSSP::vgl_dijkstra's dispatch (shortest_paths.hpp:296-318): -push / -pull select the traversal; -fused takes the library's
+            // schedules (delta-stepping; with -pull the blocked pull steps, with -do push <-> pull switching)
+            const bool pull = parser.traversal == Parser::PULL_TRAVERSAL;
+            const double perf = parser.fused ? ((pull || parser.direction_optimising) ? ShortestPaths::hip_fused_pull(graph, weights, distances, source_vertex, parser.direction_optimising)
+                                                                                      : ShortestPaths::hip_fused(graph, weights, distances, source_vertex))
+                                             : pull ? ShortestPaths::vgl_dijkstra_all_active_pull(graph, weights, distances, source_vertex)
+                                                    : ShortestPaths::vgl_dijkstra_all_active_push(graph, weights, distances, source_vertex);
             avg_perf += perf / parser.get_number_of_rounds();
             if (parser.get_check_flag()) {
                 HostCSR h(graph);

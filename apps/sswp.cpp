@@ -16,7 +16,7 @@ int main(int argc, char **argv)
         capacities.set_all_random(MAX_WEIGHT);
         double avg_perf = 0;
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {
-            const int source_vertex = graph.reorder(parser.source >= 0 ? parser.source : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
+            const int source_vertex = graph.reorder(parser.source >= 0 ? checked_vertex(graph, parser.source, "source") : graph.select_random_nz_vertex(ORIGINAL, i), ORIGINAL, SCATTER);
             const double perf = parser.fused ? WidestPaths::hip_fused(graph, capacities, widths, source_vertex)
                                              : WidestPaths::vgl_dijkstra(graph, capacities, widths, source_vertex);
             avg_perf += perf / parser.get_number_of_rounds();

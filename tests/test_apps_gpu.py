@@ -45,7 +45,8 @@ def test_bfs_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
 
 
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)
-@pytest.mark.parametrize("mode", [[], ["-fused"]])
+@pytest.mark.parametrize("mode", [[], ["-fused"], ["-pull"], ["-push", "-all-active"], ["-fused", "-pull"], ["-fused", "-do"], ["-pull", "-format", "vcsr"]],
+                         ids=["push", "fused", "pull", "push_all_active", "fused_pull", "fused_do", "pull_vcsr"])
 def test_sssp_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
     O = oracle
     src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
@@ -317,3 +318,45 @@ def test_api_performance_stats(tmp_path, ctx):
     assert bw * 1e9 / (rate * 1e6) >= 16.0
     fused, _ = run_app("bfs", ["-s", 12, "-e", 16, "-type", "rmat", "-seed", 3, "-source", 1, "-fused", "-do"], tmp_path)
     assert "total bandwidth:" not in fused                     # the fused path does not go through the operator primitives
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,ef", [("rmat", 12, 16), ("ru", 11, 24)])
+def test_advance_six_functor_contract(kind, scale, ef, fmt, ctx):
+    """the collective functor set of scatter / gather (common/advance.hpp:6-115): never called on CSR_GRAPH, called for rows shorter
+    than VECTOR_CORE_THRESHOLD_VALUE on VECTOR_CSR_GRAPH (advance_worker.hpp:204-319), for all-active / sparse / dense frontiers in
+    both directions, with the local / global edge position contract and the direction check; the app counts every call."""
+    out = subprocess.run([os.path.join(BIN, "advance_contract_hip"), "-s", str(scale), "-e", str(ef), "-type", kind, "-format", fmt],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "error count: 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_corrupt_el_container_and_bad_source_are_refused(tmp_path, oracle, ctx):
+    """-import trusts nothing in the file: counts the file cannot hold, negative counts and ids outside [0, V) are refused on
+    the host; so are -source / -sink ids outside the graph."""
+    O = oracle
+    rng = np.random.default_rng(3)
+    V, E = 500, 4000
+    src, dst = rng.integers(0, V, E).astype(np.int32), rng.integers(0, V, E).astype(np.int32)
+    good = str(tmp_path / "good.el_container")
+    O.write_el_container(good, V, src, dst)
+    raw = bytearray(open(good, "rb").read())
+
+    def run(data, extra=()):
+        path = str(tmp_path / "bad.el_container")
+        open(path, "wb").write(bytes(data))
+        return subprocess.run([os.path.join(BIN, "bfs_hip"), "-import", path, *extra], capture_output=True, text=True, timeout=120)
+
+    bad = bytearray(raw); bad[4:12] = np.int64(1 << 40).tobytes()          # edge count far beyond the file
+    out = run(bad); assert out.returncode == 1 and "corrupt header" in out.stdout
+    bad = bytearray(raw); bad[4:12] = np.int64(-5).tobytes()
+    out = run(bad); assert out.returncode == 1 and "corrupt header" in out.stdout
+    bad = bytearray(raw); bad[0:4] = np.int32(0).tobytes()
+    out = run(bad); assert out.returncode == 1 and "corrupt header" in out.stdout
+    bad = bytearray(raw); bad[16 + 4 * 7:16 + 4 * 8] = np.int32(V).tobytes()          # a source id == V
+    out = run(bad); assert out.returncode == 1 and "id out of range" in out.stdout
+    bad = bytearray(raw); bad[16 + 4 * E + 4 * 9:16 + 4 * E + 4 * 10] = np.int32(-1).tobytes()   # a negative destination id
+    out = run(bad); assert out.returncode == 1 and "id out of range" in out.stdout
+    for fmt in ("csr", "vcsr"):
+        out = run(raw, ("-source", str(V), "-format", fmt)); assert out.returncode == 1 and "outside" in out.stdout
+    out = run(raw, ("-source", "3")); assert out.returncode == 0

@@ -257,8 +257,11 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     }
     // work units.  Gather units: >= 4 per CU when the graph allows (each reloads its 128 KiB window, so not below ~256 K edges);
     // accumulate units larger (a block cut in several units costs a slab or a round of global atomics per unit)
+    // (accumulate blocks up to 1.5x the average stay whole -- on a uniform graph every block is one unit and nothing goes through slabs --
+    // but never beyond 16 K chunks = 1 M entries, ~0.25 ms of one CU's share of the HBM stream)
+    const uint32_t avg_a = (uint32_t)(p->nchunks / nA);
     const uint32_t g_cap = (uint32_t)std::max(64, env_int("VGL_BLK_GATHER_UNIT", 4096));
-    const uint32_t a_cap = (uint32_t)std::max(64, env_int("VGL_BLK_ACCUM_UNIT", 8192));
+    const uint32_t a_cap = (uint32_t)std::max(64, env_int("VGL_BLK_ACCUM_UNIT", (int)std::min<uint32_t>(16384, std::max<uint32_t>(4096, avg_a + avg_a / 2))));
     std::vector<vgl_blk_unit> gu, au;
     std::vector<vgl_blk_multi> multi, none;
     int dummy = 0;

@@ -91,6 +91,14 @@ enum TraversalDirection { SCATTER = 0, GATHER = 1, ORIGINAL = 2 };
 enum REDUCE_TYPE { REDUCE_SUM = 0, REDUCE_MAX = 1, REDUCE_MIN = 1, REDUCE_AVG = 3 };
 enum FrontierSparsityType { ALL_ACTIVE_FRONTIER = 2, SPARSE_FRONTIER = 1, DENSE_FRONTIER = 0 };
 enum DirectionType { UNDIRECTED_GRAPH = 0, DIRECTED_GRAPH = 1 };
+// degree classes of the VectCSR advance (settings.h:57-58,99-109; apps override VECTOR_CORE_THRESHOLD_VALUE before the include): rows with
+// fewer entries than the threshold form the reference's "collective" range and get the collective functor set
+#ifndef VECTOR_LENGTH
+#define VECTOR_LENGTH 32
+#endif
+#ifndef VECTOR_CORE_THRESHOLD_VALUE
+#define VECTOR_CORE_THRESHOLD_VALUE VECTOR_LENGTH
+#endif
 #define IN_FRONTIER_FLAG 1
 #define NOT_IN_FRONTIER_FLAG 0
 #define MAX_WEIGHT 100
@@ -218,10 +226,18 @@ public:
         int v = 0, type = 0; long long e = 0;
         if (fread(&v, sizeof(int), 1, f) != 1 || fread(&e, sizeof(long long), 1, f) != 1 || fread(&type, sizeof(int), 1, f) != 1) { fclose(f); return false; }
         if (type != 4) { fclose(f); throw "Error in EdgesContainer::load_from_binary_file : incorrect type of graph in file"; }
+        // the kernels trust the ids: refuse counts the file cannot hold and ids outside [0, V) before anything reaches the device
+        const long header = ftell(f);
+        fseek(f, 0, SEEK_END);
+        const long long payload = (long long)ftell(f) - header;
+        fseek(f, header, SEEK_SET);
+        if (v <= 0 || e < 0 || e > payload / (2 * (long long)sizeof(int))) { fclose(f); throw "Error in EdgesContainer::load_from_binary_file : corrupt header (vertex / edge counts)"; }
         std::vector<int> s((size_t)e), d((size_t)e);
         const bool ok = fread(s.data(), sizeof(int), (size_t)e, f) == (size_t)e && fread(d.data(), sizeof(int), (size_t)e, f) == (size_t)e;
         fclose(f);
         if (!ok) return false;
+        for (size_t i = 0; i < (size_t)e; i++)
+            if (s[i] < 0 || s[i] >= v || d[i] < 0 || d[i] >= v) throw "Error in EdgesContainer::load_from_binary_file : id out of range";
         load_from_host(v, s, d);
         return true;
     }
@@ -544,6 +560,7 @@ public:
             VGL_HIP_CALL(vgl_hip_memcpy_d2h(c, h_bwd.data(), d_bwd, sizeof(int) * (size_t)V));
         }
         VGL_HIP_CALL(vgl_hip_coo_to_csr(c, V, E, src_ids, dst_ids, 0, V, out_rowptr, out_adj, out_perm, &kept));
+        if (kept != E) throw "Error in VGL_Graph::import : edge list holds source ids outside [0, vertices count)";
         // the incoming container is built from the OUT-CSR-ordered list transposed (vgl_graph.hpp:61-64): src := adjacency, dst := row
         int32_t *csr_src = nullptr;
         MemoryAPI::allocate_device_array(&csr_src, (size_t)E);
@@ -572,6 +589,7 @@ public:
     // VGL_Graph::reorder(v, from, to) (vgl_graph get_api): SCATTER and GATHER share one numbering here
     int reorder(int v, TraversalDirection from, TraversalDirection to) const
     {
+        if (v < 0 || v >= vertices_count) throw "Error in VGL_Graph::reorder : vertex id out of range";
         if (!is_renumbered() || (from == ORIGINAL) == (to == ORIGINAL)) return v;
         return from == ORIGINAL ? h_fwd[(size_t)v] : h_bwd[(size_t)v];
     }
@@ -828,6 +846,28 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_filter_flags(int n, const lon
         flags[i] = cond(i, (int)(rowptr[i + 1] - rowptr[i])) > 0 ? 1 : 0;
 }
 
+// VECTOR_CSR_GRAPH: the reference's advance (multicore/advance_worker.hpp:204-319) hands rows of at least VECTOR_CORE_THRESHOLD_VALUE
+// entries to (edge_op, pre, post) and the shorter rows -- its collective range -- to the collective functor set.  The row's own
+// degree in the traversed direction decides here (one numbering serves both directions, so the classes are not id ranges).
+template <class A, class B>
+struct vgl_split_edge_op {
+    A big; B small; const long long *rowptr; int threshold;
+    __device__ __forceinline__ void operator()(int src, int dst, int local, long long global, int lane) const
+    {
+        if ((int)(rowptr[src + 1] - rowptr[src]) >= threshold) big(src, dst, local, global, lane);
+        else small(src, dst, local, global, lane);
+    }
+};
+template <class A, class B>
+struct vgl_split_vertex_op {
+    A big; B small; int threshold;
+    __device__ __forceinline__ void operator()(int src, int connections, int lane) const
+    {
+        if (connections >= threshold) big(src, connections, lane);
+        else small(src, connections, lane);
+    }
+};
+
 struct vgl_empty_vertex_op { __device__ void operator()(int, int, int) const {} };
 struct vgl_empty_edge_op { __device__ void operator()(int, int, int, long long, int) const {} };
 static const vgl_empty_vertex_op EMPTY_VERTEX_OP;
@@ -899,7 +939,34 @@ class GraphAbstractionsHIP {
         performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, dir == GATHER);
     }
 
+    // the six-functor form (common/advance.hpp:6-115).  CSR_GRAPH: the reference's CSR worker never calls the collective set
+    // (advance_worker.hpp:62-149) -- neither does this one.  VECTOR_CSR_GRAPH: rows shorter than VECTOR_CORE_THRESHOLD_VALUE get the
+    // collective set, with two documented differences from advance_{all_active,dense}.hpp: global_edge_pos is the CSR position
+    // (process_shift + position, as in the reference's own sparse collective kernel, advance_sparse.hpp:149) because no padded
+    // vector-extension copy of the edge arrays exists here, and pre / post run for active rows only.
+    template <class EdgeOp, class PreOp, class PostOp, class CEdgeOp, class CPreOp, class CPostOp>
+    void advance_six(VGL_Graph &g, VGL_Frontier &f, TraversalDirection dir, EdgeOp &&edge_op, PreOp &&pre, PostOp &&post, CEdgeOp &&c_edge_op,
+                     CPreOp &&c_pre, CPostOp &&c_post)
+    {
+        using E = typename std::decay<EdgeOp>::type; using CE = typename std::decay<CEdgeOp>::type;
+        using P = typename std::decay<PreOp>::type; using CP = typename std::decay<CPreOp>::type;
+        using Q = typename std::decay<PostOp>::type; using CQ = typename std::decay<CPostOp>::type;
+        constexpr bool same_set = std::is_same<E, CE>::value && std::is_same<P, CP>::value && std::is_same<Q, CQ>::value;
+        if (g.get_format() != VECTOR_CSR_GRAPH || same_set) { advance_worker(g, f, dir, edge_op, pre, post); return; }
+        const int thr = VECTOR_CORE_THRESHOLD_VALUE;
+        const vgl_csr_view v = g.get_direction_view(dir);
+        const vgl_split_edge_op<E, CE> e2{edge_op, c_edge_op, v.rowptr, thr};
+        if (is_empty_vertex_op<PreOp>() && is_empty_vertex_op<CPreOp>() && is_empty_vertex_op<PostOp>() && is_empty_vertex_op<CPostOp>())
+            advance_worker(g, f, dir, e2, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP);
+        else
+            advance_worker(g, f, dir, e2, vgl_split_vertex_op<P, CP>{pre, c_pre, thr}, vgl_split_vertex_op<Q, CQ>{post, c_post, thr});
+    }
+    std::vector<void *> user_data_containers;
+
 public:
+    // GraphAbstractions::attach_data (graph_abstractions.hpp:130-133): registers a user array with the abstraction object
+    template <typename _T> void attach_data(VerticesArray<_T> &array) { user_data_containers.push_back((void *)&array); }
+
     GraphAbstractionsHIP(VGL_Graph &g, TraversalDirection initial = SCATTER) : processed_graph_ptr(&g), current_traversal_direction(initial)
     { MemoryAPI::allocate_device_array(&reduce_buffer, (size_t)g.get_vertices_count()); MemoryAPI::allocate_device_array(&reduce_partials, 256); }
     ~GraphAbstractionsHIP() { MemoryAPI::free_device_array(reduce_buffer); MemoryAPI::free_device_array(reduce_partials); }
@@ -912,10 +979,10 @@ public:
     template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation,
               typename CollectiveEdgeOperation, typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
     void scatter(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op, VertexPreprocessOperation &&pre, VertexPostprocessOperation &&post,
-                 CollectiveEdgeOperation &&, CollectiveVertexPreprocessOperation &&, CollectiveVertexPostprocessOperation &&)
+                 CollectiveEdgeOperation &&c_edge_op, CollectiveVertexPreprocessOperation &&c_pre, CollectiveVertexPostprocessOperation &&c_post)
     {
         if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";   // common/advance.hpp:19-26
-        advance_worker(g, f, SCATTER, edge_op, pre, post);
+        advance_six(g, f, SCATTER, edge_op, pre, post, c_edge_op, c_pre, c_post);
     }
     template <typename EdgeOperation>
     void scatter(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op)
@@ -926,10 +993,10 @@ public:
     template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation,
               typename CollectiveEdgeOperation, typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
     void gather(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op, VertexPreprocessOperation &&pre, VertexPostprocessOperation &&post,
-                CollectiveEdgeOperation &&, CollectiveVertexPreprocessOperation &&, CollectiveVertexPostprocessOperation &&)
+                CollectiveEdgeOperation &&c_edge_op, CollectiveVertexPreprocessOperation &&c_pre, CollectiveVertexPostprocessOperation &&c_post)
     {
         if (current_traversal_direction != GATHER) throw "VGL ERROR: incorrect traversal direction in gather";
-        advance_worker(g, f, GATHER, edge_op, pre, post);
+        advance_six(g, f, GATHER, edge_op, pre, post, c_edge_op, c_pre, c_post);
     }
     template <typename EdgeOperation>
     void gather(VGL_Graph &g, VGL_Frontier &f, EdgeOperation &&edge_op)
@@ -989,7 +1056,10 @@ public:
         hipLaunchKernelGGL((vgl_k_filter_flags<C>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), V, v.rowptr, filter_cond, f.get_flags());
         VGL_HIP_RT(hipGetLastError());
         f.set_direction(current_traversal_direction);
-        VGL_HIP_CALL(vgl_hip_gnf_from_flags(VGL_RUNTIME::ctx(), g.get_handle(), f.get_flags(), 0.0, f.get_handle()));
+        // CSR_GRAPH frontiers are ALL_ACTIVE or SPARSE (generate_new_frontier.hpp:113-164); VECTOR_CSR_GRAPH ones turn DENSE (flags only)
+        // above FRONTIER_TYPE_CHANGE_THRESHOLD = 0.7 of the vertices (generate_new_frontier.hpp:67-91, settings.h)
+        const double dense_threshold = g.get_format() == VECTOR_CSR_GRAPH ? 0.7 : 0.0;
+        VGL_HIP_CALL(vgl_hip_gnf_from_flags(VGL_RUNTIME::ctx(), g.get_handle(), f.get_flags(), dense_threshold, f.get_handle()));
         performance_stats.update_gnf_stats(watch.seconds(), (size_t)V);
     }
 
