@@ -6,7 +6,7 @@
  * (architecture_independent_api.h:33-43; member list vgl_compute_api/template/
  * graph_abstractions_template.h:44-104; recipe manuals/add_new_architecture.txt:1-7).
  * This C ABI is the layer that class binds to (see INTEGRATION.md and
- * vectorgraphlibrary_amd/hip/graph_abstractions_hip.h): plain pointers and sizes, opaque
+ * vectorgraphlibrary_amd/hip/vgl_hip.hpp): plain pointers and sizes, opaque
  * handles, `int` status (0 = ok) + vgl_hip_last_error().  All device pointers are raw HIP
  * device pointers owned by the caller unless stated; every call is ordered on the context's
  * stream and returns after the work is ENQUEUED unless it has a host-visible result, in which

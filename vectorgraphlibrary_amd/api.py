@@ -5,7 +5,7 @@ fused BFS / SSSP / PageRank / CC entry points, with torch tensors used only as d
 Names follow the reference: VGL_Graph -> Graph (outgoing + incoming CSR, vgl_graph.h:7-79),
 VGL_Frontier -> Frontier (base_frontier.h:5-62), algorithms/{bfs,sssp,pr,cc} -> bfs(), sssp(), page_rank(),
 connected_components().  The C++ drop-in class for arbitrary user lambdas is
-vectorgraphlibrary_amd/hip/graph_abstractions_hip.h.
+vectorgraphlibrary_amd/hip/vgl_hip.hpp.
 """
 import ctypes as C
 

@@ -84,6 +84,7 @@ __device__ __forceinline__ void vgl_src_id_add(T &slot, U value)
 }
 #define VGL_SRC_ID_ADD(a, b) (vgl_src_id_add((a), (b)))
 #define VGL_INC(a) (atomicAdd(&(a), 1))
+#define VGL_DEC(a) (atomicSub(&(a), 1))     // architecture_independent_api.h:60
 #define VGL_LAMBDA_CAP(a) a
 
 // framework_types.h:120-160, settings.h:93
@@ -126,6 +127,16 @@ struct MemoryAPI {
     template <class T> static void allocate_device_array(T **p, size_t n) { VGL_HIP_CALL(vgl_hip_malloc(VGL_RUNTIME::ctx(), sizeof(T) * n, (void **)p)); }
     template <class T> static void free_device_array(T *p) { if (p) vgl_hip_free(VGL_RUNTIME::ctx(), p); }
 };
+
+// per-lane scratch "registers" of the reference's algorithm sources (vgl_compute_api/gpu/vector_register/vector_registers.h:3-70):
+// VECTOR_LENGTH words in memory both sides can touch, plus the host folds over them
+#define VEC_REGISTER_INT(name, value) int *reg_##name; MemoryAPI::allocate_array(&reg_##name, VECTOR_LENGTH); for (int i = 0; i < VECTOR_LENGTH; i++) reg_##name[i] = value;
+#define VEC_REGISTER_FLT(name, value) float *reg_##name; MemoryAPI::allocate_array(&reg_##name, VECTOR_LENGTH); for (int i = 0; i < VECTOR_LENGTH; i++) reg_##name[i] = value;
+#define VEC_REGISTER_DBL(name, value) double *reg_##name; MemoryAPI::allocate_array(&reg_##name, VECTOR_LENGTH); for (int i = 0; i < VECTOR_LENGTH; i++) reg_##name[i] = value;
+template <typename _T> _T register_sum_reduce(_T *reg) { _T s = 0; for (int i = 0; i < VECTOR_LENGTH; i++) s += reg[i]; return s; }
+template <typename _T> _T register_max_reduce(_T *reg) { _T m = std::numeric_limits<_T>::min(); for (int i = 0; i < VECTOR_LENGTH; i++) if (reg[i] > m) m = reg[i]; return m; }
+template <typename _T> _T register_min_reduce(_T *reg) { _T m = std::numeric_limits<_T>::max(); for (int i = 0; i < VECTOR_LENGTH; i++) if (reg[i] < m) m = reg[i]; return m; }
+template <typename _T> void register_free(_T *reg) { MemoryAPI::free_array(reg); }
 
 class Timer {                                 // timer.hpp:20-56 (wall time around synchronised primitives)
     std::chrono::steady_clock::time_point t0, t1;
@@ -443,6 +454,7 @@ private:
             MemoryAPI::free_device_array((char *)p);
         handle = nullptr; out_rowptr = in_rowptr = out_perm = in_perm = nullptr; out_adj = in_adj = nullptr; d_fwd = d_bwd = nullptr;
         h_fwd.clear(); h_bwd.clear();
+        mirrored = false; host_in_rowptr.clear(); host_out_adj.clear(); host_in_adj.clear();
     }
     template <class T> static T *upload(const std::vector<T> &h)
     {
@@ -594,6 +606,24 @@ public:
         return from == ORIGINAL ? h_fwd[(size_t)v] : h_bwd[(size_t)v];
     }
     int get_outgoing_connections_count(int v) const { return (int)(host_out_rowptr[v + 1] - host_out_rowptr[v]); }   // v in stored numbering
+    // host-side edge accessors of the reference (vgl_graph/get_api.hpp:14-50; its sequential checkers walk the graph through them):
+    // the CSR arrays are mirrored on the host the first time one of them is called
+    int get_incoming_connections_count(int v) { mirror(); return (int)(host_in_rowptr[(size_t)v + 1] - host_in_rowptr[(size_t)v]); }
+    int get_outgoing_edge_dst(int v, int local_edge_pos) { mirror(); return host_out_adj[(size_t)(host_out_rowptr[(size_t)v] + local_edge_pos)]; }
+    int get_incoming_edge_dst(int v, int local_edge_pos) { mirror(); return host_in_adj[(size_t)(host_in_rowptr[(size_t)v] + local_edge_pos)]; }
+    // position of an edge in an EdgesArray ([outgoing E ; incoming E], csr_edges_array.hpp:67-73; vgl_graph/get_api.hpp:53-63)
+    size_t get_outgoing_edges_array_index(int v, int edge_pos) const { return (size_t)(host_out_rowptr[(size_t)v] + edge_pos); }
+    size_t get_incoming_edges_array_index(int v, int edge_pos) { mirror(); return (size_t)(edges_count + host_in_rowptr[(size_t)v] + edge_pos); }
+private:
+    std::vector<long long> host_in_rowptr; std::vector<int> host_out_adj, host_in_adj; bool mirrored = false;
+    void mirror()
+    {
+        if (mirrored) return;
+        host_in_rowptr = download<long long>(in_rowptr, (size_t)vertices_count + 1);
+        host_out_adj = download<int>(out_adj, (size_t)edges_count); host_in_adj = download<int>(in_adj, (size_t)edges_count);
+        mirrored = true;
+    }
+public:
     // deterministic stand-in for select_random_nz_vertex (vgl_graph get_api): k-th draw of a fixed stream; the result is an ORIGINAL
     // vertex id with outgoing edges (the same vertex whatever the storage format)
     int select_random_nz_vertex(TraversalDirection = ORIGINAL, unsigned long long draw = 0) const
