@@ -315,6 +315,16 @@ int vgl_hip_cc_jump(vgl_hip_ctx *ctx, int32_t V, int32_t *d_comp);
 int vgl_hip_pr_setup(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_indeg_noloops, float *d_ranks, float *d_rdeg);
 int vgl_hip_pr_iteration_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_indeg_noloops, const float *d_rdeg,
                                float *d_ranks, float *d_contrib_scratch);
+/* "Recently changed" exchange of a replicated 4-byte vertex array (EXCHANGE_RECENTLY_CHANGED, common/mpi_exchange.hpp:110-150): instead
+ * of all-reducing V entries per super-step every rank sends the (index, value) pairs of the entries its step changed.
+ * diff_to_pairs: d_out[0] = number of i < n with d_before[i] != d_after[i] (may exceed cap), then (index, value bits) pairs of the first
+ * min(count, cap) of them, unordered; d_out holds 1 + 2 * cap int32.  Asynchronous.
+ * apply_pairs: `parts` such lists, `stride` int32 apart; every pair is merged into d_values with min (take_min != 0: SSSP distances, CC
+ * labels) or max (SSWP widths) on the 4-byte patterns (all values are non-negative); list `skip_part` (this rank's own, or -1) is
+ * skipped.  changed (optional, synchronises): 1 if an entry of d_values moved. */
+int vgl_hip_diff_to_pairs_u32(vgl_hip_ctx *ctx, int32_t n, const void *d_before, const void *d_after, int32_t cap, int32_t *d_out);
+int vgl_hip_apply_pairs_u32(vgl_hip_ctx *ctx, int parts, int64_t stride, int skip_part, const int32_t *d_lists, int take_min, int32_t n,
+                            void *d_values, int *changed);
 /* in-degree without self loops from an out-CSR shard (adds into d_indeg; zero it first; allreduce(sum) across shards) */
 int vgl_hip_indegree_noloops_add(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_indeg);
 

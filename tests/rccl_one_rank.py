@@ -1,6 +1,6 @@
 """Helper of tests/test_distributed_gpu.py (not a test module): ONE rank under torch.distributed.run with the nccl (= RCCL) backend
 and VGL_SHARD_FORCE_COLLECTIVES=1, so that every collective call of the N > 1 super-step drivers (all_gather_into_tensor on bitmap
-words and slices, all_to_all_single, all_reduce MIN / MAX / SUM on i32 / f32 / i64) runs through RCCL on the one-GPU box, and the
+words, slices, (index, value) pair lists and rank slices, all_to_all_single, all_reduce MIN / MAX / SUM on i32 / f32 / i64) runs through RCCL on the one-GPU box, and the
 results are compared with the single-GPU fused paths.  Prints 'RCCL_ONE_RANK_OK' on success."""
 import os
 import sys
@@ -36,15 +36,18 @@ def main():
         assert torch.equal(levels, ref), kw
     w = ctx.gen_weights(E, seed)[:shard.out_adj.numel()].contiguous()
     wops = vd.HipShardOps(shard, weights=w)
-    d, _ = vd.sssp_sharded(wops, source)
     d_ref, _ = api.sssp(shard, w, source, api.SSSP_ACTIVE_TILES, raw=True)
-    assert torch.equal(d.view(torch.int32), d_ref.view(torch.int32))
-    wd, _ = vd.sswp_sharded(wops, source)
     wd_ref, _ = api.sswp(shard, w, source, raw=True)
-    assert torch.equal(wd.view(torch.int32), wd_ref.view(torch.int32))
-    comp, _ = vd.cc_sharded(ops)
     comp_ref, _ = api.connected_components(shard, raw=True)
-    assert torch.equal(comp, comp_ref)
+    for dense_only in (False, True):                   # pair lists (all-gather of int32 lists of changing length) and whole-array all-reduce
+        st = {}
+        d, _ = vd.sssp_sharded(wops, source, stats=st, dense_only=dense_only)
+        assert torch.equal(d.view(torch.int32), d_ref.view(torch.int32)), dense_only
+        assert (st.get("list_steps", 0) > 0) == (not dense_only), st
+        wd, _ = vd.sswp_sharded(wops, source, dense_only=dense_only)
+        assert torch.equal(wd.view(torch.int32), wd_ref.view(torch.int32)), dense_only
+        comp, _ = vd.cc_sharded(ops, dense_only=dense_only)
+        assert torch.equal(comp, comp_ref), dense_only
     ranks = vd.page_rank_sharded(ops, 5, 0, V)
     ranks_ref, _ = api.page_rank(shard, 5, raw=True)
     assert torch.equal(ranks.view(torch.int32), ranks_ref.view(torch.int32))

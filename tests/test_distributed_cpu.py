@@ -140,6 +140,27 @@ class NumpyShardOps:
         self._pack(found, mine)
         return (int(found.sum()), int(m.sum())) if want_counts else None
 
+    def new_pair_lists(self, parts, cap): return torch.zeros(parts * (1 + 2 * cap), dtype=torch.int32)
+
+    def diff_to_pairs(self, before, after, cap, out):
+        b, a = before.numpy().view(np.int32), after.numpy().view(np.int32)
+        idx = np.nonzero(a != b)[0][::-1]                            # any order
+        o = out.numpy()
+        o[0] = len(idx)
+        k = min(cap, len(idx))
+        o[1:1 + 2 * k:2] = idx[:k]
+        o[2:2 + 2 * k:2] = a[idx[:k]]
+
+    def apply_pairs(self, parts, stride, skip_part, lists, take_min, values):
+        l = lists.numpy()
+        v = values.numpy().view(np.int32)
+        for p in range(parts):
+            if p == skip_part:
+                continue
+            n = l[p * stride]
+            idx, val = l[p * stride + 1:p * stride + 1 + 2 * n:2], l[p * stride + 2:p * stride + 2 + 2 * n:2]
+            (np.minimum if take_min else np.maximum).at(v, idx, val)
+
     def sssp_init(self, d, source):
         d.fill_(float(FLT_MAX)); d[source] = 0
 
@@ -249,11 +270,20 @@ def _worker(rank, world, port, results):
         assert (st.get("sparse_levels", 0) > 0) == (cap > 0), (cap, st)
         lv, _ = vd.bfs_sharded(eq, source, equal_ranges=True, two_phase=True, sparse_cap=cap)
         assert (lv.numpy() == levels.numpy()).all()
-    d, _ = vd.sssp_sharded(ops, source)
+    st_s, st_c = {}, {}
+    d, _ = vd.sssp_sharded(ops, source, stats=st_s)
+    assert st_s.get("list_steps", 0) > 0 and st_s.get("dense_steps", 0) > 0, st_s           # both forms of the exchange ran (V/(2P) pairs is the switch)
+    d_dense, _ = vd.sssp_sharded(ops, source, dense_only=True)
+    assert (d_dense.numpy().view(np.int32) == d.numpy().view(np.int32)).all(), "changed-only exchange != whole-array exchange"
     wd, _ = vd.sswp_sharded(ops, source)
     assert (wd.numpy().view(np.int32) == O.sswp_bellman_ford(rowptr, adj, w, source)[0].view(np.int32)).all(), "sharded SSWP != oracle"
-    comp, _ = vd.cc_sharded(ops)
-    ranks = vd.page_rank_sharded(ops, 3, bounds[rank], bounds[rank + 1])
+    assert (vd.sswp_sharded(ops, source, dense_only=True)[0].numpy().view(np.int32) == wd.numpy().view(np.int32)).all()
+    comp, _ = vd.cc_sharded(ops, stats=st_c)
+    assert st_c.get("list_steps", 0) + st_c.get("dense_steps", 0) > 0
+    assert (vd.cc_sharded(ops, dense_only=True)[0].numpy() == comp.numpy()).all()
+    st_p = {}
+    ranks = vd.page_rank_sharded(ops, 3, bounds[rank], bounds[rank + 1], stats=st_p)
+    assert st_p["gathered_bytes"] == 3 * 4 * world * max(bounds[r + 1] - bounds[r] for r in range(world))
     ok = [(levels.numpy() == O.bfs_top_down(rowptr, adj, source)[0]).all(),
           (d.numpy().view(np.int32) == O.sssp_bellman_ford(rowptr, adj, w, source)[0].view(np.int32)).all(),
           (comp.numpy() == O.cc_sv(rowptr, adj)[0]).all(),

@@ -9,9 +9,11 @@ tests/ inject a numpy double to exercise the exchange protocol with gloo on CPU 
 Exchange payloads:
   BFS  : bitmap of the vertices discovered in this super-step (V/8 bytes per rank, all-gather + OR) instead of the
          reference's whole-array exchange
-  SSSP : allreduce(min) of the f32 distance array    (EXCHANGE_ALL with min_op, shortest_paths.hpp:136-141)
-  CC   : allreduce(min) of the int32 label array
-  PR   : owned slices of the new ranks               (EXCHANGE_PRIVATE_DATA, pr.hpp:127), as a sum with zeros elsewhere
+  SSSP : the (index, value) pairs of the distances each rank's step lowered, all-gathered and merged with min
+         (EXCHANGE_RECENTLY_CHANGED, mpi_exchange.hpp:110-150); allreduce(min) of the whole f32 array (EXCHANGE_ALL with min_op,
+         shortest_paths.hpp:136-141) only while more than V/(2P) entries change per rank
+  CC   : the same with the int32 labels
+  PR   : all-gather of the owned slices of the new ranks (EXCHANGE_PRIVATE_DATA, pr.hpp:127, mpi_exchange.hpp:222-271)
 """
 import ctypes as C
 import os
@@ -119,6 +121,16 @@ class HipShardOps:
         _l.check(self.L.vgl_hip_bfs_apply_bitmaps_owned(self.ctx.h, self.V, parts, _ptr(bits_all), _ptr(levels), int(level), _ptr(visited), _ptr(front),
                                                         _ptr(degrees), self.g.row_begin, self.g.row_end, C.byref(n), C.byref(d)))
         return n.value, d.value
+
+    def new_pair_lists(self, parts, cap):
+        return torch.empty(parts * (1 + 2 * cap), dtype=torch.int32, device=self.device)
+
+    def diff_to_pairs(self, before, after, cap, out):
+        """out[0] = number of entries where after != before (may exceed cap), then (index, value bits) pairs; asynchronous"""
+        _l.check(self.L.vgl_hip_diff_to_pairs_u32(self.ctx.h, self.V, _ptr(before), _ptr(after), int(cap), _ptr(out)))
+
+    def apply_pairs(self, parts, stride, skip_part, lists, take_min, values):
+        _l.check(self.L.vgl_hip_apply_pairs_u32(self.ctx.h, int(parts), int(stride), int(skip_part), _ptr(lists), int(bool(take_min)), self.V, _ptr(values), None))
 
     def sssp_init(self, d, source):
         _l.check(self.L.vgl_hip_sssp_init(self.ctx.h, self.V, int(source), _ptr(d)))
@@ -427,82 +439,146 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
     return levels, nlevels
 
 
-def sssp_sharded(ops, source, group=None):
-    P, _ = _world(group)
+class ChangedExchange:
+    """Merge of a replicated 4-byte vertex array after a super-step in which every rank changed some entries of ITS copy
+    (EXCHANGE_RECENTLY_CHANGED, common/mpi_exchange.hpp:110-150).  Per step: snapshot() before the local work, then merge():
+      1. the entries that differ from the snapshot are compacted into (index, value) pairs on the device,
+      2. the P counts are all-gathered (4 bytes each) -- every rank now knows how much everybody changed, which also answers
+         "did anything change anywhere" without a separate flag reduction,
+      3. while no rank changed more than V / (2 P) entries the pair lists (padded to the next power of two of the largest count)
+         are all-gathered and merged with the operator (min / max); otherwise the whole array is all-reduced, which then moves
+         fewer bytes than the lists would.
+    stats (dict): "list_steps", "dense_steps", "pair_bytes" (bytes this rank received as lists)."""
+
+    def __init__(self, ops, take_min, group=None, stats=None, dense_only=False):
+        self.ops, self.take_min, self.group, self.stats = ops, take_min, group, stats if stats is not None else {}
+        self.P, self.rank = _world(group)
+        self.active = _exchanging(self.P)
+        self.lists_ok = self.active and hasattr(ops, "diff_to_pairs") and not dense_only
+        if self.lists_ok:
+            self.cap = max(64, ops.V // (2 * max(self.P, 1)))
+            self.before = ops.new_i32()
+            self.mine = ops.new_pair_lists(1, self.cap)
+            self.all = ops.new_pair_lists(self.P, self.cap)
+            self.counts = ops.new_pair_lists(self.P, 0)              # P int32
+
+    def snapshot(self, values):
+        if self.lists_ok:
+            self.before.copy_(values.view(torch.int32))
+
+    def merge(self, values, changed_locally):
+        """returns True when some rank changed something in this step"""
+        if not self.active:
+            return bool(changed_locally)
+        ops, st = self.ops, self.stats
+        if self.lists_ok:
+            ops.diff_to_pairs(self.before, values, self.cap, self.mine)
+            ops.sync()
+            dist.all_gather_into_tensor(self.counts, self.mine[:1], group=self.group)
+            counts = self.counts.tolist()
+            most = max(counts)
+            if most == 0:
+                return False
+            if most <= self.cap:
+                n = 1 << (most - 1).bit_length()
+                n = min(n, self.cap)
+                stride = 1 + 2 * n
+                dist.all_gather_into_tensor(self.all[:self.P * stride], self.mine[:stride].contiguous(), group=self.group)
+                ops.apply_pairs(self.P, stride, self.rank, self.all, self.take_min, values)
+                st["list_steps"] = st.get("list_steps", 0) + 1
+                st["pair_bytes"] = st.get("pair_bytes", 0) + 4 * stride * self.P
+                return True
+        else:
+            ops.sync()
+        dist.all_reduce(values, op=dist.ReduceOp.MIN if self.take_min else dist.ReduceOp.MAX, group=self.group)
+        st["dense_steps"] = st.get("dense_steps", 0) + 1
+        if self.lists_ok:
+            return True
+        flag = ops.scalar([int(changed_locally)])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(flag.item()))
+
+
+def sssp_sharded(ops, source, group=None, stats=None, dense_only=False):
+    """Bellman-Ford over edge-cut shards: every rank relaxes the out-edges of its rows into its copy of the distances, the copies are
+    merged with min (ChangedExchange).  dense_only=True keeps the reference's EXCHANGE_ALL (whole-array all-reduce) every step."""
     d = ops.new_f32()
     ops.sssp_init(d, source)
+    ex = ChangedExchange(ops, True, group, stats, dense_only)
     iters = 0
     while True:
+        ex.snapshot(d)
         changed = ops.sssp_relax(d)
         iters += 1
-        if _exchanging(P):
-            ops.sync()
-            dist.all_reduce(d, op=dist.ReduceOp.MIN, group=group)
-            flag = ops.scalar([changed])
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            changed = int(flag.item())
-        if not changed:
+        if not ex.merge(d, changed):
             break
     return d, iters
 
 
-def sswp_sharded(ops, source, group=None):
-    """single-source widest paths over edge-cut shards: every rank relaxes its owned rows, the widths are merged with allreduce(MAX)
+def sswp_sharded(ops, source, group=None, stats=None, dense_only=False):
+    """single-source widest paths over edge-cut shards: every rank relaxes its owned rows, the widths are merged with max
     (the exchange of SSWP::vgl_dijkstra under MPI would be EXCHANGE_ALL with a max op, like shortest_paths.hpp:136-141 with min)"""
-    P, _ = _world(group)
     wd = ops.new_f32()
     ops.sswp_init(wd, source)
+    ex = ChangedExchange(ops, False, group, stats, dense_only)
     iters = 0
     while True:
+        ex.snapshot(wd)
         changed = ops.sswp_relax(wd)
         iters += 1
-        if _exchanging(P):
-            ops.sync()
-            dist.all_reduce(wd, op=dist.ReduceOp.MAX, group=group)
-            flag = ops.scalar([changed])
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            changed = int(flag.item())
-        if not changed:
+        if not ex.merge(wd, changed):
             break
     return wd, iters
 
 
-def cc_sharded(ops, group=None):
-    P, _ = _world(group)
+def cc_sharded(ops, group=None, stats=None, dense_only=False):
+    """Shiloach-Vishkin over edge-cut shards (shiloach_vishkin.hpp:7-88): hook over the owned rows, labels merged with min, pointer
+    jumping on the merged (replicated) labels -- every rank jumps the same array, so no exchange follows the jump."""
     comp = ops.new_i32()
     ops.cc_init(comp)
+    ex = ChangedExchange(ops, True, group, stats, dense_only)
     passes = 0
     while True:
+        ex.snapshot(comp)
         changed = ops.cc_hook(comp)
         passes += 1
-        if _exchanging(P):
-            ops.sync()
-            dist.all_reduce(comp, op=dist.ReduceOp.MIN, group=group)
-            flag = ops.scalar([changed])
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            changed = int(flag.item())
-        if not changed:
+        if not ex.merge(comp, changed):
             break
         ops.cc_jump(comp)
     return comp, passes
 
 
-def page_rank_sharded(ops, iterations, row_begin, row_end, group=None):
-    P, _ = _world(group)
+def page_rank_sharded(ops, iterations, row_begin, row_end, group=None, stats=None):
+    """PageRank over edge-cut shards: every rank pulls the new ranks of the rows it owns from the replicated old ranks; the owned
+    slices are all-gathered (EXCHANGE_PRIVATE_DATA, pr.hpp:127).  Ranks own different numbers of rows in general (edge-balanced
+    cut), so the slices travel padded to the longest one: V/P * 4 bytes per rank instead of the V * 4 of a zero-padded sum."""
+    P, rank = _world(group)
     indeg = ops.new_i32()
     indeg.zero_()
     ops.indeg_add(indeg)
-    if _exchanging(P):
+    exchanging = _exchanging(P)
+    if exchanging:
         ops.sync()
         dist.all_reduce(indeg, op=dist.ReduceOp.SUM, group=group)
+        bounds = ops.scalar([row_begin, row_end])
+        every = ops.scalar([0] * (2 * P))
+        dist.all_gather_into_tensor(every, bounds, group=group)
+        every = every.view(P, 2).tolist()
+        longest = max(hi - lo for lo, hi in every)
+        send = ops.new_f32()[:longest]
+        recv = ops.new_f32()[:0].new_empty(P * longest)
     ranks, rdeg, contrib = ops.new_f32(), ops.new_f32(), ops.new_f32()
     ops.pr_setup(indeg, ranks, rdeg)
     for _ in range(iterations):
         ops.pr_iteration(indeg, rdeg, ranks, contrib)     # writes the owned rows of `ranks`
-        if _exchanging(P):
+        if exchanging:
             ops.sync()
-            ranks[:row_begin] = 0
-            ranks[row_end:] = 0
-            dist.all_reduce(ranks, op=dist.ReduceOp.SUM, group=group)   # x + 0 + ... + 0 is exact
+            send[:row_end - row_begin] = ranks[row_begin:row_end]
+            dist.all_gather_into_tensor(recv, send, group=group)
+            for p, (lo, hi) in enumerate(every):
+                if p != rank and hi > lo:
+                    ranks[lo:hi] = recv[p * longest:p * longest + (hi - lo)]
+            if stats is not None:
+                stats["gathered_bytes"] = stats.get("gathered_bytes", 0) + 4 * longest * P
     ops.sync()
     return ranks
