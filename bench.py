@@ -3,13 +3,17 @@
 
 One "step" = one BFS traversal of the synthetic graph from a fresh random non-isolated source
 (apps/bfs/bfs.cpp:36-40; TEPS = E_graph / time, performance_stats.hpp:272-275).
-N=1   : BASELINE configs[1] "BFS direction-optimising on RMAT scale-24, 1xMI355X" (graph resident in HBM).
-N>1   : weak scaling (default): RMAT scale 24+log2(N) (RMAT-27 at 8 GPUs, BASELINE configs[2]), every rank streams the
-        counter-based generator and keeps its edge-cut shard (~2^29 edges per GPU at every N), one process per GPU, bitmap
-        all-gather over RCCL per level.  `--scaling strong` shards the scale-24 graph instead.
-Prints ONE JSON line on rank 0 with the driver contract keys plus `roofline` (dominant kernel, algorithmic bytes per
-launch / HIP-event duration measured in the timed region) and `cpu_baseline` (the oracle's OpenMP port of the
-reference top-down BFS on the same graph, timed on the host cores; N=1 only).  Extra keys carry the SSSP numbers.
+N=1   : BASELINE configs[1] "BFS direction-optimising on RMAT scale-24, 1xMI355X" (graph resident in HBM).  The line carries
+        `roofline` (dominant kernel: algorithmic bytes per launch / HIP-event duration inside the timed region) and `cpu_baseline`
+        (the oracle's OpenMP port of the reference top-down BFS on the same graph, on the CPUs the box grants).  The levels of the
+        last timed traversal are checked against the reference algorithm (top-down) and the CPU oracle; a mismatch fails the run.
+        Extra keys: SSSP (configs[2]: Bellman-Ford push / pull / direction-optimising, delta-stepping), PageRank (configs[3]'s graph,
+        uniform-25), CC (configs[4]'s algorithm on the symmetrised RMAT-24), each with its own CPU-baseline leg.
+N>1   : weak scaling (default): RMAT scale 24+log2(N) (RMAT-27 at 8 GPUs), every rank streams the counter-based generator and keeps
+        its edge-cut shard (~2^29 edges per GPU at every N), one process per GPU, bitmap all-gather over RCCL per level.
+        `--scaling strong` shards the scale-24 graph instead.  Extra keys: PageRank on uniform-25 cut N ways (configs[3]) and
+        Shiloach-Vishkin on the symmetrised RMAT scale 24+log2(N) (configs[4] at 8 GPUs: RMAT-27), with rank 0's kernel rooflines.
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a child process).
 """
 import argparse
 import json
@@ -48,6 +52,309 @@ def pick_sources(rowptr_dev, n, seed, degrees=None):
     return [int(nz[i]) for i in pick]
 
 
+def frac(gbps):
+    return round(gbps / HBM_PEAK_GBS, 5)
+
+
+def timed_kernels(ctx, names):
+    out = {}
+    for name in names:
+        n, ms = ctx.timing_get(name)
+        out[name] = {"launches": n, "total_ms": round(ms, 4), "ms_per_launch": round(ms / n, 5) if n else None}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# single-GPU legs
+# ------------------------------------------------------------------------------------------------------------------------
+def leg_sssp(api, ctx, g, w, E, V, sources, args, extra, cpu):
+    """BASELINE configs[2]: Bellman-Ford SSSP on RMAT-24 with f32 weights.  Every schedule reaches the same f32 bits (checked
+    here against the all-active push run); what differs is how many edges a run streams."""
+    import torch
+    res, ref = {}, None
+    t1 = time.perf_counter()
+    pull_plan = api.SsspPullPlan(g, w)
+    torch.cuda.synchronize()
+    t_pull_plan = time.perf_counter() - t1
+    runs = [("bellman_ford_push_all_active", dict(mode=api.SSSP_ALL_ACTIVE), ("sssp_relax",)),
+            ("bellman_ford_push_active_tiles", dict(mode=api.SSSP_ACTIVE_TILES), ("sssp_relax",)),
+            ("bellman_ford_pull_blocked", dict(mode=api.SSSP_PULL, plan=pull_plan), ("sssp_pull_gather", "sssp_pull_accumulate")),
+            ("bellman_ford_direction_optimising", dict(mode=api.SSSP_DIRECTION_OPT, plan=pull_plan), ("sssp_relax", "sssp_pull_gather", "sssp_pull_accumulate"))]
+    srcs = sources[args.warmup:args.warmup + 3]
+    for name, kw, kernels in runs:
+        api.sssp(g, w, sources[0], raw=True, **kw)
+        ctx.timing(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sst = []
+        for s in srcs:
+            dist_s, st = api.sssp(g, w, s, raw=True, **kw)
+            sst.append(st)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t1) / len(sst)
+        kern = timed_kernels(ctx, kernels)
+        ctx.timing(False)
+        if ref is None:
+            ref = dist_s.clone()
+        elif api.count_not_equal(ctx, dist_s, ref):
+            sys.exit(f"bench.py: SSSP schedule {name} changed the distances")
+        edges = sum(s["edges_relaxed"] for s in sst)
+        rec = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "iterations": sst[-1]["iterations"], "push_steps": sst[-1]["push_steps"],
+               "pull_steps": sst[-1]["pull_steps"], "edges_relaxed_per_run": edges // len(sst), "kernels": kern}
+        alg = 12 * E + 28 * V                     # one all-edges relax pass (SURVEY 8d)
+        if name == "bellman_ford_push_all_active":
+            ms = kern["sssp_relax"]["ms_per_launch"]
+            rec["relax_pass"] = {"ms": ms, "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms * 1e-3) / 1e9)}
+        if name == "bellman_ford_pull_blocked":
+            ms = kern["sssp_pull_gather"]["ms_per_launch"] + kern["sssp_pull_accumulate"]["ms_per_launch"]
+            # one all-edges relax pass = gather launch + accumulate launch; the pass really streams 16 B per edge (2 + 4 + 4 in the
+            # gather kernel, 4 + 2 in the accumulate kernel)
+            rec["relax_pass"] = {"ms": round(ms, 4), "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms * 1e-3) / 1e9),
+                                 "streamed_GBps": round(16 * E / (ms * 1e-3) / 1e9, 1)}
+        if kw.get("plan") is not None:
+            rec["plan_build_ms_once_per_weights_NOT_in_ms"] = round(t_pull_plan * 1e3, 1)
+        res[name] = rec
+    pull_plan.close()
+    t1 = time.perf_counter()
+    plan = api.SsspPlan(g, w, args.sssp_delta)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t1
+    api.sssp(g, w, sources[0], plan=plan, raw=True)
+    ctx.timing(True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    sst = []
+    for s in sources[args.warmup:args.warmup + 6]:
+        dist_s, st = api.sssp(g, w, s, plan=plan, raw=True)
+        sst.append(st)
+    torch.cuda.synchronize()
+    dts = (time.perf_counter() - t1) / len(sst)
+    n, ms = ctx.timing_get("sssp_relax")
+    ctx.timing(False)
+    edges = sum(s["edges_relaxed"] for s in sst)
+    res["delta_stepping"] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "delta": args.sssp_delta, "steps": sst[0]["iterations"],
+                             "edges_relaxed_per_run": edges // len(sst), "plan_build_ms_once_per_weights_NOT_in_ms": round(t_plan * 1e3, 2),
+                             "relax_kernel": {"launches": n, "total_ms": round(ms, 3),
+                                              "algorithmic_GBps": round(12 * edges / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}}
+    plan.close()
+    extra["sssp"] = res
+    extra["sssp_value_teps"] = res["bellman_ford_direction_optimising"]["teps"]
+    extra["sssp_value_note"] = ("direction-optimising Bellman-Ford (push <-> blocked pull); the blocked plan is built once per weights and is "
+                                "not in the time; the bucketed schedule (sssp.delta_stepping, plan likewise excluded) is faster still")
+    if cpu is not None:
+        O, threads = cpu
+        rp, adj, wh = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy(), w.cpu().numpy()
+        s = srcs[-1]
+        tc = time.perf_counter()
+        cd, it = O.sssp_bellman_ford(rp, adj, wh, s, parallel=True)
+        dtc = time.perf_counter() - tc
+        gd = api.sssp(g, w, s, api.SSSP_ACTIVE_TILES, raw=True)[0]
+        if not (gd.cpu().numpy().view("int32") == cd.view("int32")).all():
+            sys.exit("bench.py: SSSP distances differ from the CPU oracle's")
+        extra["verified"]["sssp_equals_cpu_oracle"] = True
+        extra["cpu_baseline_sssp"] = {"value": round(E / dtc, 1), "unit": "edges/s", "cores": threads, "kind": "port", "iterations": it,
+                                      "sample": "1 all-active push Bellman-Ford run (oracle/vgl_oracle.c, OpenMP) on the same RMAT graph and weights"}
+        del rp, adj, wh
+    # widest paths (f1 widening): same graph, the weights as capacities
+    api.sswp(g, w, sources[0], raw=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    wst = [api.sswp(g, w, s, raw=True)[1] for s in srcs]
+    torch.cuda.synchronize()
+    dts = (time.perf_counter() - t1) / len(wst)
+    extra["sswp"] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "super_steps": wst[0]["iterations"]}
+
+
+def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
+    """PageRank (BASELINE configs[3]: uniform-random scale 25) and CC (configs[4]'s algorithm on one GPU's worth: symmetrised
+    RMAT-24 x16, 537 M stored edges); TEPS = iterations * E / time for PR (pr.hpp:147), E / time for CC."""
+    import numpy as np
+    import torch
+    iters = 10
+    for kind, pscale in (("uniform", 25), ("rmat", 24)):
+        pV, pE = 1 << pscale, (1 << pscale) * ef
+        ps, pd = (ctx.gen_uniform if kind == "uniform" else ctx.gen_rmat)(pscale, ef, seed)
+        pg = api.Graph.from_coo(ctx, pV, ps, pd, with_incoming=True, renumber=None if kind == "uniform" else renumber)
+        del ps, pd
+        rec, auto_ranks = {}, None
+        for mode, mname in ((api.PR_AUTO, "auto"), (api.PR_EXACT_ORDER, "exact_order")):
+            t1 = time.perf_counter()
+            api.page_rank(pg, 2, raw=True, mode=mode)
+            torch.cuda.synchronize()
+            t_first = time.perf_counter() - t1
+            ctx.timing(True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ranks, pst = api.page_rank(pg, iters, raw=True, mode=mode)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t1
+            kern = timed_kernels(ctx, ("pr_pull", "pr_blk_gather", "pr_blk_accumulate"))
+            ctx.timing(False)
+            blocked = kern["pr_blk_gather"]["launches"] > 0
+            pass_ms = (kern["pr_blk_gather"]["ms_per_launch"] + kern["pr_blk_accumulate"]["ms_per_launch"]) if blocked else kern["pr_pull"]["ms_per_launch"]
+            alg = 8 * pE + 28 * pV
+            one = {"path": "blocked (LDS windows, exact fixed-point sums)" if blocked else "adjacency-order f32 chain",
+                   "teps": round(iters * pE / dtp, 1), "ms_per_iteration": round(dtp / iters * 1e3, 3), "iterations": iters,
+                   "pull_pass": {"ms": round(pass_ms, 4), "algorithmic_GBps": round(alg / (pass_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (pass_ms * 1e-3) / 1e9)},
+                   "whole_iteration_frac_of_hbm_peak": frac(alg / (dtp / iters) / 1e9),
+                   "kernels": {k: v for k, v in kern.items() if v["launches"]}}
+            if blocked:
+                one["plan_build_ms_once_per_graph_NOT_in_ms"] = round(max(0.0, t_first - 2 * dtp / iters) * 1e3, 1)
+            if mname == "auto":
+                rec.update(one)
+                auto_ranks = ranks
+                if not blocked:
+                    break                                         # AUTO chose the ordered kernel: nothing else to compare
+            else:
+                rec["exact_order"] = one
+                rec["max_relative_difference_blocked_vs_chain"] = float(((auto_ranks - ranks).abs() / ranks).max())
+        extra[f"pagerank_{kind}{pscale}"] = rec
+        if cpu is not None and kind == "uniform":
+            O, threads = cpu
+            rp, adj = pg.out_rowptr.cpu().numpy(), pg.out_adj.cpu().numpy()
+            indeg = O.indegree_noloops(rp, adj)
+            tc = time.perf_counter()
+            cr = O.pagerank(rp, adj, 2, 1, parallel=True, indeg=indeg)
+            dtc = time.perf_counter() - tc
+            gr, _ = api.page_rank(pg, 2, raw=True)
+            err = float(np.max(np.abs(gr.cpu().numpy().astype(np.float64) - cr) / cr))
+            if err > 1e-6:
+                sys.exit(f"bench.py: PageRank differs from the CPU oracle's by {err} relative")
+            extra["verified"]["pagerank_uniform25_max_rel_err_vs_cpu_oracle"] = err
+            extra["cpu_baseline_pagerank"] = {"value": round(2 * pE / dtc, 1), "unit": "edges/s", "cores": threads, "kind": "port",
+                                              "sample": "2 pull iterations (oracle/vgl_oracle.c, OpenMP) on the same uniform-25 graph"}
+            del rp, adj
+        pg.close()
+        del pg, auto_ranks
+        torch.cuda.empty_cache()
+    cs, cd = ctx.gen_rmat(24, 16, seed)
+    cs, cd = torch.cat([cs, cd]), torch.cat([cd, cs])
+    cE = cs.numel()
+    cg = api.Graph.from_coo(ctx, 1 << 24, cs, cd, with_incoming=False, renumber=renumber)
+    del cs, cd
+    res = {}
+    for name, sym in (("shiloach_vishkin", False), ("union_find_symmetric", True)):
+        api.connected_components(cg, raw=True, symmetric=sym)
+        ctx.timing(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            comp, cst = api.connected_components(cg, raw=True, symmetric=sym)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t1) / 3
+        n, ms = ctx.timing_get("cc_hook")
+        ctx.timing(False)
+        res[name] = {"teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "passes": cst["hook_passes"]}
+        if n and not sym:
+            alg = 8 * cE + 12 * (1 << 24)
+            res[name]["hook_pass"] = {"ms": round(ms / n, 4), "algorithmic_GBps": round(alg / (ms / n * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms / n * 1e-3) / 1e9)}
+    extra["cc_rmat24x16_symmetrised"] = res
+    if cpu is not None:
+        O, threads = cpu
+        rp, adj = cg.out_rowptr.cpu().numpy(), cg.out_adj.cpu().numpy()
+        tc = time.perf_counter()
+        cc, passes = O.cc_sv(rp, adj, parallel=True)
+        dtc = time.perf_counter() - tc
+        if not (comp.cpu().numpy() == cc).all():
+            sys.exit("bench.py: CC labels differ from the CPU oracle's")
+        extra["verified"]["cc_equals_cpu_oracle"] = True
+        extra["cpu_baseline_cc"] = {"value": round(cE / dtc, 1), "unit": "edges/s", "cores": threads, "kind": "port", "passes": passes,
+                                    "sample": "1 Shiloach-Vishkin run (oracle/vgl_oracle.c, OpenMP) on the same symmetrised RMAT-24 x16 graph"}
+    cg.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# multi-GPU legs (PageRank / CC over edge-cut shards; the BFS leg is in main)
+# ------------------------------------------------------------------------------------------------------------------------
+def leg_pr_sharded(api, vd, ctx, dist, world, rank, pscale, ef, seed, chunk_edges, extra):
+    """BASELINE configs[3]: PageRank pull on uniform-random scale 25 cut `world` ways, owned slices all-gathered per iteration"""
+    import torch
+    iters = 10
+    pV, pE = 1 << pscale, (1 << pscale) * ef
+    t1 = time.perf_counter()
+    shard, _, bounds = vd.build_generated_shard(ctx, pscale, ef, seed, rank, world, kind="uniform", renumber=None, chunk_edges=chunk_edges,
+                                                placement="ranges", with_incoming=False)
+    ctx.sync()
+    t_build = time.perf_counter() - t1
+    ops = vd.HipShardOps(shard)
+    vd.page_rank_sharded(ops, 2, bounds[rank], bounds[rank + 1])
+    st = {}
+    ctx.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ranks = vd.page_rank_sharded(ops, iters, bounds[rank], bounds[rank + 1], stats=st)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dtp = time.perf_counter() - t1
+    kern = timed_kernels(ctx, ("pr_pull", "pr_blk_gather", "pr_blk_accumulate"))
+    ctx.timing(False)
+    if world > 1:
+        tmax = torch.tensor([dtp], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dtp = float(tmax.item())
+    mass = float(ranks.double().sum())
+    blocked = kern["pr_blk_gather"]["launches"] > 0
+    pass_ms = (kern["pr_blk_gather"]["ms_per_launch"] + kern["pr_blk_accumulate"]["ms_per_launch"]) if blocked else kern["pr_pull"]["ms_per_launch"]
+    alg = 8 * int(shard.E) + 28 * pV                              # this shard's edges; the V-proportional passes are replicated
+    extra[f"pagerank_uniform{pscale}_sharded"] = {
+        "teps": round(iters * pE / dtp, 1), "ms_per_iteration": round(dtp / iters * 1e3, 3), "iterations": iters, "ranks_sum": mass,
+        "shard_edges": int(shard.E), "graph_build_s": round(t_build, 2), "exchange": "all-gather of owned rank slices",
+        "gathered_bytes_per_iteration": st.get("gathered_bytes", 0) // iters,
+        "rank0_pull_pass": {"ms": round(pass_ms, 4), "algorithmic_GBps": round(alg / (pass_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (pass_ms * 1e-3) / 1e9),
+                            "path": "blocked" if blocked else "adjacency-order chain"}}
+    if abs(mass - 1.0) > 1e-3:
+        sys.exit(f"bench.py: sharded PageRank lost mass ({mass})")
+    shard.close()
+    del shard, ops, ranks
+    torch.cuda.empty_cache()
+
+
+def leg_cc_sharded(api, vd, ctx, dist, world, rank, cc_scale, seed, chunk_edges, renumber, extra):
+    """BASELINE configs[4]: Shiloach-Vishkin on the symmetrised RMAT graph (edge factor 16 generated, 32 stored), edge-cut, labels merged
+    by the changed-only exchange (whole-array all-reduce while most labels change)"""
+    import torch
+    cV, cE = 1 << cc_scale, (1 << cc_scale) * 16 * 2
+    t1 = time.perf_counter()
+    shard, _, bounds = vd.build_generated_shard(ctx, cc_scale, 16, seed, rank, world, kind="rmat", renumber=renumber, chunk_edges=chunk_edges,
+                                                placement="ranges", symmetric=True, with_incoming=False)
+    ctx.sync()
+    t_build = time.perf_counter() - t1
+    ops = vd.HipShardOps(shard)
+    vd.cc_sharded(ops)
+    st = {}
+    ctx.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    comp, passes = vd.cc_sharded(ops, stats=st)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dtc = time.perf_counter() - t1
+    n, ms = ctx.timing_get("cc_hook")
+    ctx.timing(False)
+    if world > 1:
+        tmax = torch.tensor([dtc], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dtc = float(tmax.item())
+    ok = bool((comp[comp.long()] == comp).all())                 # labels are roots: idempotent under the pointer jump
+    alg = 8 * int(shard.E) + 12 * cV
+    extra["cc_rmat_symmetrised_sharded"] = {
+        "scale": cc_scale, "stored_edges": cE, "teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "hook_passes": passes, "shard_edges": int(shard.E),
+        "graph_build_s": round(t_build, 2), "exchange": st, "labels_idempotent": ok,
+        "rank0_hook_pass": {"ms": round(ms / max(n, 1), 4), "algorithmic_GBps": round(alg / (ms / max(n, 1) * 1e-3) / 1e9, 1) if ms > 0 else None,
+                            "frac_of_hbm_peak": frac(alg / (ms / max(n, 1) * 1e-3) / 1e9) if ms > 0 else None}}
+    if not ok:
+        sys.exit("bench.py: sharded CC labels are not idempotent")
+    shard.close()
+    del shard, ops, comp
+    torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,11 +365,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sssp", action="store_true")
-    ap.add_argument("--no-pr-cc", action="store_true", help="skip the PageRank (uniform-25) and CC (symmetrised RMAT-24x16) extras")
+    ap.add_argument("--no-pr-cc", action="store_true", help="skip the PageRank (uniform-25) and CC (symmetrised RMAT) extras")
     ap.add_argument("--cpu-sources", type=int, default=10)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU super-step path even with one rank (debug)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = RMAT scale+log2(N) built shard-by-shard (default), strong = the scale-24 graph cut N ways")
+    ap.add_argument("--pr-scale", type=int, default=25, help="N>1: scale of the uniform-random graph of the PageRank leg (BASELINE configs[3]: 25)")
+    ap.add_argument("--cc-scale", type=int, default=0, help="N>1: scale of the symmetrised RMAT graph of the CC leg (default: the BFS leg's scale, RMAT-27 at 8 GPUs)")
     ap.add_argument("--chunk-edges", type=int, default=1 << 27, help="generator chunk of the streaming shard build")
     ap.add_argument("--sssp-delta", type=float, default=10.0)    # 8 .. 12 measure the same (13.0 ms), 16: 13.9 ms, 4: 14.0 ms
     ap.add_argument("--renumber", default="total", choices=["none", "out", "in", "total"],
@@ -79,7 +388,7 @@ def main():
         sys.exit(subprocess.run(cmd).returncode)
     if env_world is not None and int(env_world) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}")
-    if args.gpus & (args.gpus - 1):
+    if args.gpus < 1 or args.gpus & (args.gpus - 1):
         sys.exit("bench.py: --gpus must be a power of two (weak scaling adds log2(N) to the scale; blocks are dealt round-robin)")
     # the CPU baseline's OpenMP runtime reads these when it is first loaded (scripts/helpers.py:147-153)
     os.environ.setdefault("OMP_PROC_BIND", "close")
@@ -103,8 +412,9 @@ def main():
     renumber = None if args.renumber == "none" else args.renumber
     sharded = world > 1 or args.force_sharded
     weak = sharded and args.scaling == "weak"
+    log2n = max(world, 1).bit_length() - 1
     if weak:
-        scale += max(world, 1).bit_length() - 1              # per-GPU edges stay ~2^scale * ef
+        scale += log2n                                           # per-GPU edges stay ~2^scale * ef
     V, E = 1 << scale, (1 << scale) * ef
     t_build = time.time()
     if weak:
@@ -187,11 +497,13 @@ def main():
                         "bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(per_launch_ms, 5),
                         "launches": kern[dom]["launches"]}
         total_alg = sum(s["algorithmic_bytes"] for s in stats)
+        kernel_sum_ms = sum(v["total_ms"] for v in kern.values())
         # the reference's own accounting (settings.h:140-155, INT_ELEMENTS_PER_EDGE = 4 for BFS, apps/bfs/bfs.cpp:3): 16 B per edge
         # of the GRAPH per traversal, whatever was actually touched -- reported for comparability only
         extra["vgl_accounting_GBps"] = round(16.0 * E * args.steps / dt / 1e9, 1)
         extra["bfs"] = {"kernels": kern, "levels_per_bfs": levels / len(stats), "td_steps": td_steps, "bu_steps": bu_steps,
                         "edges_examined_per_bfs": (bu_edges + td_edges) / len(stats),
+                        "timed_kernels_over_wall_time": round(kernel_sum_ms * 1e-3 / dt, 4),
                         "whole_bfs_algorithmic_GBps": round(total_alg / dt / 1e9, 2),
                         "whole_bfs_frac_of_hbm_peak": round(total_alg / dt / 1e9 / HBM_PEAK_GBS, 5)}
         # reference algorithm (pure top-down, bfs.hpp:6-51) for comparison
@@ -203,78 +515,12 @@ def main():
             "teps": round(E / dt_td, 1), "ms": round(dt_td * 1e3, 3),
             "algorithmic_GBps": round(sum(s["algorithmic_bytes"] for s in td_stats) / len(td_stats) / dt_td / 1e9, 2)}
 
-        # ---- SSSP (BASELINE configs[2]) ----
-        if not args.no_sssp:
-            w = ctx.gather_u32(g.perm, ctx.gen_weights(E, seed))
-            res = {}
-            for mode, name in ((api.SSSP_ACTIVE_TILES, "active_tiles"), (api.SSSP_ALL_ACTIVE, "all_active")):
-                api.sssp(g, w, sources[0], mode, raw=True)
-                ctx.timing(True)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                sst = [api.sssp(g, w, s, mode, raw=True)[1] for s in sources[args.warmup:args.warmup + 3]]
-                torch.cuda.synchronize()
-                dts = (time.perf_counter() - t1) / len(sst)
-                n, ms = ctx.timing_get("sssp_relax")
-                ctx.timing(False)
-                edges = sum(s["edges_relaxed"] for s in sst)
-                res[name] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "iterations": sst[0]["iterations"],
-                             "edges_relaxed_per_run": edges // len(sst),
-                             "relax_kernel": {"launches": n, "total_ms": round(ms, 3),
-                                              "algorithmic_GBps": round(12 * edges / (ms * 1e-3) / 1e9, 2) if ms > 0 else None,
-                                              "frac_of_hbm_peak": round(12 * edges / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None}}
-            t1 = time.perf_counter()
-            plan = api.SsspPlan(g, w, args.sssp_delta)
-            torch.cuda.synchronize()
-            t_plan = time.perf_counter() - t1
-            api.sssp(g, w, sources[0], plan=plan, raw=True)
-            ctx.timing(True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            sst = [api.sssp(g, w, s, plan=plan, raw=True)[1] for s in sources[args.warmup:args.warmup + 6]]
-            torch.cuda.synchronize()
-            dts = (time.perf_counter() - t1) / len(sst)
-            n, ms = ctx.timing_get("sssp_relax")
-            ctx.timing(False)
-            edges = sum(s["edges_relaxed"] for s in sst)
-            res["delta_stepping"] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "delta": args.sssp_delta, "steps": sst[0]["iterations"],
-                                     "edges_relaxed_per_run": edges // len(sst), "plan_build_ms_once_per_weights": round(t_plan * 1e3, 2),
-                                     "relax_kernel": {"launches": n, "total_ms": round(ms, 3),
-                                                      "algorithmic_GBps": round(12 * edges / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}}
-            plan.close()
-            extra["sssp"] = res
-            extra["sssp_value_teps"] = res["delta_stepping"]["teps"]
-            # widest paths (f1 widening): same graph, the weights as capacities
-            api.sswp(g, w, sources[0], raw=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            wst = [api.sswp(g, w, s, raw=True)[1] for s in sources[args.warmup:args.warmup + 3]]
-            torch.cuda.synchronize()
-            dts = (time.perf_counter() - t1) / len(wst)
-            extra["sswp"] = {"teps": round(E / dts, 1), "ms": round(dts * 1e3, 3), "super_steps": wst[0]["iterations"]}
-            del w
-
-        # ---- HITS (f64) and SCC on the same graph (f1 widening) ----
-        if not args.no_pr_cc:
-            api.hits(g, 1, raw=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            api.hits(g, 5, raw=True)
-            torch.cuda.synchronize()
-            dth = (time.perf_counter() - t1) / 5
-            extra["hits"] = {"teps": round(2 * E / dth, 1), "ms_per_step": round(dth * 1e3, 3), "edge_sweeps_per_step": 2, "dtype": "f64"}
-            api.strongly_connected_components(g, raw=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            _, sst = api.strongly_connected_components(g, raw=True)
-            torch.cuda.synchronize()
-            dtsc = time.perf_counter() - t1
-            extra["scc"] = {"teps": round(E / dtsc, 1), "ms": round(dtsc * 1e3, 3), **sst}
-
-        # ---- CPU baseline: the oracle's OpenMP port of the reference top-down BFS, same graph, host cores ----
+        # ---- CPU baseline: the oracle's OpenMP port of the reference top-down BFS, same graph, the CPUs the box grants ----
+        cpu = None
         if not args.no_cpu_baseline:
             from oracle import oracle as O
-            threads = O.set_threads()                                    # the CPUs this box grants (affinity / cgroup quota), not every core it shows
+            threads = O.set_threads()                                    # affinity / cgroup quota, not every core the box shows
+            cpu = (O, threads)
             rp = g.out_rowptr.cpu().numpy()
             adj = g.out_adj.cpu().numpy()
             ref_lv, _ = O.bfs_top_down(rp, adj, check_source, parallel=True)           # warm-up / page-in, and the checker of the timed path
@@ -294,53 +540,36 @@ def main():
                                       f"{os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}) of the same RMAT-{scale} graph",
                             "host": O.host_description()}
             del rp, adj
+        del lv_do, lv_td
 
-        # ---- PageRank (BASELINE configs[3]: uniform-random scale 25) and CC (configs[4] stand-in on one GPU: symmetrised
-        #      RMAT-24 x16, 537 M stored edges); TEPS = iterations * E / time for PR (pr.hpp:147), E / time for CC ----
+        # ---- SSSP (BASELINE configs[2]) ----
+        if not args.no_sssp:
+            w = ctx.gather_u32(g.perm, ctx.gen_weights(E, seed))
+            leg_sssp(api, ctx, g, w, E, V, sources, args, extra, cpu)
+            del w
+
+        # ---- HITS (f64) and SCC on the same graph (f1 widening) ----
+        if not args.no_pr_cc:
+            api.hits(g, 1, raw=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            api.hits(g, 5, raw=True)
+            torch.cuda.synchronize()
+            dth = (time.perf_counter() - t1) / 5
+            extra["hits"] = {"teps": round(2 * E / dth, 1), "ms_per_step": round(dth * 1e3, 3), "edge_sweeps_per_step": 2, "dtype": "f64"}
+            api.strongly_connected_components(g, raw=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, sst = api.strongly_connected_components(g, raw=True)
+            torch.cuda.synchronize()
+            dtsc = time.perf_counter() - t1
+            extra["scc"] = {"teps": round(E / dtsc, 1), "ms": round(dtsc * 1e3, 3), **sst}
+
         if not args.no_pr_cc and scale == 24:
             g.close()
             g.out_adj = g.in_adj = g.perm = None
             torch.cuda.empty_cache()
-            iters = 10
-            for kind, pscale in (("uniform", 25), ("rmat", 24)):
-                pV, pE = 1 << pscale, (1 << pscale) * ef
-                ps, pd = (ctx.gen_uniform if kind == "uniform" else ctx.gen_rmat)(pscale, ef, seed)
-                pg = api.Graph.from_coo(ctx, pV, ps, pd, with_incoming=True, renumber=None if kind == "uniform" else renumber)
-                del ps, pd
-                api.page_rank(pg, 2, raw=True)
-                ctx.timing(True)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                _, pst = api.page_rank(pg, iters, raw=True)
-                torch.cuda.synchronize()
-                dtp = time.perf_counter() - t1
-                n, ms = ctx.timing_get("pr_pull")
-                ctx.timing(False)
-                extra[f"pagerank_{kind}{pscale}"] = {
-                    "teps": round(iters * pE / dtp, 1), "ms_per_iteration": round(dtp / iters * 1e3, 3), "iterations": iters,
-                    "pull_kernel": {"launches": n, "ms_per_launch": round(ms / max(n, 1), 3),
-                                    "algorithmic_GBps": round((8 * pE + 28 * pV) / (ms / max(n, 1) * 1e-3) / 1e9, 1) if ms > 0 else None}}
-                pg.close()
-                del pg
-                torch.cuda.empty_cache()
-            cs, cd = ctx.gen_rmat(24, 16, seed)
-            cs, cd = torch.cat([cs, cd]), torch.cat([cd, cs])
-            cE = cs.numel()
-            cg = api.Graph.from_coo(ctx, 1 << 24, cs, cd, with_incoming=False, renumber=renumber)
-            del cs, cd
-            res = {}
-            for name, sym in (("shiloach_vishkin", False), ("union_find_symmetric", True)):
-                api.connected_components(cg, raw=True, symmetric=sym)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    _, cst = api.connected_components(cg, raw=True, symmetric=sym)
-                torch.cuda.synchronize()
-                dtc = (time.perf_counter() - t1) / 3
-                res[name] = {"teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "passes": cst["hook_passes"]}
-            extra["cc_rmat24x16_symmetrised"] = res
-            cg.close()
-            del cg
+            leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu)
         workload = f"BFS direction-optimising on RMAT scale-{scale} (edge factor {ef}), 1xMI355X"
         scaling = "none"
     else:
@@ -395,6 +624,13 @@ def main():
         workload = (f"BFS direction-optimising super-steps (bitmap all-gather per level) on RMAT scale-{scale} "
                     f"(edge factor {ef}), edge-cut over {world} GPUs")
         scaling = "weak" if weak else "strong"
+        if not args.no_pr_cc:
+            # BASELINE configs[3] and [4]: PageRank on uniform-25 and Shiloach-Vishkin on the symmetrised RMAT graph over the same ranks
+            shard.close()
+            del shard, ops, degrees
+            torch.cuda.empty_cache()
+            leg_pr_sharded(api, vd, ctx, dist, world, rank, args.pr_scale, ef, seed, args.chunk_edges, extra)
+            leg_cc_sharded(api, vd, ctx, dist, world, rank, args.cc_scale or scale, seed, args.chunk_edges, renumber, extra)
 
     if rank == 0:
         out = {

@@ -30,3 +30,17 @@ def test_bench_sharded_path_one_rank(ctx):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["launches"] > 0 and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-4
+
+
+def test_bench_sharded_pagerank_and_cc_legs_one_rank(ctx):
+    """the PageRank (BASELINE configs[3]) and Shiloach-Vishkin (configs[4]) legs of bench.py's multi-GPU branch with one rank at small scales:
+    streaming shard builds (uniform / symmetrised RMAT, outgoing lists only), super-step drivers, result checks and rank-0 rooflines"""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--scale", "15", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-sssp", "--pr-scale", "16", "--cc-scale", "15", "--chunk-edges", str(1 << 18)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    pr, cc = line["pagerank_uniform16_sharded"], line["cc_rmat_symmetrised_sharded"]
+    assert abs(pr["ranks_sum"] - 1.0) < 1e-3 and pr["teps"] > 0 and pr["shard_edges"] == (1 << 16) * 32
+    assert cc["labels_idempotent"] and cc["hook_passes"] >= 1 and cc["shard_edges"] == cc["stored_edges"] == (1 << 15) * 32

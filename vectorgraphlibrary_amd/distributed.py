@@ -173,7 +173,7 @@ class HipShardOps:
 
 
 def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat", renumber="total", chunk_edges=1 << 27,
-                          placement="ranges", piece_edges=1 << 30):
+                          placement="ranges", piece_edges=1 << 30, symmetric=False, with_incoming=True):
     """This rank's edge-cut shard of a synthetic graph that is too large to materialise on one GPU (RMAT-27 over 8 GPUs,
     BASELINE.json configs[2]).  Every rank streams the whole counter-based edge list in chunks twice -- once for the degree
     histograms (renumbering + partition bounds, identical on all ranks), once to keep the edges whose source (outgoing
@@ -185,14 +185,21 @@ def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat
     ranks and the stored numbering is made rank-major, so that every rank owns exactly V/P consecutive stored ids with the
     same mix of hubs and leaves -- rows AND edges are balanced (bottom-up work follows rows, not edges) and bottom-up levels can
     exchange owned bitmap slices (bfs_sharded(equal_ranges=True)).  shard.fwd/bwd map original <-> stored ids either way.
+    symmetric=True: every generated edge is stored in both directions (the undirected input of the cc app, apps/cc/cc.cpp:24-36:
+    2 * E stored edges).  with_incoming=False: only the outgoing CSR is built (push-only algorithms: CC, PageRank's pull over the
+    outgoing lists).
     Returns (shard, out_degrees[V] replicated, bounds)."""
     from .api import Graph
     V, E = 1 << scale, (1 << scale) * edge_factor
 
     def chunk(e0, n):
         if kind == "rmat":
-            return ctx.gen_rmat(scale, edge_factor, seed, first_edge=e0, count=n)
-        return ctx.gen_uniform(scale, edge_factor, seed, first_edge=e0, count=n)
+            s, d = ctx.gen_rmat(scale, edge_factor, seed, first_edge=e0, count=n)
+        else:
+            s, d = ctx.gen_uniform(scale, edge_factor, seed, first_edge=e0, count=n)
+        if symmetric:
+            s, d = torch.cat([s, d]), torch.cat([d, s])
+        return s, d
 
     chunks = [(e0, min(chunk_edges, E - e0)) for e0 in range(0, E, chunk_edges)]
     outdeg = torch.zeros(V, dtype=torch.int32, device=ctx.device)
@@ -234,7 +241,7 @@ def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat
     # row-range pieces of at most `piece_edges` edges each: the generator is streamed once per piece and the piece CSRs are
     # concatenated (rows are independent, so the result is the same CSR).  In-degrees for the incoming direction are counted here.
     indeg_owned = torch.zeros(V, dtype=torch.int32, device=ctx.device)
-    for e0, n in chunks:
+    for e0, n in (chunks if with_incoming else []):
         s, d = chunk(e0, n)
         if fwd is not None:
             s, d = ctx.relabel(fwd, s), ctx.relabel(fwd, d)
@@ -284,7 +291,10 @@ def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat
 
     out_pieces, in_pieces = pieces(outdeg), pieces(indeg_owned)
     del indeg_owned
-    if len(out_pieces) == 1 and len(in_pieces) == 1:             # the usual case: both directions in ONE pass over the generator
+    if not with_incoming:
+        orp, oadj = build("out", out_pieces)
+        irp = iadj = None
+    elif len(out_pieces) == 1 and len(in_pieces) == 1:           # the usual case: both directions in ONE pass over the generator
         keep = {"os": [], "od": [], "is": [], "id": []}
         for e0, n in chunks:
             s, d = chunk(e0, n)
