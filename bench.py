@@ -393,6 +393,9 @@ def main():
     # the CPU baseline's OpenMP runtime reads these when it is first loaded (scripts/helpers.py:147-153)
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
+    if not args.no_cpu_baseline:                        # the CPUs this process may use, counted before any OpenMP runtime binds the main thread to one place
+        from oracle import oracle as O_early
+        os.environ.setdefault("VGL_HOST_CPUS", str(O_early.host_cpus()))
 
     import torch
     import torch.distributed as dist

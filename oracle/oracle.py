@@ -248,6 +248,8 @@ def max_threads():
 def host_cpus():
     """CPUs this process may really use: the affinity mask, cut down by a cgroup CPU quota where one is set (a GPU box shows every
     core of the host but grants a share of them; an OpenMP team of all visible cores is then heavily over-subscribed)."""
+    if os.environ.get("VGL_HOST_CPUS"):             # counted before an OpenMP runtime with OMP_PROC_BIND narrowed this thread's own mask
+        return max(1, int(os.environ["VGL_HOST_CPUS"]))
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
