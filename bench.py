@@ -64,6 +64,16 @@ def timed_kernels(ctx, names):
     return out
 
 
+def cc_hook_pass(ctx):
+    """(launches, total ms, path) of the Shiloach-Vishkin hook passes timed so far: the atomic-min kernel, or gather + accumulate launches"""
+    n, ms = ctx.timing_get("cc_hook")
+    if n:
+        return n, ms, "atomic-min kernel"
+    ng, msg = ctx.timing_get("cc_hook_gather")
+    na, msa = ctx.timing_get("cc_hook_accumulate")
+    return ng, msg + msa, "blocked (LDS windows)"
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # single-GPU legs
 # ------------------------------------------------------------------------------------------------------------------------
@@ -242,12 +252,12 @@ def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
             comp, cst = api.connected_components(cg, raw=True, symmetric=sym)
         torch.cuda.synchronize()
         dtc = (time.perf_counter() - t1) / 3
-        n, ms = ctx.timing_get("cc_hook")
+        n, ms, path = cc_hook_pass(ctx)
         ctx.timing(False)
         res[name] = {"teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "passes": cst["hook_passes"]}
         if n and not sym:
             alg = 8 * cE + 12 * (1 << 24)
-            res[name]["hook_pass"] = {"ms": round(ms / n, 4), "algorithmic_GBps": round(alg / (ms / n * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms / n * 1e-3) / 1e9)}
+            res[name]["hook_pass"] = {"path": path, "ms": round(ms / n, 4), "algorithmic_GBps": round(alg / (ms / n * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms / n * 1e-3) / 1e9)}
     extra["cc_rmat24x16_symmetrised"] = res
     if cpu is not None:
         O, threads = cpu
@@ -335,7 +345,7 @@ def leg_cc_sharded(api, vd, ctx, dist, world, rank, cc_scale, seed, chunk_edges,
         dist.barrier()
     torch.cuda.synchronize()
     dtc = time.perf_counter() - t1
-    n, ms = ctx.timing_get("cc_hook")
+    n, ms, path = cc_hook_pass(ctx)
     ctx.timing(False)
     if world > 1:
         tmax = torch.tensor([dtc], dtype=torch.float64, device=ctx.device)
@@ -346,7 +356,7 @@ def leg_cc_sharded(api, vd, ctx, dist, world, rank, cc_scale, seed, chunk_edges,
     extra["cc_rmat_symmetrised_sharded"] = {
         "scale": cc_scale, "stored_edges": cE, "teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "hook_passes": passes, "shard_edges": int(shard.E),
         "graph_build_s": round(t_build, 2), "exchange": st, "labels_idempotent": ok,
-        "rank0_hook_pass": {"ms": round(ms / max(n, 1), 4), "algorithmic_GBps": round(alg / (ms / max(n, 1) * 1e-3) / 1e9, 1) if ms > 0 else None,
+        "rank0_hook_pass": {"path": path, "ms": round(ms / max(n, 1), 4), "algorithmic_GBps": round(alg / (ms / max(n, 1) * 1e-3) / 1e9, 1) if ms > 0 else None,
                             "frac_of_hbm_peak": frac(alg / (ms / max(n, 1) * 1e-3) / 1e9) if ms > 0 else None}}
     if not ok:
         sys.exit("bench.py: sharded CC labels are not idempotent")

@@ -1068,3 +1068,43 @@ def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, orac
             assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all() and st["push_steps"] == 0
         plan.close()
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef,symmetric", [("rmat", 16, 8, True), ("ru", 17, 2, True), ("rmat", 16, 8, False), ("ru", 15, 1, False)])
+def test_cc_blocked_hook(kind, scale, ef, symmetric, ctx, oracle):
+    """Shiloach-Vishkin with the hook as a blocked pass (vgl_blocked.h, forced on at these sizes): labels equal to the oracle's on symmetric
+    and on directed inputs (min id that reaches each vertex), whole-graph run and three shards driven in lock-step, small units."""
+    import os
+    import torch
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import distributed as vd
+    O = oracle
+    g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, kind, scale, ef, 17, symmetric=symmetric)
+    ref, _ = O.cc_sv(rowptr, adj)
+    for unit in ("", "64"):
+        os.environ["VGL_CC_BLOCKED"] = "1"
+        if unit:
+            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = unit
+        try:
+            g2 = api.Graph(ctx, V, g.out_rowptr, g.out_adj, g.in_rowptr, g.in_adj)
+            comp, st = api.connected_components(g2)
+            assert (comp.cpu().numpy() == ref).all(), (unit, "whole graph")
+            bounds = ctx.partition_rows(g.out_rowptr, 3)
+            shards = [g.shard(bounds[p], bounds[p + 1]) for p in range(3)]
+            comps = torch.arange(V, dtype=torch.int32, device=ctx.device)
+            while True:                                                      # lock-step: every shard hooks its rows into the shared labels
+                changed = 0
+                for s in shards:
+                    changed |= vd.HipShardOps(s).cc_hook(comps)
+                if not changed:
+                    break
+                vd.HipShardOps(shards[0]).cc_jump(comps)
+            assert (comps.cpu().numpy() == ref).all(), (unit, "shards")
+            for s in shards:
+                s.close()
+            g2.close()
+        finally:
+            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT"):
+                os.environ.pop(k, None)
+    g.close()

@@ -104,6 +104,7 @@ struct vgl_hip_graph {
     vgl_hip_graph *transposed = nullptr; // SCC: handle with the two directions swapped (backward reach = BFS on it), lazy, owned
     int64_t *ds_partials = nullptr;
     struct vgl_blocked_plan *blk_pr = nullptr;  // PageRank's blocked pull over the outgoing CSR (lazy, owned; vgl_blocked.h)
+    struct vgl_blocked_plan *blk_cc = nullptr;  // the Shiloach-Vishkin hook as a blocked pass (lazy, owned)
 };
 
 struct vgl_hip_frontier {
