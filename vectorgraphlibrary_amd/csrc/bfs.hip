@@ -438,6 +438,17 @@ constexpr int VGL_BU_BLOCKS = 2048;
 // together (two dependent memory round trips per vertex).  Writes whole words of the next-frontier bitmap.
 typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte load from a 4-byte aligned address
 
+// Two phases per workgroup (counters of the one-phase version, profiles/r02_pmc_bfs.json: 3 M L2 requests and 67 MB per 60 us launch --
+// neither the L2 request rate nor the bandwidth is near its limit -- but the wavefronts wait 80 % of the time: a wavefront-iteration is
+// a chain of up to six dependent loads (candidate words, head record, first probe, probes 2-4, second head record, probes 5-8) and
+// ends when its SLOWEST lane does; with 93 % first-probe hits per candidate almost every wavefront still holds a lane that goes the
+// whole way).
+//   phase A  every candidate does the same thing: head record, first in-neighbour's frontier bit.  No divergence, so VGL_BU_UNROLL
+//            row groups are in flight per thread (their loads are independent).  A candidate that misses and has more in-neighbours
+//            is appended to the workgroup's list.
+//   phase B  the list, densely: one thread per listed row, in-neighbours 2-8 from the head records; rows longer than eight that
+//            still miss stay on the list (compacted in place) for vgl_k_bu_heavy.
+constexpr int VGL_BU_UNROLL = 4;
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
                                                             const int32_t *in_adj, int64_t in_edges, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
@@ -445,62 +456,102 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                                                             int32_t *heavy_off, uint32_t *ticket, const int4 *in_head, const uint64_t *in_long)
 {
     __shared__ int64_t s64[VGL_WAVES];
-    __shared__ int s_nheavy;
-    if (threadIdx.x == 0) s_nheavy = 0;
+    __shared__ int s_nmiss, s_nheavy;
+    if (threadIdx.x == 0) { s_nmiss = 0; s_nheavy = 0; }
     __syncthreads();
+    auto in_front = [&](int32_t u) -> uint32_t { return (uint32_t)((front[u >> 6] >> (u & 63)) & 1ULL); };
     int64_t found_cnt = 0, probes = 0;
     // Rows are dealt to the workgroups in slices of 256 (slice s goes to workgroup s mod VGL_BU_BLOCKS): candidates cluster -- in a
     // degree-sorted graph the unvisited vertices of the later levels are the low-degree tail -- and contiguous chunks left most
-    // workgroups idle while a few did the level.  The deferred list of a workgroup still has room for all of its rows.
+    // workgroups idle while a few did the level.  The list of a workgroup has room for all of its rows.
     const int32_t r_round = (nrows + 63) & ~63;
-    int32_t *my_heavy = heavy + (int64_t)blockIdx.x * chunk;         // at most `chunk` deferrals per workgroup
-    for (int32_t r = (int32_t)blockIdx.x * VGL_BLOCK + threadIdx.x; r < r_round; r += VGL_BU_BLOCKS * VGL_BLOCK) {
-        const int32_t v = row_base + r;
-        const uint64_t cand_word = ~visited[v >> 6] & in_nz[v >> 6];       // wave-uniform
-        bool found = false, defer = false;
-        if (cand_word != 0ULL) {
-            if (r < nrows && ((cand_word >> (v & 63)) & 1ULL)) {
-                // The row's first eight in-neighbours come from two planes of 16-byte head records (coalesced over the wavefront, no
-                // row offsets, no dependent adjacency load): most candidates find their parent among the first four, the rest look
-                // at the next four; a row that still misses and is longer than eight goes to the wavefront pass.
-                const int4 h = in_head[r];
-                const int32_t u0[4] = {h.x, h.y, h.z, h.w};
-                uint32_t hit = 0;
-                int n = 0;
-                // the first in-neighbour alone first: when it is in the frontier (the common case once the frontier is large) the
-                // other three frontier words are never requested -- the kernel is bound by the rate of these scattered requests
-                if (u0[0] >= 0) { n = 1; hit = (uint32_t)((front[u0[0] >> 6] >> (u0[0] & 63)) & 1ULL); }
-                if (hit == 0) {
+    constexpr int32_t STRIDE = VGL_BU_BLOCKS * VGL_BLOCK;
+    int32_t *my_list = heavy + (int64_t)blockIdx.x * chunk;
+    for (int64_t r0 = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; r0 < r_round; r0 += (int64_t)STRIDE * VGL_BU_UNROLL) {
+        bool cand[VGL_BU_UNROLL];
+        int4 h[VGL_BU_UNROLL];
+        uint32_t hit[VGL_BU_UNROLL];
 #pragma unroll
-                    for (int j = 1; j < 4; j++)
-                        if (u0[j] >= 0) { n = j + 1; hit |= (uint32_t)((front[u0[j] >> 6] >> (u0[j] & 63)) & 1ULL) << j; }
-                }
-                bool longer = false;
-                if (hit == 0 && n == 4) {
-                    const int4 k = in_head[(int64_t)nrows + r];
-                    const int32_t u1[4] = {k.x, k.y, k.z, k.w};
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (u1[j] >= 0) { n = 5 + j; hit |= (uint32_t)((front[u1[j] >> 6] >> (u1[j] & 63)) & 1ULL) << (4 + j); }
-                    longer = (in_long[v >> 6] >> (v & 63)) & 1ULL;
-                }
-                found = hit != 0;
-                probes += found ? __ffs(hit) : n;        // adjacency entries a sequential scan would have examined
-                defer = !found && longer;
-                if (found) levels[v] = next_level;
+        for (int k = 0; k < VGL_BU_UNROLL; k++) {
+            const int64_t r = r0 + (int64_t)k * STRIDE;
+            cand[k] = false;
+            if (r < r_round) {
+                const int32_t v = row_base + (int32_t)r;
+                const uint64_t cw = ~visited[v >> 6] & in_nz[v >> 6];       // wave-uniform
+                cand[k] = r < nrows && ((cw >> (v & 63)) & 1ULL);
             }
         }
-        const unsigned long long fm = __ballot(found);
-        if (vgl_lane() == 0) next[v >> 6] = fm;
-        found_cnt += found;
+#pragma unroll
+        for (int k = 0; k < VGL_BU_UNROLL; k++) {
+            h[k] = make_int4(-1, -1, -1, -1);
+            if (cand[k]) h[k] = in_head[r0 + (int64_t)k * STRIDE];
+        }
+#pragma unroll
+        for (int k = 0; k < VGL_BU_UNROLL; k++) hit[k] = (cand[k] && h[k].x >= 0) ? in_front(h[k].x) : 0u;
+#pragma unroll
+        for (int k = 0; k < VGL_BU_UNROLL; k++) {
+            const int64_t r = r0 + (int64_t)k * STRIDE;
+            if (r >= r_round) continue;                                    // (uniform over the wavefront: r_round is a multiple of 64)
+            const int32_t v = row_base + (int32_t)r;
+            const bool found = hit[k] != 0;
+            const bool miss = cand[k] && !found && h[k].y >= 0;            // more in-neighbours to look at
+            if (found) levels[v] = next_level;
+            if (cand[k] && h[k].x >= 0 && (found || !miss)) probes += 1;    // rows that go on are charged in phase B
+            const unsigned long long fm = __ballot(found);
+            if (vgl_lane() == 0) next[v >> 6] = fm;
+            found_cnt += found;
+            const unsigned long long mm = __ballot(miss);
+            if (mm) {                               // wave-aggregated append to this workgroup's list (LDS counter)
+                int base = 0;
+                if (vgl_lane() == 0) base = atomicAdd(&s_nmiss, (int)__popcll(mm));
+                base = __shfl(base, 0);
+                if (miss) my_list[base + __popcll(mm & ((1ULL << vgl_lane()) - 1ULL))] = (int32_t)r;
+            }
+        }
+    }
+    __syncthreads();                                // the list is complete, the words of `next` this workgroup wrote have left (vmcnt 0)
+    const int nmiss = s_nmiss;
+    for (int i0 = 0; i0 < nmiss; i0 += VGL_BLOCK) {
+        const int i = i0 + threadIdx.x;
+        const int32_t r = i < nmiss ? my_list[i] : -1;
+        __syncthreads();                            // every entry of this round is in a register: slots below i0 + VGL_BLOCK may be overwritten
+        bool found = false, defer = false;
+        if (r >= 0) {
+            const int32_t v = row_base + r;
+            const int4 a = in_head[r];
+            const int32_t u0[4] = {a.x, a.y, a.z, a.w};
+            uint32_t hitm = 0;
+            int n = 1;
+#pragma unroll
+            for (int j = 1; j < 4; j++)
+                if (u0[j] >= 0) { n = j + 1; hitm |= in_front(u0[j]) << j; }
+            bool longer = false;
+            if (hitm == 0 && n == 4) {
+                const int4 k4 = in_head[(int64_t)nrows + r];
+                const int32_t u1[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (u1[j] >= 0) { n = 5 + j; hitm |= in_front(u1[j]) << (4 + j); }
+                longer = (in_long[v >> 6] >> (v & 63)) & 1ULL;
+            }
+            found = hitm != 0;
+            probes += found ? __ffs(hitm) : n;       // adjacency entries a sequential scan would have examined (the first one included)
+            defer = !found && longer;
+            if (found) {
+                levels[v] = next_level;
+                atomicOr((unsigned long long *)&next[v >> 6], 1ULL << (v & 63));
+                found_cnt++;
+            }
+        }
         const unsigned long long dm = __ballot(defer);
-        if (dm) {                                   // wave-aggregated append to this workgroup's segment (LDS counter)
+        if (dm) {
             int base = 0;
             if (vgl_lane() == 0) base = atomicAdd(&s_nheavy, (int)__popcll(dm));
             base = __shfl(base, 0);
-            if (defer) my_heavy[base + __popcll(dm & ((1ULL << vgl_lane()) - 1ULL))] = r;
+            if (defer) my_list[base + __popcll(dm & ((1ULL << vgl_lane()) - 1ULL))] = r;
         }
     }
+    __syncthreads();
     found_cnt = vgl_block_reduce_add(found_cnt, s64);
     probes = vgl_block_reduce_add(probes, s64);
     uint32_t dep = 0;
