@@ -1,7 +1,7 @@
 #!/bin/bash
 # BFS on RMAT-24 under the bottom-up probe variants (env switches read by bfs.hip); prints value / ms_per_step / probe time per launch
 cd "$(dirname "$0")/../.."
-for v in "0 0" "1 0" "0 1" "1 1"; do
+for v in "0 0"; do
     set -- $v
     VGL_BFS_PROBE_NT=$1 VGL_BFS_PROBE_LDS=$2 python3 bench.py --no-cpu-baseline --no-sssp --no-pr-cc 2>/dev/null | python3 -c "
 import json,sys

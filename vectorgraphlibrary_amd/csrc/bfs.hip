@@ -438,17 +438,13 @@ constexpr int VGL_BU_BLOCKS = 2048;
 // together (two dependent memory round trips per vertex).  Writes whole words of the next-frontier bitmap.
 typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte load from a 4-byte aligned address
 
-// Two phases per workgroup (counters of the one-phase version, profiles/r02_pmc_bfs.json: 3 M L2 requests and 67 MB per 60 us launch --
-// neither the L2 request rate nor the bandwidth is near its limit -- but the wavefronts wait 80 % of the time: a wavefront-iteration is
-// a chain of up to six dependent loads (candidate words, head record, first probe, probes 2-4, second head record, probes 5-8) and
-// ends when its SLOWEST lane does; with 93 % first-probe hits per candidate almost every wavefront still holds a lane that goes the
-// whole way).
-//   phase A  every candidate does the same thing: head record, first in-neighbour's frontier bit.  No divergence, so VGL_BU_UNROLL
-//            row groups are in flight per thread (their loads are independent).  A candidate that misses and has more in-neighbours
-//            is appended to the workgroup's list.
-//   phase B  the list, densely: one thread per listed row, in-neighbours 2-8 from the head records; rows longer than eight that
-//            still miss stay on the list (compacted in place) for vgl_k_bu_heavy.
-constexpr int VGL_BU_UNROLL = 4;
+// Counters of this kernel before the candidate words were fetched 64 at a time (profiles/r02_pmc_bfs.json, per 60 us launch): 3 M L2
+// requests and 67 MB fetched -- neither the L2 request rate (~2e11 /s) nor the bandwidth is near its limit; the wavefronts were parked
+// on memory 77 % of their cycles.  Tried on top of that and dropped (no gain): non-temporal loads for the once-read streams (the hot
+// frontier words are not being evicted from L1), the first 2048 words of the frontier bitmap in LDS (16 KiB per workgroup: 61.9 vs
+// 62.5 us; 4096 words halve the occupancy: 94 us -- the kernel's rate follows the number of resident wavefronts), a two-phase form
+// (uniform first probe for all candidates with four row groups in flight, misses compacted and probed densely: 78 us), requesting
+// the next group's head records ahead.
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
                                                             const int32_t *in_adj, int64_t in_edges, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
@@ -456,102 +452,80 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                                                             int32_t *heavy_off, uint32_t *ticket, const int4 *in_head, const uint64_t *in_long)
 {
     __shared__ int64_t s64[VGL_WAVES];
-    __shared__ int s_nmiss, s_nheavy;
-    if (threadIdx.x == 0) { s_nmiss = 0; s_nheavy = 0; }
+    __shared__ int s_nheavy;
+    if (threadIdx.x == 0) s_nheavy = 0;
     __syncthreads();
     auto in_front = [&](int32_t u) -> uint32_t { return (uint32_t)((front[u >> 6] >> (u & 63)) & 1ULL); };
     int64_t found_cnt = 0, probes = 0;
-    // Rows are dealt to the workgroups in slices of 256 (slice s goes to workgroup s mod VGL_BU_BLOCKS): candidates cluster -- in a
-    // degree-sorted graph the unvisited vertices of the later levels are the low-degree tail -- and contiguous chunks left most
-    // workgroups idle while a few did the level.  The list of a workgroup has room for all of its rows.
-    const int32_t r_round = (nrows + 63) & ~63;
-    constexpr int32_t STRIDE = VGL_BU_BLOCKS * VGL_BLOCK;
-    int32_t *my_list = heavy + (int64_t)blockIdx.x * chunk;
-    for (int64_t r0 = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; r0 < r_round; r0 += (int64_t)STRIDE * VGL_BU_UNROLL) {
-        bool cand[VGL_BU_UNROLL];
-        int4 h[VGL_BU_UNROLL];
-        uint32_t hit[VGL_BU_UNROLL];
-#pragma unroll
-        for (int k = 0; k < VGL_BU_UNROLL; k++) {
-            const int64_t r = r0 + (int64_t)k * STRIDE;
-            cand[k] = false;
-            if (r < r_round) {
-                const int32_t v = row_base + (int32_t)r;
-                const uint64_t cw = ~visited[v >> 6] & in_nz[v >> 6];       // wave-uniform
-                cand[k] = r < nrows && ((cw >> (v & 63)) & 1ULL);
-            }
+    // The 64-row groups are dealt round-robin to the wavefronts of the grid (candidates cluster -- in a degree-sorted graph the unvisited
+    // vertices of the later levels are the low-degree tail -- so contiguous chunks would leave most workgroups idle), and a wavefront
+    // fetches the candidate words of 64 of its groups with ONE load per lane, then walks the groups that hold candidates.  (One group
+    // per iteration with its own candidate-word load was a chain of 32 dependent L2 round trips per thread: 31 us per launch even
+    // for a level with no candidates at all -- the last bottom-up level of every traversal -- and three round trips per group otherwise.)
+    const int64_t groups = ((int64_t)nrows + 63) >> 6;
+    const int64_t word0 = (int64_t)row_base >> 6;                       // row_base is a multiple of 64 (shards own whole bitmap words)
+    constexpr int64_t NW = (int64_t)VGL_BU_BLOCKS * VGL_WAVES;
+    int32_t *my_heavy = heavy + (int64_t)blockIdx.x * chunk;            // at most `chunk` deferrals per workgroup
+    const int lane = vgl_lane();
+    for (int64_t g0 = (int64_t)blockIdx.x * VGL_WAVES + vgl_wave(); g0 < groups; g0 += NW * 64) {
+        const int64_t mine = g0 + (int64_t)lane * NW;                   // lane l holds the candidate word of group g0 + l * NW
+        uint64_t cw = 0;
+        if (mine < groups) {
+            cw = ~visited[word0 + mine] & in_nz[word0 + mine];
+            if (cw == 0ULL) next[word0 + mine] = 0ULL;                  // nothing to find here
         }
-#pragma unroll
-        for (int k = 0; k < VGL_BU_UNROLL; k++) {
-            h[k] = make_int4(-1, -1, -1, -1);
-            if (cand[k]) h[k] = in_head[r0 + (int64_t)k * STRIDE];
-        }
-#pragma unroll
-        for (int k = 0; k < VGL_BU_UNROLL; k++) hit[k] = (cand[k] && h[k].x >= 0) ? in_front(h[k].x) : 0u;
-#pragma unroll
-        for (int k = 0; k < VGL_BU_UNROLL; k++) {
-            const int64_t r = r0 + (int64_t)k * STRIDE;
-            if (r >= r_round) continue;                                    // (uniform over the wavefront: r_round is a multiple of 64)
-            const int32_t v = row_base + (int32_t)r;
-            const bool found = hit[k] != 0;
-            const bool miss = cand[k] && !found && h[k].y >= 0;            // more in-neighbours to look at
-            if (found) levels[v] = next_level;
-            if (cand[k] && h[k].x >= 0 && (found || !miss)) probes += 1;    // rows that go on are charged in phase B
-            const unsigned long long fm = __ballot(found);
-            if (vgl_lane() == 0) next[v >> 6] = fm;
-            found_cnt += found;
-            const unsigned long long mm = __ballot(miss);
-            if (mm) {                               // wave-aggregated append to this workgroup's list (LDS counter)
-                int base = 0;
-                if (vgl_lane() == 0) base = atomicAdd(&s_nmiss, (int)__popcll(mm));
-                base = __shfl(base, 0);
-                if (miss) my_list[base + __popcll(mm & ((1ULL << vgl_lane()) - 1ULL))] = (int32_t)r;
-            }
-        }
-    }
-    __syncthreads();                                // the list is complete, the words of `next` this workgroup wrote have left (vmcnt 0)
-    const int nmiss = s_nmiss;
-    for (int i0 = 0; i0 < nmiss; i0 += VGL_BLOCK) {
-        const int i = i0 + threadIdx.x;
-        const int32_t r = i < nmiss ? my_list[i] : -1;
-        __syncthreads();                            // every entry of this round is in a register: slots below i0 + VGL_BLOCK may be overwritten
-        bool found = false, defer = false;
-        if (r >= 0) {
+        unsigned long long todo = __ballot(cw != 0ULL);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint64_t cand_word = __shfl(cw, j);
+            const int64_t grp = g0 + (int64_t)j * NW;
+            const int32_t r = (int32_t)(grp << 6) + lane;
             const int32_t v = row_base + r;
-            const int4 a = in_head[r];
-            const int32_t u0[4] = {a.x, a.y, a.z, a.w};
-            uint32_t hitm = 0;
-            int n = 1;
+            bool found = false, defer = false;
+            if (r < nrows && ((cand_word >> lane) & 1ULL)) {
+                // The row's first eight in-neighbours come from two planes of 16-byte head records (coalesced over the wavefront, no
+                // row offsets, no dependent adjacency load): most candidates find their parent among the first four, the rest look
+                // at the next four; a row that still misses and is longer than eight goes to the wavefront pass.  (Requesting the next
+                // group's records before waiting for this group's probes was tried: no change.)
+                const int4 h = in_head[r];
+                const int32_t u0[4] = {h.x, h.y, h.z, h.w};
+                uint32_t hit = 0;
+                int n = 0;
+                // the first in-neighbour alone first: when it is in the frontier (the common case once the frontier is large) the
+                // other three frontier words are never requested
+                if (u0[0] >= 0) { n = 1; hit = in_front(u0[0]); }
+                if (hit == 0) {
 #pragma unroll
-            for (int j = 1; j < 4; j++)
-                if (u0[j] >= 0) { n = j + 1; hitm |= in_front(u0[j]) << j; }
-            bool longer = false;
-            if (hitm == 0 && n == 4) {
-                const int4 k4 = in_head[(int64_t)nrows + r];
-                const int32_t u1[4] = {k4.x, k4.y, k4.z, k4.w};
+                    for (int q = 1; q < 4; q++)
+                        if (u0[q] >= 0) { n = q + 1; hit |= in_front(u0[q]) << q; }
+                }
+                bool longer = false;
+                if (hit == 0 && n == 4) {
+                    const int4 k = in_head[(int64_t)nrows + r];
+                    const int32_t u1[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (u1[j] >= 0) { n = 5 + j; hitm |= in_front(u1[j]) << (4 + j); }
-                longer = (in_long[v >> 6] >> (v & 63)) & 1ULL;
+                    for (int q = 0; q < 4; q++)
+                        if (u1[q] >= 0) { n = 5 + q; hit |= in_front(u1[q]) << (4 + q); }
+                    longer = (in_long[v >> 6] >> (v & 63)) & 1ULL;
+                }
+                found = hit != 0;
+                probes += found ? __ffs(hit) : n;        // adjacency entries a sequential scan would have examined
+                defer = !found && longer;
+                if (found) levels[v] = next_level;
             }
-            found = hitm != 0;
-            probes += found ? __ffs(hitm) : n;       // adjacency entries a sequential scan would have examined (the first one included)
-            defer = !found && longer;
-            if (found) {
-                levels[v] = next_level;
-                atomicOr((unsigned long long *)&next[v >> 6], 1ULL << (v & 63));
-                found_cnt++;
+            const unsigned long long fm = __ballot(found);
+            if (lane == 0) next[word0 + grp] = fm;
+            found_cnt += found;
+            const unsigned long long dm = __ballot(defer);
+            if (dm) {                                   // wave-aggregated append to this workgroup's segment (LDS counter)
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nheavy, (int)__popcll(dm));
+                base = __shfl(base, 0);
+                if (defer) my_heavy[base + __popcll(dm & ((1ULL << lane) - 1ULL))] = r;
             }
-        }
-        const unsigned long long dm = __ballot(defer);
-        if (dm) {
-            int base = 0;
-            if (vgl_lane() == 0) base = atomicAdd(&s_nheavy, (int)__popcll(dm));
-            base = __shfl(base, 0);
-            if (defer) my_list[base + __popcll(dm & ((1ULL << vgl_lane()) - 1ULL))] = r;
         }
     }
-    __syncthreads();
     found_cnt = vgl_block_reduce_add(found_cnt, s64);
     probes = vgl_block_reduce_add(probes, s64);
     uint32_t dep = 0;
@@ -585,9 +559,13 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, in
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s_off[VGL_BU_BLOCKS + 1];
-    for (int i = threadIdx.x; i <= VGL_BU_BLOCKS; i += VGL_BLOCK) s_off[i] = heavy_off[i];
+    // most levels defer a few hundred rows or none: only the workgroups that will scan rows stage the 8 KiB offset table (every one of
+    // the 2048 doing it made an empty pass cost 11 us)
+    const int total = heavy_off[VGL_BU_BLOCKS];
+    if ((int64_t)blockIdx.x * VGL_WAVES * (64 / VGL_BU_HEAVY_LANES) < total) {
+        for (int i = threadIdx.x; i <= VGL_BU_BLOCKS; i += VGL_BLOCK) s_off[i] = heavy_off[i];
+    }
     __syncthreads();
-    const int total = s_off[VGL_BU_BLOCKS];
     int64_t found_cnt = 0, probes = 0;
     // Four deferred vertices per wavefront, 16 lanes each: most deferred rows have a few dozen entries left, a whole wavefront per
     // row left three quarters of the lanes idle.  A quarter scans 16 entries per step and stops at its first hit; the wavefront
