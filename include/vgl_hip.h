@@ -331,6 +331,9 @@ int vgl_hip_indegree_noloops_add(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_
 /* ---- kernel timing hooks for bench.py's roofline line: when enabled every launch of the named dominant kernels
  *      is bracketed by hipEvents on the context stream; totals are read back afterwards. ---- */
 int vgl_hip_timing_enable(vgl_hip_ctx *ctx, int enable);
+/* restrict the bracketing to ONE kernel name (NULL or "" = all): two event records cost ~4-5 us of stream time per launch, which is
+ * 10 % of a BFS traversal when every kernel is bracketed -- the timed region of bench.py brackets only the kernel it reports */
+int vgl_hip_timing_only(vgl_hip_ctx *ctx, const char *kernel_name);
 int vgl_hip_timing_reset(vgl_hip_ctx *ctx);
 /* kernel_name: "bfs_bottom_up", "bfs_top_down", "gnf", "sssp_relax", "pr_pull", "cc_hook"; returns launches and total ms */
 int vgl_hip_timing_get(vgl_hip_ctx *ctx, const char *kernel_name, int64_t *launches, double *total_ms);

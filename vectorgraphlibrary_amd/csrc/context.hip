@@ -111,6 +111,12 @@ int vgl_hip_timing_enable(vgl_hip_ctx *c, int enable)
     c->timing = enable != 0;
     return 0;
 }
+int vgl_hip_timing_only(vgl_hip_ctx *c, const char *kernel_name)
+{
+    if (!c) VGL_FAIL("null context");
+    c->timing_only = kernel_name ? kernel_name : "";
+    return 0;
+}
 int vgl_hip_timing_reset(vgl_hip_ctx *c)
 {
     if (!c) VGL_FAIL("null context");
@@ -156,6 +162,7 @@ static hipEvent_t vgl_get_event(vgl_hip_ctx *c)
 vgl_timed_launch::vgl_timed_launch(vgl_hip_ctx *c, const char *name) : ctx(c), slot(nullptr), a(nullptr), b(nullptr)
 {
     if (!c->timing) return;
+    if (!c->timing_only.empty() && c->timing_only != name) return;      // only the named kernel pays for its two event records
     slot = &c->slots[name];
     a = vgl_get_event(c);
     b = vgl_get_event(c);

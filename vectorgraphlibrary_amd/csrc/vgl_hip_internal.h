@@ -54,6 +54,7 @@ struct vgl_hip_ctx {
     double *d_partials = nullptr;    // reduction partials (f64), capacity partials_cap
     size_t partials_cap = 0;
     bool timing = false;
+    std::string timing_only;          // when not empty: only launches under this name are bracketed by events
     std::map<std::string, vgl_timing_slot> slots;
     std::vector<hipEvent_t> event_pool;
 };

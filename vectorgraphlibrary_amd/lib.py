@@ -122,6 +122,7 @@ _SIGNATURES = {
     "vgl_hip_diff_to_pairs_u32": [_p, _i32, _p, _p, _i32, _p],
     "vgl_hip_apply_pairs_u32": [_p, _int, _i64, _int, _p, _int, _i32, _p, C.POINTER(_int)],
     "vgl_hip_timing_enable": [_p, _int],
+    "vgl_hip_timing_only": [_p, C.c_char_p],
     "vgl_hip_timing_reset": [_p],
     "vgl_hip_timing_get": [_p, C.c_char_p, C.POINTER(_i64), C.POINTER(_dbl)],
 }
