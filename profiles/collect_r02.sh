@@ -29,6 +29,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCES
     rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_r24_$i -- python3 profiles/microbench/blocked_bench.py rmat 24 > $OUT/pmc_r24_$i.log 2>&1
     echo "pmc blocked $i done ($set)" >> $OUT/progress.txt
 done
+# 4. the 8-rank lock-step rehearsal of the RMAT-27 weak-scaling traversal on this one GPU (levels kept per owner)
+python3 profiles/microbench/emulate_weak.py 27 8 dealt v owned > $OUT/emulate_weak_s27_p8_owned.log 2>&1
+echo "rehearsal done" >> $OUT/progress.txt
 # keep what is small: stats tables and per-kernel counter sums
 python3 profiles/pmc_reduce.py $OUT > $OUT/summary.log 2>&1
 find $OUT -name "*_kernel_trace.csv" -size +2M -delete
