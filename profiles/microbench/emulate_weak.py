@@ -45,7 +45,7 @@ def run(source, direction_opt):
             if not bottom_up:
                 if F > prevF and M >= ((V - visited_total) * factor + V) // vd.ALPHA:
                     bottom_up = True
-            elif F < prevF and F < ((V - visited_total) * factor + V) // (factor * vd.BETA):
+            elif F <= prevF and F < ((V - visited_total) * factor + V) // (factor * vd.BETA):
                 bottom_up = False
         prevF = F
         tstep, tbm, tap = [], [], []

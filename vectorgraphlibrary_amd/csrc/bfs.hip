@@ -958,7 +958,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         if (mode == VGL_HIP_BFS_DIRECTION_OPT) {
             if (!bottom_up) {
                 if (F > prevF && M >= ((V - visited_total) * factor + V) / VGL_DO_ALPHA) bottom_up = true;
-            } else if (F < prevF && F < ((V - visited_total) * factor + V) / (factor * VGL_DO_BETA)) {
+            } else if (F <= prevF && F < ((V - visited_total) * factor + V) / (factor * VGL_DO_BETA)) {      // "shrinking phase" = not growing (change_state.hpp:106,121)
                 bottom_up = false;
                 if (small_m > 0 && F <= bm_expand_f) {
                     // a modest frontier of short rows: expand it from the bitmap and let the list kernel run whatever follows -- no

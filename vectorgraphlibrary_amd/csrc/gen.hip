@@ -213,6 +213,12 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
     int32_t *keys = nullptr, *keys_sorted = nullptr;
     void *temp = nullptr;
     size_t temp_bytes = 0, need = 0;
+    // whatever is still allocated when the function leaves -- normally or through VGL_HIP_TRY on a failed allocation -- is freed (an
+    // out-of-memory in the middle of a scale-27 shard build must not leak the multi-GB temporaries of the piece before it)
+    struct cleanup {
+        int64_t *&a, *&b, *&c; int32_t *&d, *&e; void *&f;
+        ~cleanup() { for (void *p : {(void *)a, (void *)b, (void *)c, (void *)d, (void *)e, f}) if (p) hipFree(p); }
+    } guard{kept_idx, sorted_idx, d_nkept, keys, keys_sorted, temp};
     VGL_HIP_TRY(hipMalloc((void **)&kept_idx, sizeof(int64_t) * (size_t)count));
     VGL_HIP_TRY(hipMalloc((void **)&d_nkept, sizeof(int64_t)));
     rocprim::counting_iterator<int64_t> iota(0);
@@ -238,7 +244,7 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
         while (bits < 31 && (1LL << bits) < (int64_t)nrows) bits++;
         need = 0;
         VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys_sorted, kept_idx, sorted_idx, (size_t)nkept, 0, bits, st));
-        if (need > temp_bytes) { VGL_HIP_TRY(hipFree(temp)); temp_bytes = need; VGL_HIP_TRY(hipMalloc(&temp, temp_bytes)); }
+        if (need > temp_bytes) { VGL_HIP_TRY(hipFree(temp)); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(hipMalloc(&temp, temp_bytes)); }
         VGL_HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys, keys_sorted, kept_idx, sorted_idx, (size_t)nkept, 0, bits, st));
         // 4. adjacency + optional permutation
         hipLaunchKernelGGL(vgl_k_gather<int32_t>, dim3(vgl_grid_for(nkept)), dim3(VGL_BLOCK), 0, st, nkept, sorted_idx, d_dst, d_adj);
@@ -247,14 +253,10 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
         // 5. row offsets: inclusive scan of the histogram stored at rowptr[1..nrows]
         need = 0;
         VGL_HIP_TRY(rocprim::inclusive_scan(nullptr, need, d_rowptr + 1, d_rowptr + 1, (size_t)nrows, rocprim::plus<int64_t>(), st));
-        if (need > temp_bytes) { VGL_HIP_TRY(hipFree(temp)); temp_bytes = need; VGL_HIP_TRY(hipMalloc(&temp, temp_bytes)); }
+        if (need > temp_bytes) { VGL_HIP_TRY(hipFree(temp)); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(hipMalloc(&temp, temp_bytes)); }
         VGL_HIP_TRY(rocprim::inclusive_scan(temp, need, d_rowptr + 1, d_rowptr + 1, (size_t)nrows, rocprim::plus<int64_t>(), st));
     }
     VGL_HIP_TRY(hipStreamSynchronize(st));
-    hipFree(temp); hipFree(kept_idx); hipFree(d_nkept);
-    if (keys) hipFree(keys);
-    if (keys_sorted) hipFree(keys_sorted);
-    if (sorted_idx) hipFree(sorted_idx);
     return 0;
 }
 
@@ -289,6 +291,10 @@ int vgl_hip_degree_order_from_degrees(vgl_hip_ctx *c, int32_t V, const uint32_t 
     int32_t *ids = nullptr;
     void *temp = nullptr;
     size_t need = 0;
+    struct cleanup {
+        uint32_t *&a, *&b; int32_t *&c; void *&d;
+        ~cleanup() { for (void *p : {(void *)a, (void *)b, (void *)c, d}) if (p) hipFree(p); }
+    } guard{keys, keys_out, ids, temp};
     VGL_HIP_TRY(hipMalloc((void **)&keys, sizeof(uint32_t) * (size_t)V));
     VGL_HIP_TRY(hipMalloc((void **)&keys_out, sizeof(uint32_t) * (size_t)V));
     VGL_HIP_TRY(hipMalloc((void **)&ids, sizeof(int32_t) * (size_t)V));
@@ -300,7 +306,6 @@ int vgl_hip_degree_order_from_degrees(vgl_hip_ctx *c, int32_t V, const uint32_t 
     hipLaunchKernelGGL(vgl_k_invert, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, st, V, d_bwd, d_fwd);
     VGL_HIP_TRY(hipGetLastError());
     VGL_HIP_TRY(hipStreamSynchronize(st));
-    hipFree(temp); hipFree(keys); hipFree(keys_out); hipFree(ids);
     return 0;
 }
 

@@ -183,6 +183,8 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     if (out_edges < 0 || in_edges < 0) VGL_FAIL("graph_create: negative edge count");
     VGL_HIP_TRY(hipSetDevice(c->device));
     vgl_hip_graph *g = new vgl_hip_graph();
+    // a failure below (an allocation, a launch) must not leave the half-built handle and its device arrays behind
+    struct rollback { vgl_hip_ctx *c; vgl_hip_graph *g; ~rollback() { if (g) vgl_hip_graph_destroy(c, g); } } undo{c, g};
     g->V = V; g->row_begin = row_begin; g->row_end = row_end; g->nrows = row_end - row_begin;
     g->out.rowptr = d_out_rowptr; g->out.adj = d_out_adj; g->out.edges = out_edges;
     VGL_TRY(vgl_build_tile_rows(c, g->out, g->nrows));
@@ -229,6 +231,7 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
         VGL_HIP_TRY(hipGetLastError());
     }
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    undo.g = nullptr;
     *out = g;
     return 0;
 }

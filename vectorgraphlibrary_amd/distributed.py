@@ -389,7 +389,7 @@ def bfs_sharded(ops, source, group=None, degrees=None, edges=None, equal_ranges=
             if not bottom_up:
                 if F > prevF and M >= ((V - visited_total) * factor + V) // ALPHA:
                     bottom_up = True
-            elif F < prevF and F < ((V - visited_total) * factor + V) // (factor * BETA):
+            elif F <= prevF and F < ((V - visited_total) * factor + V) // (factor * BETA):
                 bottom_up = False
         prevF = F
         parts, bits = P, everyone
