@@ -1108,3 +1108,49 @@ def test_cc_blocked_hook(kind, scale, ef, symmetric, ctx, oracle):
             for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT"):
                 os.environ.pop(k, None)
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_graphs_blocked_paths(seed, ctx, oracle):
+    """differential sweep of the blocked advance (vgl_blocked.h) over random graphs of awkward shapes -- V below, at and above one
+    32768-vertex block and not a multiple of anything, empty graphs, isolated vertices, self loops, duplicates, hub rows -- with the
+    default and with tiny work units (every block cut in many units: slabs, global-atomic folds): SSSP / SSWP pull and
+    direction-optimising, Shiloach-Vishkin with the blocked hook, PageRank with exact sums, all against the oracle"""
+    import os
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    rng = np.random.default_rng(7000 + seed)
+    V = int(rng.choice([1, 63, 4097, 32767, 32768, 32769, 50001, 70000, 98305, 140001][seed % 10: seed % 10 + 1])[0])
+    E = int(rng.integers(0, 6 * V + 1)) if seed % 6 else 0
+    src = np.minimum((rng.random(E) ** (1 + seed % 3) * V).astype(np.int32), V - 1)
+    dst = np.minimum((rng.random(E) ** (1 + (seed // 3) % 3) * V).astype(np.int32), V - 1)
+    rowptr, adj, perm = O.coo_to_csr(V, src, dst)
+    w_in = (rng.random(E) * 100).astype(np.float32)
+    w = w_in[perm] if E else np.zeros(0, np.float32)
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device) if len(a) else torch.zeros(0, dtype=dt, device=ctx.device)
+    source = int(rng.integers(0, V))
+    ref_dist, _ = O.sssp_bellman_ford(rowptr, adj, w, source)
+    ref_width, _ = O.sswp_bellman_ford(rowptr, adj, w, source)
+    ref_comp = O.cc_sv(rowptr, adj)[0]
+    ref_pr = pagerank_exact_sums(O, rowptr, adj, 3)
+    for unit in ("", "64"):
+        os.environ["VGL_CC_BLOCKED"] = "1"
+        if unit:
+            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = unit
+        try:
+            g = api.Graph.from_coo(ctx, V, dev(src, torch.int32), dev(dst, torch.int32), want_perm=True)
+            w_d = ctx.gather_u32(g.perm, dev(w_in, torch.float32)) if E else torch.zeros(1, dtype=torch.float32, device=ctx.device)
+            for mode in (api.SSSP_PULL, api.SSSP_DIRECTION_OPT):
+                d, st = api.sssp(g, w_d, source, mode)
+                assert (d.cpu().numpy().view(np.int32) == ref_dist.view(np.int32)).all(), (unit, mode)
+                wd, _ = api.sswp(g, w_d, source, mode)
+                assert (wd.cpu().numpy().view(np.int32) == ref_width.view(np.int32)).all(), (unit, mode)
+            assert (api.connected_components(g)[0].cpu().numpy() == ref_comp).all(), unit
+            rk = api.page_rank(g, 3, mode=api.PR_BLOCKED)[0].cpu().numpy()
+            assert relerr(rk, ref_pr) <= 3e-7, (unit, relerr(rk, ref_pr))
+            g.close()
+        finally:
+            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT"):
+                os.environ.pop(k, None)
