@@ -56,10 +56,12 @@ if kind == "rmat":
     print(f"SSSP pull plan build {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
     ref = None
     for name, kw in (("push all-active", dict(mode=api.SSSP_ALL_ACTIVE)), ("push active tiles", dict(mode=api.SSSP_ACTIVE_TILES)),
-                     ("pull (blocked)", dict(mode=api.SSSP_PULL, plan=plan)), ("direction-opt 0.35", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan)),
+                     ("pull (blocked)", dict(mode=api.SSSP_PULL, plan=plan)), ("direction-opt default", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan)),
                      ("direction-opt 0.2", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.2")),
-                     ("direction-opt 0.5", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.5")),
-                     ("direction-opt 0.7", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.7"))):
+                     ("direction-opt 0.35", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.35")),
+                     ("direction-opt 0.65", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.65")),
+                     ("direction-opt 0.8", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="0.8")),
+                     ("push only (share 2)", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan, share="2"))):
         share = kw.pop("share", None)
         if share:
             os.environ["VGL_SSSP_PULL_SHARE"] = share

@@ -17,6 +17,7 @@
 // are non-negative too, so the integer atomic-max on the f32 bits is exact; only min / max of inputs occur (no rounding).
 #include "vgl_hip_internal.h"
 #include "vgl_blocked.h"
+#include "vgl_gnf.h"
 #include <cfloat>
 #include <cstdlib>
 #include <string>
@@ -155,9 +156,10 @@ static int vgl_sssp_launch(vgl_hip_ctx *c, vgl_hip_graph *g, const float *w, flo
 // is read from a 128 KiB LDS window, dist[src] (+) w travels to the destination's block, where the minimum is an LDS integer
 // atomic; one plain compare + store per vertex ends the step (blocks cut into several units: one global atomic per improved
 // vertex and unit).  No random L2 line per edge and no global atomics per edge.  A pull step sees the distances as they were
-// when it started (Jacobi), so it moves information one hop per step; the push kernel above (asynchronous, work proportional to
-// the rows that changed) is better when few rows changed.  DIRECTION_OPT switches between the two per super-step on the share
-// of the edges whose source changed in the step before -- the fixed point, hence every bit of the result, is the same.
+// when it started (Jacobi), so it moves information one hop per step; a push over the compacted frontier of the rows that changed
+// (vgl_k_sssp_relax_sparse: asynchronous, work proportional to their edges) is better when few rows changed.  DIRECTION_OPT switches
+// between the two per super-step on the share of the edges whose source changed in the step before -- the fixed point, hence every
+// bit of the result, is the same.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <class Path>
 struct vgl_path_blk_op {
@@ -195,20 +197,60 @@ struct vgl_path_blk_op {
     }
 };
 
-// rows that changed in super-step `iter` and the number of their outgoing edges (what the next push step would relax)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_active_count(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *epoch,
-                                                                     int32_t iter, int64_t *counters)
+// tile_first[t] = frontier position whose edge range contains edge t * VGL_TILE (defined in bfs.hip, shared by the sparse advances)
+__global__ void vgl_k_tile_first(int32_t F, const int64_t *offs, int32_t *tile_first);
+
+// Push over a compacted frontier (the rows whose value changed in the step before: ids + exclusive edge offsets from the GNF),
+// edge-balanced like vgl_k_td_expand: workgroup = 2048 consecutive frontier edges.  Work is proportional to the frontier's edges;
+// the tile-filtered kernel above still walks every tile's row epochs (>= 0.7 ms per step on RMAT-24 however little changed).
+template <class Path>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax_sparse(const int32_t *ids, const int64_t *offs, const int32_t *tile_first, int32_t F, int64_t M,
+                                                                     const int64_t *rowptr, const int32_t *adj, const float *w, int32_t row_base,
+                                                                     float *dist, int32_t *epoch, int32_t iter)
 {
-    __shared__ unsigned long long s[VGL_WAVES];
-    unsigned long long rows = 0, edges = 0;
-    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nrows; r += gridDim.x * VGL_BLOCK)
-        if (epoch[row_base + r] == iter) { rows++; edges += (unsigned long long)(rowptr[r + 1] - rowptr[r]); }
-    rows = vgl_block_reduce_add(rows, s);
-    edges = vgl_block_reduce_add(edges, s);
-    if (threadIdx.x == 0 && rows) {
-        atomicAdd((unsigned long long *)&counters[C_FRONT], rows);
-        atomicAdd((unsigned long long *)&counters[C_NEIGH], edges);
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int64_t s_base[VGL_TILE];
+    __shared__ float s_d[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, M - e0);
+    const int p_first = tile_first[blockIdx.x];
+    const int p_last = tile_first[blockIdx.x + 1];      // last tile: owner of the last edge
+    const int np = p_last - p_first + 1;
+    const bool staged = np <= VGL_TILE;                 // (more than 2048 frontier positions in one tile: thousands of empty rows)
+    if (staged)
+        for (int k = threadIdx.x; k < np; k += VGL_BLOCK) {
+            const int p = p_first + k;
+            const int32_t u = ids[p];
+            s_base[k] = rowptr[u - row_base] - offs[p];
+            s_d[k] = dist[u];
+        }
+    vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);      // ends with a barrier: s_base / s_d are visible too
+    int32_t dsts[VGL_EPT];
+    float cand[VGL_EPT], olds[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;          // strided slots => coalesced adjacency / weight reads
+        dsts[j] = -1;
+        cand[j] = Path::dead_value();
+        if (i < n) {
+            const int k = s_map[i];
+            const int32_t u = staged ? 0 : ids[p_first + k];
+            const int64_t base = staged ? s_base[k] : (rowptr[u - row_base] - offs[p_first + k]);
+            const float d = staged ? s_d[k] : dist[u];
+            const int64_t e = base + e0 + i;
+            dsts[j] = adj[e];
+            if (Path::live(d)) cand[j] = Path::extend(d, w[e]);
+        }
     }
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) olds[j] = dsts[j] >= 0 ? dist[dsts[j]] : Path::dead_value();
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++)
+        if (dsts[j] >= 0 && Path::live(cand[j]) && Path::better(cand[j], olds[j])) {
+            const int before = Path::update(dist + dsts[j], cand[j]);
+            if (Path::improved(before, cand[j])) epoch[dsts[j]] = iter;
+        }
 }
 
 struct vgl_hip_sssp_pull_plan {
@@ -228,34 +270,37 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     if (source < 0 || source >= g->V) return fail("source vertex out of range");
     if (mode != VGL_HIP_SSSP_PULL && mode != VGL_HIP_SSSP_DIRECTION_OPT) return fail("unknown mode");
     const char *env = getenv("VGL_SSSP_PULL_SHARE");
-    const double share = (env && *env) ? atof(env) : 0.35;      // pull when the rows that changed own more than this share of the edges
+    const double share = (env && *env) ? atof(env) : 0.35;      // pull when the rows that changed own more than this share of the edges (0.2 - 0.5 measure within 3 % on RMAT-24)
     hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, g->epoch);
-    VGL_TRY(vgl_zero_counters(c, C_EDGES, 1));
     vgl_hip_sssp_stats st = {0, 0, 0, 0, 0};
-    int64_t active_edges = 0;                                   // out-edges of the rows that changed in the last step (the source: unknown, small)
-    int64_t pull_edges = 0;
+    int64_t pull_edges = 0, push_edges = 0;
+    // Every step starts from the frontier of the step before -- the rows whose value changed in it (epoch == iter - 1; the source
+    // carries epoch 0), compacted with their edge counts by the GNF.  An empty frontier ends the run (the step before changed nothing:
+    // do { ... } while(changes), shortest_paths.hpp:112-154); its edge share picks the direction of a DIRECTION_OPT step.
     for (int32_t iter = 1;; iter++) {
-        const bool pull = mode == VGL_HIP_SSSP_PULL || (double)active_edges > share * (double)g->out.edges;
-        VGL_TRY(vgl_zero_counters(c, C_CHANGED, 1));
-        VGL_TRY(vgl_zero_counters(c, C_FRONT, 2));
+        const vgl_pred_equal_i32 pred{g->epoch, iter - 1};                  // (whole-graph handle: row_begin == 0)
+        VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)nullptr, (uint8_t *)nullptr, (int32_t *)nullptr, true, true));
+        const int64_t F = c->h_counters[C_FRONT], M = c->h_counters[C_NEIGH];
+        if (F == 0) break;
+        st.iterations = iter;
+        const bool pull = mode == VGL_HIP_SSSP_PULL || (double)M > share * (double)g->out.edges;
         if (pull) {
             const vgl_path_blk_op<Path> op{d_dist, g->epoch, iter, g->row_begin, c->d_counters};
             VGL_TRY((vgl_blocked_pass<vgl_path_blk_op<Path>, true, false>(c, plan->blk, op, "sssp_pull_gather", "sssp_pull_accumulate")));
             pull_edges += plan->blk->edges;
             st.pull_steps++;
-        } else {
-            VGL_TRY(vgl_sssp_launch<Path>(c, g, d_weights, d_dist, true, iter));
+        } else if (M > 0) {
+            hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid1(F)), dim3(VGL_BLOCK), 0, c->stream, (int32_t)F, (const int64_t *)g->offs, g->tile_first);
+            vgl_timed_launch tl(c, "sssp_relax");
+            hipLaunchKernelGGL((vgl_k_sssp_relax_sparse<Path>), dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, (const int32_t *)g->ids,
+                               (const int64_t *)g->offs, (const int32_t *)g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, d_weights, g->row_begin, d_dist,
+                               g->epoch, iter);
+            push_edges += M;
             st.push_steps++;
-        }
-        if (mode == VGL_HIP_SSSP_DIRECTION_OPT && g->nrows > 0)
-            hipLaunchKernelGGL(vgl_k_sssp_active_count, dim3(vgl_grid1(g->nrows) > 1024 ? 1024 : vgl_grid1(g->nrows)), dim3(VGL_BLOCK), 0, c->stream, g->nrows,
-                               g->row_begin, g->out.rowptr, (const int32_t *)g->epoch, iter, c->d_counters);
-        VGL_TRY(vgl_read_counters(c));
-        st.iterations = iter;
-        if (!c->h_counters[C_CHANGED]) break;
-        active_edges = c->h_counters[C_NEIGH];
+        } else st.push_steps++;                                 // the frontier has no outgoing edges: nothing to relax, the next frontier is empty
+        VGL_HIP_TRY(hipGetLastError());
     }
-    st.edges_relaxed = c->h_counters[C_EDGES] + pull_edges;
+    st.edges_relaxed = push_edges + pull_edges;
     st.algorithmic_bytes = 12 * st.edges_relaxed + 28 * (int64_t)g->V * st.iterations;
     if (stats) *stats = st;
     return 0;
