@@ -82,6 +82,7 @@ def leg_sssp(api, ctx, g, w, E, V, sources, args, extra, cpu):
     here against the all-active push run); what differs is how many edges a run streams."""
     import torch
     res, ref = {}, None
+    torch.cuda.synchronize()                                      # (the graph build may still be running: it is not part of the plan's time)
     t1 = time.perf_counter()
     pull_plan = api.SsspPullPlan(g, w)
     torch.cuda.synchronize()
@@ -188,6 +189,7 @@ def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
         del ps, pd
         rec, auto_ranks = {}, None
         for mode, mname in ((api.PR_AUTO, "auto"), (api.PR_EXACT_ORDER, "exact_order")):
+            torch.cuda.synchronize()                              # (graph build finished: t_first is the plan build + two iterations only)
             t1 = time.perf_counter()
             api.page_rank(pg, 2, raw=True, mode=mode)
             torch.cuda.synchronize()

@@ -444,7 +444,9 @@ typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 1
 // frontier words are not being evicted from L1), the first 2048 words of the frontier bitmap in LDS (16 KiB per workgroup: 61.9 vs
 // 62.5 us; 4096 words halve the occupancy: 94 us -- the kernel's rate follows the number of resident wavefronts), a two-phase form
 // (uniform first probe for all candidates with four row groups in flight, misses compacted and probed densely: 78 us), requesting
-// the next group's head records ahead.  Also tried: chaining the bottom-up levels on the device (the last workgroup of a level evaluates the
+// the next group's head records ahead (also as a true software pipeline: this group's first probe issued, then the next group's records
+// issued unconditionally, s_waitcnt vmcnt(1) checked in the ISA: 49.1 vs 48 us -- a wavefront's dependent chain is not the limit either, the
+// other resident wavefronts already cover it).  Also tried: chaining the bottom-up levels on the device (the last workgroup of a level evaluates the
 // switch rule, speculative launches of the next levels return at once when it says stop; one host wait per chain): 0.394 ms per
 // traversal with three levels per wait against 0.389 with one -- the polled hand-over costs less than the extra launches.
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,

@@ -5,6 +5,8 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -110,6 +112,22 @@ __global__ void vgl_k_blk_pick(int n, uint32_t stride, const uint32_t *in, uint3
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[(size_t)i * stride];
 }
 
+// VGL_BLK_BUILD_TRACE=1: wall time of every stage of the build on stderr (each mark waits for the stream)
+struct stage_trace {
+    bool on;
+    hipStream_t st;
+    std::chrono::steady_clock::time_point t;
+    stage_trace(hipStream_t s) : on(getenv("VGL_BLK_BUILD_TRACE") != nullptr), st(s), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vgl blocked plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 int env_int(const char *name, int dflt)
 {
     const char *s = getenv(name);
@@ -166,6 +184,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     if ((int64_t)nG * nA >= (1LL << 31)) VGL_FAIL("blocked_plan_build: too many block pairs");
 
     dev_bufs tmp;
+    stage_trace trace(st);
     uint32_t *keys = nullptr, *keys2 = nullptr, *packed = nullptr, *packed2 = nullptr, *seg_first = nullptr, *seg_end = nullptr;
     uint32_t *nch_a = nullptr, *nch_m = nullptr, *a_start = nullptr, *m_start = nullptr, *picked = nullptr;
     float *w2 = nullptr;
@@ -184,9 +203,11 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         VGL_HIP_TRY(tmp.alloc(&keys2, (size_t)E));
         VGL_HIP_TRY(tmp.alloc(&packed, (size_t)E));
         VGL_HIP_TRY(tmp.alloc(&packed2, (size_t)E));
+        trace.mark("allocate keys");
         hipLaunchKernelGGL(vgl_k_blk_keys, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E,
                            row_base, gather_rows, skip_self, nG, nseg, a_bits, keys, packed);
         VGL_HIP_TRY(hipGetLastError());
+        trace.mark("keys kernel");
         int bits = 1;
         while ((1u << bits) <= nseg) bits++;                       // the sentinel nseg must sort last
         size_t need = 0;
@@ -194,6 +215,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         VGL_HIP_TRY(hipMalloc(&sort_tmp, std::max<size_t>(need, 16)));
         tmp.ptrs.push_back(sort_tmp);
         VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need, keys, keys2, packed, packed2, (size_t)E, 0, bits, st));
+        trace.mark("sort (block pair, packed ids)");
         if (d_weights) {                                            // same keys, same stable sort: the weights land in the same order
             VGL_HIP_TRY(hipStreamSynchronize(st));
             tmp.release(packed);
@@ -207,6 +229,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
             VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need2, keys, keys3, d_weights, w2, (size_t)E, 0, bits, st));
             VGL_HIP_TRY(hipStreamSynchronize(st));
             tmp.release(keys3);
+            trace.mark("sort weights");
         }
         hipLaunchKernelGGL(vgl_k_blk_runs, dim3((unsigned)std::min<int64_t>(16384, vgl_ceil_div(E, VGL_BLOCK))), dim3(VGL_BLOCK), 0, st, E,
                            (const uint32_t *)keys2, seg_first, seg_end);
@@ -224,6 +247,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         VGL_HIP_TRY(rocprim::exclusive_scan(scan_tmp, need, nch_a, a_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
         VGL_HIP_TRY(rocprim::exclusive_scan(scan_tmp, need, nch_m, m_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
     }
+    trace.mark("runs, chunk counts, scans");
     // chunk ranges of the blocks on both sides -> host
     hipLaunchKernelGGL(vgl_k_blk_pick, dim3(8), dim3(256), 0, st, (int)nA + 1, nG, (const uint32_t *)a_start, picked);
     hipLaunchKernelGGL(vgl_k_blk_pick, dim3(8), dim3(256), 0, st, (int)nG + 1, nA, (const uint32_t *)m_start, picked + nA + 1);
@@ -249,12 +273,14 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     if (d_weights) VGL_HIP_TRY(hipMalloc((void **)&p->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
     VGL_HIP_TRY(hipMalloc((void **)&p->g_dirty, (size_t)nG));
     VGL_HIP_TRY(hipMemsetAsync(p->g_dirty, 1, (size_t)nG, st));
+    trace.mark("allocate plan arrays");
     if (p->nchunks > 0) {
         hipLaunchKernelGGL(vgl_k_blk_fill, dim3((unsigned)std::min<int64_t>(65536, vgl_ceil_div(p->nchunks, VGL_WAVES))), dim3(VGL_BLOCK), 0, st, p->nchunks, nG, nA,
                            (const uint32_t *)a_start, (const uint32_t *)m_start, (const uint32_t *)seg_first, (const uint32_t *)seg_end,
                            (const uint32_t *)packed2, (const float *)w2, a_bits, p->g_lo, p->a_lo, p->w_mid, p->mid_to_a);
         VGL_HIP_TRY(hipGetLastError());
     }
+    trace.mark("fill kernel");
     // work units.  Gather units: >= 4 per CU when the graph allows (each reloads its 128 KiB window, so not below ~256 K edges);
     // accumulate units larger (a block cut in several units costs a slab or a round of global atomics per unit)
     // (accumulate blocks up to 1.5x the average stay whole -- on a uniform graph every block is one unit and nothing goes through slabs --
@@ -276,6 +302,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     if (!multi.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->multi, multi.data(), sizeof(vgl_blk_multi) * multi.size()));
     VGL_HIP_TRY(hipMalloc(&p->slabs, sizeof(uint32_t) * VGL_BLK * (size_t)std::max(p->n_slabs, 1)));
     VGL_HIP_TRY(hipStreamSynchronize(st));
+    trace.mark("work units");
     own.p = nullptr;
     *out = p;
     return 0;
