@@ -446,7 +446,12 @@ typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 1
 // (uniform first probe for all candidates with four row groups in flight, misses compacted and probed densely: 78 us), requesting
 // the next group's head records ahead (also as a true software pipeline: this group's first probe issued, then the next group's records
 // issued unconditionally, s_waitcnt vmcnt(1) checked in the ISA: 49.1 vs 48 us -- a wavefront's dependent chain is not the limit either, the
-// other resident wavefronts already cover it).  Also tried: chaining the bottom-up levels on the device (the last workgroup of a level evaluates the
+// other resident wavefronts already cover it); head records holding each row's eight SMALLEST ids (= its best-connected in-neighbours
+// under the degree renumbering) instead of the first eight: on RMAT the first bottom-up level then sends half as many candidates to the
+// second round of probes and a quarter to the deferred pass (simulated on scale 20, tests/studies/bu_head_order.py) -- and the
+// traversal takes 0.396 ms against 0.389-0.404, probe 49.3 vs 49.1 us: the kernel's time does not follow the number of probe rounds.
+// Per-launch durations (profiles/microbench/bfs_launches.py on a kernel trace): first bottom-up level 58-120 us, second 20-52, third
+// 12-18; an empty deferred pass costs 9.5 us, vgl_k_bm_advance 4.2.  Also tried: chaining the bottom-up levels on the device (the last workgroup of a level evaluates the
 // switch rule, speculative launches of the next levels return at once when it says stop; one host wait per chain): 0.394 ms per
 // traversal with three levels per wait against 0.389 with one -- the polled hand-over costs less than the extra launches.
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
