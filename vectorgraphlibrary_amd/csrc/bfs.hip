@@ -450,6 +450,22 @@ typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 1
 // under the degree renumbering) instead of the first eight: on RMAT the first bottom-up level then sends half as many candidates to the
 // second round of probes and a quarter to the deferred pass (simulated on scale 20, tests/studies/bu_head_order.py) -- and the
 // traversal takes 0.396 ms against 0.389-0.404, probe 49.3 vs 49.1 us: the kernel's time does not follow the number of probe rounds.
+// What a divergent load costs was then measured on its own (profiles/microbench/ta_rate_bench.hip, profiles/r02_ta_rate_bench.log): 2.3
+// clocks per ACTIVE LANE when it misses L1 (0.6 when it hits), never less than 8 (4-byte) / 17 (8-byte) clocks per instruction -- 2.65e11
+// lane-loads/s for the chip whatever the occupancy; a random LDS read costs 0.1 clock per lane.  On that basis the kernel was rebuilt
+// around an LDS copy of the frontier bits of the first 2^20 ids (one 1024-thread workgroup per CU, 128 KiB window, smallest-id heads so
+// that 96 % of the first probes land in it, four groups per round, memory only for entries outside the window), in three stages, each
+// traced per launch on RMAT-24 (first / second / third bottom-up level; this kernel: 80 / 30 / 14 us):
+//   window + guarded loads, stores as here             80 / 43 / 18   (the compiler waits for each guarded load before issuing the next)
+//   + unconditional loads issued together, NO store in the loop (found masks stored once per lane after it, levels written from the
+//     bitmap by vgl_k_bm_advance: +9 / +5 / +0 us there)                                    64 / 37 / 15
+//   + next round's head records requested before this round's second step                  64 / 41 / 16
+// Removing every global gather did not change the first level; taking the stores out did (a wavefront cannot wait for a load without
+// waiting for every store issued before it -- one in-order counter -- and a partial-line store takes ~1.4 us to be acknowledged), but the
+// levels still have to be written somewhere; overlapping the dependent steps changed nothing.  With synthetic head records the same launch
+// takes 36 us, without the loop 8: what is left is the head records themselves -- ~250 MB of 128-byte lines on the first level, i.e. the
+// launch runs at ~4 TB/s of lines touched.  The traversal took 0.396-0.400 ms with the rebuilt kernel against 0.389-0.404 with this one, so
+// this one (simpler, no assumption about where the hubs are numbered) stayed.
 // Per-launch durations (profiles/microbench/bfs_launches.py on a kernel trace): first bottom-up level 58-120 us, second 20-52, third
 // 12-18; an empty deferred pass costs 9.5 us, vgl_k_bm_advance 4.2.  Also tried: chaining the bottom-up levels on the device (the last workgroup of a level evaluates the
 // switch rule, speculative launches of the next levels return at once when it says stop; one host wait per chain): 0.394 ms per
