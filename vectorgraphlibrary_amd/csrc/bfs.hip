@@ -58,6 +58,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_first(int32_t F, const i
 // edge_op of bfs.hpp:28-36: if levels[dst] == UNVISITED then levels[dst] = cur+1 (benign race, same value).
 // EMIT: every newly discovered vertex also sets its bit in the next-frontier bitmap (idempotent atomicOr), so that the next
 // level's frontier can be generated from 2 MiB of bitmap instead of a 64 MiB scan of levels.  Used for small frontiers only.
+// (levels[dst] == -1 is what keeps the atomics few: asking the next-frontier bitmap instead -- 2 MiB in L2 against a random sector of
+// a 64 MiB array per unvisited edge -- lets every edge that arrives before the bit is visible issue its own atomicOr: 252 us per level
+// instead of 74.)
 template <bool EMIT>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids, const int64_t *offs, const int32_t *tile_first,
                                                              int32_t F, int64_t M, const int64_t *rowptr, const int32_t *adj,
