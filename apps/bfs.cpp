@@ -10,6 +10,10 @@ int main(int argc, char **argv)
         parser.parse_args(argc, argv);
         VGL_Graph graph(parser.format);
         prepare_graph(graph, parser);
+        if (parser.blocked) {
+            if (!parser.fused) throw "-blocked goes with -fused (the blocked levels are part of vgl_hip_bfs_run)";
+            VGL_HIP_CALL(vgl_hip_bfs_prepare_blocked(VGL_RUNTIME::ctx(), graph.get_handle()));     // graph preparation, like the import: outside the timers
+        }
         VerticesArray<int> levels(graph, SCATTER);
         double avg_perf = 0;
         for (int i = 0; i < parser.get_number_of_rounds(); i++) {

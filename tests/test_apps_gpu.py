@@ -34,7 +34,7 @@ CASES = [("rmat", 12, 16, 3), ("ru", 11, 8, 5)]
 
 
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)
-@pytest.mark.parametrize("mode", [[], ["-fused", "-td"], ["-fused", "-do"]])
+@pytest.mark.parametrize("mode", [[], ["-fused", "-td"], ["-fused", "-do"], ["-fused", "-td", "-blocked"]])
 def test_bfs_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
     O = oracle
     src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)

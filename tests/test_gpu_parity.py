@@ -1135,6 +1135,7 @@ def test_random_graphs_blocked_paths(seed, ctx, oracle):
     ref_width, _ = O.sswp_bellman_ford(rowptr, adj, w, source)
     ref_comp = O.cc_sv(rowptr, adj)[0]
     ref_pr = pagerank_exact_sums(O, rowptr, adj, 3)
+    ref_levels, ref_bst = O.bfs_top_down(rowptr, adj, source)
     for unit in ("", "64"):
         os.environ["VGL_CC_BLOCKED"] = "1"
         if unit:
@@ -1150,7 +1151,58 @@ def test_random_graphs_blocked_paths(seed, ctx, oracle):
             assert (api.connected_components(g)[0].cpu().numpy() == ref_comp).all(), unit
             rk = api.page_rank(g, 3, mode=api.PR_BLOCKED)[0].cpu().numpy()
             assert relerr(rk, ref_pr) <= 3e-7, (unit, relerr(rk, ref_pr))
+            # blocked top-down levels: every level (share 0), the default rule, and never -- same levels and statistics
+            g.prepare_blocked_bfs()
+            for share in ("0", "", "2"):
+                if share:
+                    os.environ["VGL_BFS_BLOCKED_SHARE"] = share
+                for bmode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+                    lv, bst = api.bfs(g, source, bmode)
+                    assert (lv.cpu().numpy() == ref_levels).all(), (unit, share, bmode)
+                    assert bst["discovered"] == ref_bst["discovered"] and bst["frontier_total"] == ref_bst["frontier_total"]
+                    if bmode == api.BFS_TOP_DOWN:
+                        assert bst["edges_examined"] == ref_bst["edges_examined"] and bst["levels"] == ref_bst["levels"]
+                os.environ.pop("VGL_BFS_BLOCKED_SHARE", None)
             g.close()
         finally:
-            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT"):
+            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BFS_BLOCKED_SHARE"):
                 os.environ.pop(k, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef", [("rmat", 16, 32), ("uniform", 15, 16), ("rmat", 18, 32)])
+def test_bfs_blocked_top_down_levels(kind, scale, ef, ctx, oracle):
+    """vgl_hip_bfs_prepare_blocked: top-down traversals whose large levels run as the blocked pass (one bit per edge through LDS windows)
+    return the levels, level count and work statistics of the plain top-down run and of the oracle (bfs.hpp:6-51); degree-renumbered and
+    identity numbering, several sources, share 0 (every level blocked) and the default rule"""
+    import os
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    V = 1 << scale
+    hs, hd = (O.gen_rmat if kind == "rmat" else O.gen_uniform)(scale, ef, 3)
+    rowptr, adj, _ = O.coo_to_csr(V, hs, hd)
+    s_d, d_d = torch.from_numpy(hs).to(ctx.device), torch.from_numpy(hd).to(ctx.device)
+    for renumber in (None, "total"):
+        g = api.Graph.from_coo(ctx, V, s_d, d_d, renumber=renumber)
+        plain = {}
+        srcs = [int(x) for x in np.nonzero(np.diff(rowptr) > 0)[0][[1, 77, 4321]]]
+        for s in srcs:
+            plain[s] = api.bfs(g, s, api.BFS_TOP_DOWN)
+        g.prepare_blocked_bfs()
+        try:
+            for share in ("", "0"):
+                if share:
+                    os.environ["VGL_BFS_BLOCKED_SHARE"] = share
+                for s in srcs:
+                    ref, ref_st = O.bfs_top_down(rowptr, adj, s)
+                    lv, st = api.bfs(g, s, api.BFS_TOP_DOWN)
+                    assert (lv.cpu().numpy() == ref).all(), (renumber, share, s)
+                    assert torch.equal(lv, plain[s][0])
+                    for k in ("levels", "edges_examined", "frontier_total", "discovered"):
+                        assert st[k] == ref_st[k] == plain[s][1][k], (k, renumber, share, s)
+                    lv2, _ = api.bfs(g, s, api.BFS_DIRECTION_OPT)
+                    assert (lv2.cpu().numpy() == ref).all()
+        finally:
+            os.environ.pop("VGL_BFS_BLOCKED_SHARE", None)
+        g.close()

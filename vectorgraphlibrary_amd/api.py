@@ -196,6 +196,10 @@ class Graph:
     def out_edge_range(self, row_begin, row_end):
         return int(self.out_rowptr[row_begin]), int(self.out_rowptr[row_end])
 
+    def prepare_blocked_bfs(self):
+        """one-time layout for the blocked top-down BFS levels (vgl_hip_bfs_prepare_blocked); bfs() results do not change"""
+        _l.check(self.ctx.L.vgl_hip_bfs_prepare_blocked(self.ctx.h, self.h))
+
     def close(self):
         if self.h:
             self.ctx.L.vgl_hip_graph_destroy(self.ctx.h, self.h)

@@ -12,6 +12,7 @@
 //                                        remaining long rows strip-mined 64-wide by one wavefront per vertex
 #include "vgl_hip_internal.h"
 #include "vgl_gnf.h"
+#include "vgl_blocked.h"
 
 constexpr int VGL_BU_PROBES = 8;
 #ifndef VGL_BU_HEAVY_LANES
@@ -106,6 +107,93 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
             levels[dsts[j]] = next_level;
             if (EMIT) atomicOr((unsigned long long *)&next[dsts[j] >> 6], 1ULL << (dsts[j] & 63));
         }
+}
+
+// ---- a large top-down level as a blocked pass (vgl_blocked.h; plan built by vgl_hip_bfs_prepare_blocked) ----
+// vgl_k_td_expand pays per frontier edge one adjacency entry, one probe of the visited bitmap (an L2 line) and one sector of `levels`:
+// 4.7 us per million edges, 2.1 ms for the level of an RMAT-24 traversal that holds 83 % of the edges.  What has to travel from the
+// source's side of an edge to the destination's is ONE BIT (source in the frontier?), so the blocked pass carries one 64-bit word per
+// 64-edge chunk: the gather kernel keeps the frontier bits of its 32768 rows in LDS (4 KiB) and reads the uint16 row indices (2 B per
+// edge), the accumulate kernel reads the uint16 destination indices of the chunks that hold a frontier edge (2 B per edge) and ORs
+// discovery bits into an LDS window; its epilogue masks with `visited`, writes the next-frontier words and the levels.  4.2 B per edge
+// of streamed traffic whatever the frontier -- the all-edges cost of ~0.5 ms on RMAT-24 pays from about a fifth of the edges.
+__global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_bfs_blk_gather(const vgl_blk_unit *units, const uint16_t *g_lo, const uint32_t *mid_to_a,
+                                                                     uint64_t *bits, int32_t g_count, const uint64_t *front, int64_t word0)
+{
+    __shared__ uint32_t s_f[VGL_BLK / 32];
+    const vgl_blk_unit u = units[blockIdx.x];
+    const int32_t base = u.block << VGL_BLK_BITS;
+    const int nw = (min(VGL_BLK, g_count - base) + 31) >> 5;            // 32-bit words of this block that exist
+    const uint32_t *f32 = reinterpret_cast<const uint32_t *>(front + word0) + ((size_t)u.block << (VGL_BLK_BITS - 5));
+    uint32_t mine = 0;
+    if ((int)threadIdx.x < nw) mine = f32[threadIdx.x];                  // VGL_BTHREADS = VGL_BLK / 32: one word per thread
+    s_f[threadIdx.x] = mine;
+    const bool any = __syncthreads_or(mine != 0u);                       // no frontier row in this block: its chunks carry zeros
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, off = (lane & 7) * 8;                    // this lane: entries off..off+7 of chunk m0 + sub
+    for (uint32_t m0 = u.chunk0 + wave * VGL_BGROUP; m0 < u.chunk1; m0 += VGL_BWAVES * VGL_BGROUP) {
+        const uint32_t m = m0 + sub;                                    // (the eight lanes of a chunk agree on m)
+        if (m >= u.chunk1) continue;
+        uint32_t mask = 0;
+        if (any) {
+            const uint4 gl = *reinterpret_cast<const uint4 *>(g_lo + (size_t)m * VGL_CHUNK + off);
+            const uint32_t g[4] = {gl.x, gl.y, gl.z, gl.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t lo = g[k] & 0xFFFFu, hi = g[k] >> 16;
+                mask |= ((s_f[lo >> 5] >> (lo & 31)) & 1u) << (2 * k);
+                mask |= ((s_f[hi >> 5] >> (hi & 31)) & 1u) << (2 * k + 1);
+            }
+        }
+        // the chunk's word: byte (lane & 7) comes from this lane (pad entries read row 0 of the block: their destinations are dummies)
+        uint32_t w0 = (lane & 4) ? 0u : mask << (8 * (lane & 3)), w1 = (lane & 4) ? mask << (8 * (lane & 3)) : 0u;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) { w0 |= __shfl_xor(w0, d); w1 |= __shfl_xor(w1, d); }
+        if ((lane & 7) == 0) bits[mid_to_a[m]] = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    }
+}
+
+// slab < 0: the block is this workgroup's alone (plain stores of the next-frontier words), else several units share it (atomicOr)
+__global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_bfs_blk_accumulate(const vgl_blk_unit *units, const uint16_t *a_lo, const uint64_t *bits,
+                                                                         int32_t a_count, const uint64_t *visited, uint64_t *next, int32_t *levels,
+                                                                         int32_t next_level)
+{
+    __shared__ uint32_t s_d[VGL_BLK / 32 + VGL_CHUNK / 32];              // + the dummy destinations of pad entries
+    const vgl_blk_unit u = units[blockIdx.x];
+    s_d[threadIdx.x] = 0;
+    if (threadIdx.x < VGL_CHUNK / 32) s_d[VGL_BLK / 32 + threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, off = (lane & 7) * 8;
+    for (uint32_t j0 = u.chunk0 + wave * VGL_BGROUP; j0 < u.chunk1; j0 += VGL_BWAVES * VGL_BGROUP) {
+        const uint32_t j = j0 + sub;
+        if (j >= u.chunk1) continue;
+        const uint32_t mask = (uint32_t)(bits[j] >> off) & 0xFFu;       // this lane's eight entries
+        if (mask == 0) continue;                                        // (their indices are not even read)
+        const uint4 al = *reinterpret_cast<const uint4 *>(a_lo + (size_t)j * VGL_CHUNK + off);
+        const uint32_t a[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = a[k] & 0xFFFFu, hi = a[k] >> 16;
+            if (mask & (1u << (2 * k))) atomicOr(&s_d[lo >> 5], 1u << (lo & 31));
+            if (mask & (2u << (2 * k))) atomicOr(&s_d[hi >> 5], 1u << (hi & 31));
+        }
+    }
+    __syncthreads();
+    // one 32-bit word of the block per thread: discovered and not visited before -> next frontier + levels
+    const int32_t base = u.block << VGL_BLK_BITS;
+    const int32_t v0 = base + (int32_t)threadIdx.x * 32;
+    if (v0 >= a_count) return;
+    const size_t wi = ((size_t)u.block << (VGL_BLK_BITS - 5)) + threadIdx.x;
+    uint32_t n = s_d[threadIdx.x] & ~reinterpret_cast<const uint32_t *>(visited)[wi];
+    if (n == 0) return;
+    if (u.slab < 0) reinterpret_cast<uint32_t *>(next)[wi] = n;
+    else atomicOr(reinterpret_cast<uint32_t *>(next) + wi, n);
+    while (n) {
+        const int b = __ffs(n) - 1;
+        n &= n - 1;
+        levels[v0 + b] = next_level;
+    }
 }
 
 // ---- frontier generation from the frontier BITMAP (small frontiers): one 64-bit word per thread, 256 words per workgroup ----
@@ -869,7 +957,39 @@ static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, 
     return 0;
 }
 
+// one top-down level from g->bm_front / g->bm_visited (both current) into g->bm_next (all zero before) and levels
+static int vgl_bfs_blocked_level(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, int32_t next_level)
+{
+    const vgl_blocked_plan *p = g->blk_bfs;
+    if (p->n_g_units > 0) {
+        vgl_timed_launch tl(c, "bfs_blk_gather");
+        hipLaunchKernelGGL(vgl_k_bfs_blk_gather, dim3((unsigned)p->n_g_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_unit *)p->g_units,
+                           (const uint16_t *)p->g_lo, (const uint32_t *)p->mid_to_a, reinterpret_cast<uint64_t *>(p->vals), p->g_count,
+                           (const uint64_t *)g->bm_front, (int64_t)g->row_begin >> 6);
+    }
+    if (p->n_a_units > 0) {
+        vgl_timed_launch tl(c, "bfs_blk_accumulate");
+        hipLaunchKernelGGL(vgl_k_bfs_blk_accumulate, dim3((unsigned)p->n_a_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_unit *)p->a_units,
+                           (const uint16_t *)p->a_lo, reinterpret_cast<const uint64_t *>(p->vals), p->a_count, (const uint64_t *)g->bm_visited,
+                           g->bm_next, levels, next_level);
+    }
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
+
+// Graph preparation for repeated top-down traversals (like the reference's offline import, vgl_graph.hpp:57-68): lays the outgoing
+// edges out for the blocked level above (4 B per edge kept; a radix sort of the edges, ~40 ms for RMAT-24).  vgl_hip_bfs_run then
+// takes the blocked pass for the levels that hold at least VGL_BFS_BLOCKED_SHARE (0.2) of the edges; levels are the same.
+int vgl_hip_bfs_prepare_blocked(vgl_hip_ctx *c, vgl_hip_graph *g)
+{
+    if (!c || !g) VGL_FAIL("bfs_prepare_blocked: null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("bfs_prepare_blocked: graph handle must own all rows");
+    if (g->blk_bfs) return 0;
+    static_assert(VGL_BTHREADS == VGL_BLK / 32, "one 32-bit frontier word per thread");
+    return vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 1, nullptr, VGL_BLK_BITS, &g->blk_bfs, 1);
+}
 
 int vgl_hip_bfs_init(vgl_hip_ctx *c, int32_t V, int32_t source, int32_t *d_levels)
 {
@@ -906,6 +1026,8 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     int64_t F = 0, M = 0, prevF = 0, visited_total = 0;
     const int64_t factor = std::max<int64_t>(1, (E / V) / 2);     // change_state.hpp:104
     constexpr int64_t VGL_TD_EMIT_EDGES = 16 << 20;
+    double blocked_share = 0.2;                          // top-down levels with at least this share of the edges take the blocked pass (when prepared)
+    if (const char *e = getenv("VGL_BFS_BLOCKED_SHARE")) blocked_share = atof(e);
     auto count_frontier = [&]() -> int {
         if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false, -1, advance_pending)); counted_from_bitmap = true; advance_pending = false; }
         else {
@@ -1005,6 +1127,15 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             }
         }
         prevF = F;
+        if (!bottom_up && g->blk_bfs && front_valid && (double)M >= blocked_share * (double)E) {
+            // a level that holds a large share of the edges: the blocked pass (bitmaps in, bitmap + levels out: the state afterwards is
+            // that after an emitting top-down level)
+            VGL_TRY(vgl_bfs_blocked_level(c, g, d_levels, cur + 1));
+            advance_pending = true;
+            st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
+            cur++;
+            continue;
+        }
         if (!bottom_up) {
             if (!counted) VGL_FAIL("bfs_run: internal error (frontier not counted)");
             if (ids_ready) {}                                   // written by the list kernel

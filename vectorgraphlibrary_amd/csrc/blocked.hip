@@ -23,7 +23,8 @@ struct dev_bufs {                                   // frees whatever the build 
     {
         for (auto &q : ptrs) if (q == p) { hipFree(q); q = nullptr; }
     }
-    ~dev_bufs() { for (void *q : ptrs) if (q) hipFree(q); }
+    void free_all() { for (auto &q : ptrs) if (q) { hipFree(q); q = nullptr; } }
+    ~dev_bufs() { free_all(); }
 };
 
 // key = ab * nG + gb (sentinel nseg for dropped self loops), value = g_lo | a_lo << 16
@@ -165,8 +166,9 @@ void vgl_blocked_plan_destroy(vgl_blocked_plan *p)
 }
 
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
-                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out)
+                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits)
 {
+    if (value_bits != 32 && value_bits != 1) VGL_FAIL("blocked_plan_build: values are 32 bits or 1 bit per edge");
     if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
     if (a_bits != VGL_BLK_BITS && a_bits != VGL_BLK_BITS - 1) VGL_FAIL("blocked_plan_build: accumulate blocks hold 2^15 (4-byte) or 2^14 (8-byte) accumulators");
     if (dir.edges > 0 && (!dir.rowptr || !dir.adj || !dir.tile_row)) VGL_FAIL("blocked_plan_build: CSR direction is missing");
@@ -268,7 +270,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     const size_t slots = (size_t)p->nchunks * VGL_CHUNK;
     VGL_HIP_TRY(hipMalloc((void **)&p->g_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
     VGL_HIP_TRY(hipMalloc((void **)&p->a_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->vals, sizeof(uint32_t) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(hipMalloc((void **)&p->vals, value_bits == 1 ? sizeof(uint64_t) * std::max<size_t>(p->nchunks, 1) : sizeof(uint32_t) * std::max<size_t>(slots, 8)));
     VGL_HIP_TRY(hipMalloc((void **)&p->mid_to_a, sizeof(uint32_t) * std::max<size_t>(p->nchunks, 1)));
     if (d_weights) VGL_HIP_TRY(hipMalloc((void **)&p->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
     VGL_HIP_TRY(hipMalloc((void **)&p->g_dirty, (size_t)nG));
@@ -303,6 +305,8 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     VGL_HIP_TRY(hipMalloc(&p->slabs, sizeof(uint32_t) * VGL_BLK * (size_t)std::max(p->n_slabs, 1)));
     VGL_HIP_TRY(hipStreamSynchronize(st));
     trace.mark("work units");
+    tmp.free_all();
+    trace.mark("free temporaries");
     own.p = nullptr;
     *out = p;
     return 0;

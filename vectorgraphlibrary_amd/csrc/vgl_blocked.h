@@ -59,7 +59,7 @@ struct vgl_blocked_plan {
     uint16_t *g_lo = nullptr, *a_lo = nullptr;
     float *w_mid = nullptr;
     uint32_t *mid_to_a = nullptr;
-    uint32_t *vals = nullptr;
+    uint32_t *vals = nullptr;                    // scratch: 4 bytes per entry (or 8 per chunk: value_bits = 1)
     vgl_blk_unit *g_units = nullptr, *a_units = nullptr;
     int n_g_units = 0, n_a_units = 0;
     vgl_blk_multi *multi = nullptr;
@@ -72,8 +72,9 @@ struct vgl_blocked_plan {
 // gather_rows = 1: x by the local rows, y by the adjacency ids.  skip_self: edges whose adjacency id equals row_base + row are left
 // out (PageRank, pr.hpp:111).  d_weights (optional): f32 per CSR position, carried to the mid order.  Synchronises; offline cost
 // (a 3-pass radix sort of the edges), like the reference's graph import.
+// value_bits = 1: what travels is one BIT per edge (the blocked top-down BFS level): `vals` then holds one 64-bit word per chunk.
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
-                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out);
+                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits = 32);
 void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
 
 #ifdef __HIPCC__

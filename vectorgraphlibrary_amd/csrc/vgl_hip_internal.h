@@ -106,6 +106,7 @@ struct vgl_hip_graph {
     int64_t *ds_partials = nullptr;
     struct vgl_blocked_plan *blk_pr = nullptr;  // PageRank's blocked pull over the outgoing CSR (lazy, owned; vgl_blocked.h)
     struct vgl_blocked_plan *blk_cc = nullptr;  // the Shiloach-Vishkin hook as a blocked pass (lazy, owned)
+    struct vgl_blocked_plan *blk_bfs = nullptr; // the large top-down BFS levels as a blocked pass (vgl_hip_bfs_prepare_blocked, owned)
 };
 
 struct vgl_hip_frontier {
