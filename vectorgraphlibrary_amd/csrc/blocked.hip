@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 
 namespace {
 
@@ -187,6 +188,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
 
     dev_bufs tmp;
     stage_trace trace(st);
+    std::unique_ptr<vgl_timed_launch> timed;
     uint32_t *keys = nullptr, *keys2 = nullptr, *packed = nullptr, *packed2 = nullptr, *seg_first = nullptr, *seg_end = nullptr;
     uint32_t *nch_a = nullptr, *nch_m = nullptr, *a_start = nullptr, *m_start = nullptr, *picked = nullptr;
     float *w2 = nullptr;
@@ -206,6 +208,9 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         VGL_HIP_TRY(tmp.alloc(&packed, (size_t)E));
         VGL_HIP_TRY(tmp.alloc(&packed2, (size_t)E));
         trace.mark("allocate keys");
+        // (timing on: the stream time from here to the fill kernel is booked under "blk_plan_build" -- what the build costs the GPU,
+        // without the allocator, which can stall for seconds right after tens of GB were freed)
+        timed.reset(new vgl_timed_launch(c, "blk_plan_build"));
         hipLaunchKernelGGL(vgl_k_blk_keys, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E,
                            row_base, gather_rows, skip_self, nG, nseg, a_bits, keys, packed);
         VGL_HIP_TRY(hipGetLastError());
@@ -282,6 +287,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
                            (const uint32_t *)packed2, (const float *)w2, a_bits, p->g_lo, p->a_lo, p->w_mid, p->mid_to_a);
         VGL_HIP_TRY(hipGetLastError());
     }
+    timed.reset();
     trace.mark("fill kernel");
     // work units.  Gather units: >= 4 per CU when the graph allows (each reloads its 128 KiB window, so not below ~256 K edges);
     // accumulate units larger (a block cut in several units costs a slab or a round of global atomics per unit)
