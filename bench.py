@@ -550,7 +550,7 @@ def main():
         extra["bfs_top_down_reference_algorithm"] = {
             "teps": round(E / dt_td, 1), "ms": round(dt_td * 1e3, 3),
             "algorithmic_GBps": round(sum(s["algorithmic_bytes"] for s in td_stats) / len(td_stats) / dt_td / 1e9, 2)}
-        # ... and with the graph prepared for blocked top-down levels (vgl_hip_bfs_prepare_blocked: the levels that hold a fifth of the
+        # ... and with the graph prepared for blocked top-down levels (vgl_hip_bfs_prepare_blocked: the levels that hold a tenth of the
         # edges or more run as a blocked pass, one bit per edge through LDS windows).  The direction-optimising traversals above were
         # timed before the preparation; they do not use it (their large levels are bottom-up).
         torch.cuda.synchronize()

@@ -156,7 +156,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t source, int mode
                     int32_t *d_levels, vgl_hip_bfs_stats *stats);
 /* Optional graph preparation for repeated top-down traversals (the counterpart of the reference's offline graph import,
  * vgl_graph.hpp:57-68): lays the outgoing edges out for the blocked advance (4 bytes per edge kept, a radix sort of the edges once).
- * Afterwards vgl_hip_bfs_run expands the levels that hold at least a fifth of the edges (VGL_BFS_BLOCKED_SHARE) as a blocked pass --
+ * Afterwards vgl_hip_bfs_run expands the levels that hold at least a tenth of the edges (VGL_BFS_BLOCKED_SHARE) as a blocked pass --
  * one bit per edge travels from the source's block to the destination's, 4.2 bytes per edge streamed -- instead of
  * bfs.hpp:28-36's per-edge probe of levels[dst].  Levels are identical.  The handle must own all rows. */
 int vgl_hip_bfs_prepare_blocked(vgl_hip_ctx *ctx, vgl_hip_graph *g);

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
 // 64-edge chunk: the gather kernel keeps the frontier bits of its 32768 rows in LDS (4 KiB) and reads the uint16 row indices (2 B per
 // edge), the accumulate kernel reads the uint16 destination indices of the chunks that hold a frontier edge (2 B per edge) and ORs
 // discovery bits into an LDS window; its epilogue masks with `visited`, writes the next-frontier words and the levels.  4.2 B per edge
-// of streamed traffic whatever the frontier -- the all-edges cost of ~0.5 ms on RMAT-24 pays from about a fifth of the edges.
+// of streamed traffic whatever the frontier -- the all-edges cost of ~0.5 ms on RMAT-24 pays from about a tenth of the edges (the sparse path adds a frontier
+// generation per level on top of its 4.7 us per million edges).
 __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_bfs_blk_gather(const vgl_blk_unit *units, const uint16_t *g_lo, const uint32_t *mid_to_a,
                                                                      uint64_t *bits, int32_t g_count, const uint64_t *front, int64_t word0)
 {
@@ -981,7 +982,7 @@ extern "C" {
 
 // Graph preparation for repeated top-down traversals (like the reference's offline import, vgl_graph.hpp:57-68): lays the outgoing
 // edges out for the blocked level above (4 B per edge kept; a radix sort of the edges, ~40 ms for RMAT-24).  vgl_hip_bfs_run then
-// takes the blocked pass for the levels that hold at least VGL_BFS_BLOCKED_SHARE (0.2) of the edges; levels are the same.
+// takes the blocked pass for the levels that hold at least VGL_BFS_BLOCKED_SHARE (0.1) of the edges; levels are the same.
 int vgl_hip_bfs_prepare_blocked(vgl_hip_ctx *c, vgl_hip_graph *g)
 {
     if (!c || !g) VGL_FAIL("bfs_prepare_blocked: null argument");
@@ -1026,7 +1027,8 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     int64_t F = 0, M = 0, prevF = 0, visited_total = 0;
     const int64_t factor = std::max<int64_t>(1, (E / V) / 2);     // change_state.hpp:104
     constexpr int64_t VGL_TD_EMIT_EDGES = 16 << 20;
-    double blocked_share = 0.2;                          // top-down levels with at least this share of the edges take the blocked pass (when prepared)
+    double blocked_share = 0.1;                          // top-down levels with at least this share of the edges take the blocked pass (when prepared;
+                                                         // RMAT-24 top-down traversal: 1.83 ms at 0.2, 1.67 at 0.1, 1.66 at 0.05, 1.69 at 0.02)
     if (const char *e = getenv("VGL_BFS_BLOCKED_SHARE")) blocked_share = atof(e);
     auto count_frontier = [&]() -> int {
         if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false, -1, advance_pending)); counted_from_bitmap = true; advance_pending = false; }
