@@ -553,36 +553,39 @@ def main():
         # ... and with the graph prepared for blocked top-down levels (vgl_hip_bfs_prepare_blocked: the levels that hold a tenth of the
         # edges or more run as a blocked pass, one bit per edge through LDS windows).  The direction-optimising traversals above were
         # timed before the preparation; they do not use it (their large levels are bottom-up).
-        torch.cuda.synchronize()
-        ctx.timing(True)
-        t1 = time.perf_counter()
-        g.prepare_blocked_bfs()
-        torch.cuda.synchronize()
-        t_prep_wall = time.perf_counter() - t1
-        t_prep = ctx.timing_get("blk_plan_build")[1] * 1e-3
-        ctx.timing(False)
-        td_src = sources[args.warmup:args.warmup + 4]
-        lv_b, _ = api.bfs(g, td_src[0], api.BFS_TOP_DOWN, raw=True)
-        if not torch.equal(lv_b, api.bfs(g, td_src[0], api.BFS_DIRECTION_OPT, raw=True)[0]):
-            sys.exit("bench.py: blocked top-down levels differ from the direction-optimising traversal")
-        ctx.timing(True)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        tdb_stats = [api.bfs(g, s, api.BFS_TOP_DOWN, raw=True)[1] for s in td_src]
-        torch.cuda.synchronize()
-        dt_tdb = (time.perf_counter() - t1) / len(tdb_stats)
-        kb = timed_kernels(ctx, ("bfs_blk_gather", "bfs_blk_accumulate"))
-        ctx.timing(False)
-        one = {"teps": round(E / dt_tdb, 1), "ms": round(dt_tdb * 1e3, 3), "prepare_ms_once_per_graph_NOT_in_ms": round(t_prep * 1e3, 1),
-               "prepare_call_wall_ms": round(t_prep_wall * 1e3, 1), "kernels": kb}
-        if kb["bfs_blk_gather"]["launches"]:
-            pass_ms = kb["bfs_blk_gather"]["ms_per_launch"] + kb["bfs_blk_accumulate"]["ms_per_launch"]
-            # streamed by one blocked level: 2 B (row index) + 2 B (destination index) per edge + 16 B per 64-edge chunk
-            streamed = 4.25 * E
-            one["blocked_level"] = {"ms": round(pass_ms, 4), "levels_per_bfs": kb["bfs_blk_gather"]["launches"] / len(tdb_stats),
-                                    "streamed_GBps": round(streamed / (pass_ms * 1e-3) / 1e9, 1),
-                                    "streamed_frac_of_hbm_peak": frac(streamed / (pass_ms * 1e-3) / 1e9)}
-        extra["bfs_top_down_reference_algorithm"]["blocked_levels"] = one
+        if E >= (1 << 32) - 4096:
+            extra["bfs_top_down_reference_algorithm"]["blocked_levels"] = "not built: a blocked plan holds fewer than 2^32 edges (split the graph in shards)"
+        else:
+            torch.cuda.synchronize()
+            ctx.timing(True)
+            t1 = time.perf_counter()
+            g.prepare_blocked_bfs()
+            torch.cuda.synchronize()
+            t_prep_wall = time.perf_counter() - t1
+            t_prep = ctx.timing_get("blk_plan_build")[1] * 1e-3
+            ctx.timing(False)
+            td_src = sources[args.warmup:args.warmup + 4]
+            lv_b, _ = api.bfs(g, td_src[0], api.BFS_TOP_DOWN, raw=True)
+            if not torch.equal(lv_b, api.bfs(g, td_src[0], api.BFS_DIRECTION_OPT, raw=True)[0]):
+                sys.exit("bench.py: blocked top-down levels differ from the direction-optimising traversal")
+            ctx.timing(True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tdb_stats = [api.bfs(g, s, api.BFS_TOP_DOWN, raw=True)[1] for s in td_src]
+            torch.cuda.synchronize()
+            dt_tdb = (time.perf_counter() - t1) / len(tdb_stats)
+            kb = timed_kernels(ctx, ("bfs_blk_gather", "bfs_blk_accumulate"))
+            ctx.timing(False)
+            one = {"teps": round(E / dt_tdb, 1), "ms": round(dt_tdb * 1e3, 3), "prepare_ms_once_per_graph_NOT_in_ms": round(t_prep * 1e3, 1),
+                   "prepare_call_wall_ms": round(t_prep_wall * 1e3, 1), "kernels": kb}
+            if kb["bfs_blk_gather"]["launches"]:
+                pass_ms = kb["bfs_blk_gather"]["ms_per_launch"] + kb["bfs_blk_accumulate"]["ms_per_launch"]
+                # streamed by one blocked level: 2 B (row index) + 2 B (destination index) per edge + 16 B per 64-edge chunk
+                streamed = 4.25 * E
+                one["blocked_level"] = {"ms": round(pass_ms, 4), "levels_per_bfs": kb["bfs_blk_gather"]["launches"] / len(tdb_stats),
+                                        "streamed_GBps": round(streamed / (pass_ms * 1e-3) / 1e9, 1),
+                                        "streamed_frac_of_hbm_peak": frac(streamed / (pass_ms * 1e-3) / 1e9)}
+            extra["bfs_top_down_reference_algorithm"]["blocked_levels"] = one
 
         # ---- CPU baseline: the oracle's OpenMP port of the reference top-down BFS, same graph, the CPUs the box grants ----
         cpu = None
