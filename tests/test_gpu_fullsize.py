@@ -80,6 +80,13 @@ def test_config2_do_bfs_rmat24(rmat24, ctx, oracle):
             assert (lv.cpu().numpy() == ref).all(), f"source {s} mode {mode}: levels differ from the oracle"
             assert st["discovered"] == ref_st["discovered"]
         assert st["edges_examined"] == ref_st["edges_examined"] and st["levels"] == ref_st["levels"]
+    # the same traversals with the graph prepared for blocked top-down levels (vgl_hip_bfs_prepare_blocked): same levels, same statistics
+    g.prepare_blocked_bfs()
+    for s in _sources(host["rowptr"], 2, 24):
+        ref, ref_st = oracle.bfs_top_down(host["rowptr"], host["adj"], s, parallel=True)
+        lv, st = api.bfs(g, s, api.BFS_TOP_DOWN, raw=True)
+        assert (lv.cpu().numpy() == ref).all(), f"source {s}: blocked top-down levels differ from the oracle"
+        assert st["edges_examined"] == ref_st["edges_examined"] and st["levels"] == ref_st["levels"] and st["discovered"] == ref_st["discovered"]
 
 
 def test_config3_bellman_ford_sssp_rmat24(rmat24, ctx, oracle):
