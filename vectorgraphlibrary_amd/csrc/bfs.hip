@@ -14,7 +14,6 @@
 #include "vgl_gnf.h"
 #include "vgl_blocked.h"
 
-constexpr int VGL_BU_PROBES = 8;
 #ifndef VGL_BU_HEAVY_LANES
 #define VGL_BU_HEAVY_LANES 16       // lanes per deferred vertex in the second bottom-up pass
 #endif       // thread-serial probes before a vertex is deferred to the wavefront pass
@@ -538,10 +537,12 @@ typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 1
 // (uniform first probe for all candidates with four row groups in flight, misses compacted and probed densely: 78 us), requesting
 // the next group's head records ahead (also as a true software pipeline: this group's first probe issued, then the next group's records
 // issued unconditionally, s_waitcnt vmcnt(1) checked in the ISA: 49.1 vs 48 us -- a wavefront's dependent chain is not the limit either, the
-// other resident wavefronts already cover it); head records holding each row's eight SMALLEST ids (= its best-connected in-neighbours
-// under the degree renumbering) instead of the first eight: on RMAT the first bottom-up level then sends half as many candidates to the
-// second round of probes and a quarter to the deferred pass (simulated on scale 20, tests/studies/bu_head_order.py) -- and the
-// traversal takes 0.396 ms against 0.389-0.404, probe 49.3 vs 49.1 us: the kernel's time does not follow the number of probe rounds.
+// other resident wavefronts already cover it).  The head records hold each row's eight SMALLEST ids (= its best-connected in-neighbours
+// under the degree renumbering; vgl_k_row_heads) instead of the first eight: on RMAT the first bottom-up level then sends half as many
+// candidates to the second round of probes and a quarter to the deferred pass (simulated on scale 20, tests/studies/bu_head_order.py).
+// On RMAT-24 that changes nothing in this kernel (49 us either way: its time does not follow the number of probe rounds) and the
+// traversal is 1-2 % slower (the deferred pass now scans whole rows); on RMAT-27, where the deferred pass had grown to half of this
+// kernel's time (301 us per launch against 594), the traversal goes from 3.13 to 2.11 ms (probe 408, deferred pass 91 us).
 // What a divergent load costs was then measured on its own (profiles/microbench/ta_rate_bench.hip, profiles/r02_ta_rate_bench.log): 2.3
 // clocks per ACTIVE LANE when it misses L1 (0.6 when it hits), never less than 8 (4-byte) / 17 (8-byte) clocks per instruction -- 2.65e11
 // lane-loads/s for the chip whatever the occupancy; a random LDS read costs 0.1 clock per lane.  On that basis the kernel was rebuilt
@@ -698,14 +699,14 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, in
             int lo = 0, hi = VGL_BU_BLOCKS;                 // segment s with s_off[s] <= h < s_off[s+1]
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= h) lo = mid; else hi = mid; }
             r = heavy[(int64_t)lo * chunk + (h - s_off[lo])];
-            p = in_rowptr[r] + VGL_BU_PROBES; e = in_rowptr[r + 1];
+            p = in_rowptr[r]; e = in_rowptr[r + 1];             // the whole row: its head records are a selection (the smallest ids), not a prefix
         }
         while (!__all(done)) {
             const int64_t q = p + ql;
             bool hit = false;
             if (!done && q < e) { const int32_t u = in_adj[q]; hit = (front[u >> 6] >> (u & 63)) & 1ULL; }
             const unsigned long long hm = __ballot(hit);
-            const unsigned qm = (unsigned)(hm >> (quarter * G)) & ((1u << G) - 1u);
+            const unsigned qm = (unsigned)(hm >> (quarter * G)) & (G >= 32 ? 0xFFFFFFFFu : ((1u << (G & 31)) - 1u));
             if (!done) {
                 if (qm) { hit_any = true; done = true; if (ql == 0) probes += __ffs(qm); }
                 else { if (ql == 0) probes += min((int64_t)G, e - p); p += G; if (p >= e) done = true; }

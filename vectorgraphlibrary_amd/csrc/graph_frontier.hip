@@ -28,24 +28,92 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_nonempty_rows(int32_t nrows, 
     }
 }
 
-// head[r] = the first four entries of row r (-1 padded): one aligned 16-byte record per row, so the bottom-up probe reads its first
-// candidates with a single coalesced load instead of row offsets + a dependent adjacency load
+// The eight smallest distinct ids seen so far, ascending (INT32_MAX = free slot); `overflow` = a distinct id did not fit.
+struct vgl_small8 {
+    int32_t a[8];
+    bool overflow;
+    __device__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = INT32_MAX;
+        overflow = false;
+    }
+    __device__ void insert(int32_t x)
+    {
+        if (x >= a[7]) { overflow |= x > a[7]; return; }             // (the common case in a long row; ids are < INT32_MAX)
+        bool dup = false;
+#pragma unroll
+        for (int i = 0; i < 7; i++) dup |= a[i] == x;
+        if (dup) return;
+        overflow |= a[7] != INT32_MAX;
+        a[7] = x;
+#pragma unroll
+        for (int i = 7; i > 0; i--)
+            if (a[i] < a[i - 1]) { const int32_t t = a[i]; a[i] = a[i - 1]; a[i - 1] = t; }
+    }
+    __device__ void pop()
+    {
+#pragma unroll
+        for (int i = 0; i < 7; i++) a[i] = a[i + 1];
+        a[7] = INT32_MAX;
+    }
+};
+
+// head0[r] / head1[r] = the eight SMALLEST distinct ids of row r, ascending, -1 padded: two aligned 16-byte records per row, so the
+// bottom-up probe reads its candidates with coalesced loads instead of row offsets + a dependent adjacency load.  Smallest ids first:
+// with the degree renumbering (ids ascending = degrees descending) these are the row's best-connected in-neighbours -- the ones most
+// likely to be in a large frontier: on the first bottom-up level of an RMAT traversal half as many candidates go on to the second round
+// of probes and a quarter as many rows are deferred (tests/studies/bu_head_order.py).  long_bits[v] = row v holds ids that are not in
+// its head; the deferred pass then scans the WHOLE row: the head is a selection, not a prefix.  One
+// wavefront per 64 rows: rows of more than 64 entries are scanned by the whole wavefront (per-lane selections merged by eight wave
+// minima), the others by their own lane.
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_row_heads(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj, int4 *head0,
                                                              int4 *head1, uint64_t *long_bits)
 {
-    const int32_t nround = (nrows + 63) & ~63;
-    for (int32_t r = blockIdx.x * VGL_BLOCK + threadIdx.x; r < nround; r += gridDim.x * VGL_BLOCK) {
-        int64_t n = 0;
-        if (r < nrows) {
-            const int64_t b = rowptr[r];
-            n = rowptr[r + 1] - b;
-            int4 h, k;
-            h.x = n > 0 ? adj[b] : -1; h.y = n > 1 ? adj[b + 1] : -1; h.z = n > 2 ? adj[b + 2] : -1; h.w = n > 3 ? adj[b + 3] : -1;
-            k.x = n > 4 ? adj[b + 4] : -1; k.y = n > 5 ? adj[b + 5] : -1; k.z = n > 6 ? adj[b + 6] : -1; k.w = n > 7 ? adj[b + 7] : -1;
-            head0[r] = h; head1[r] = k;
+    const int lane = threadIdx.x & 63;
+    const int32_t ngroups = (nrows + 63) >> 6;
+    for (int32_t grp = blockIdx.x * VGL_WAVES + (threadIdx.x >> 6); grp < ngroups; grp += gridDim.x * VGL_WAVES) {
+        const int32_t r = (grp << 6) + lane;
+        int64_t b = 0, n = 0;
+        if (r < nrows) { b = rowptr[r]; n = rowptr[r + 1] - b; }
+        bool has_more = false;
+        unsigned long long big = __ballot(n > 64);
+        while (big) {                                               // long rows: all lanes on one row
+            const int j = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const int64_t bj = __shfl(b, j), nj = __shfl(n, j);
+            vgl_small8 s;
+            s.init();
+            for (int64_t i = lane; i < nj; i += 64) s.insert(adj[bj + i]);
+            int32_t out[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                int32_t m = s.a[0];
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) m = min(m, __shfl_xor(m, d));
+                out[k] = m == INT32_MAX ? -1 : m;
+                if (s.a[0] == m && m != INT32_MAX) s.pop();
+            }
+            const bool more = __any(s.overflow || s.a[0] != INT32_MAX);
+            if (lane == j) {
+                head0[r] = make_int4(out[0], out[1], out[2], out[3]);
+                head1[r] = make_int4(out[4], out[5], out[6], out[7]);
+                has_more = more;
+            }
         }
-        const unsigned long long m = __ballot(n > 8);
-        if ((threadIdx.x & 63) == 0) long_bits[(row_base + r) >> 6] = m;
+        if (r < nrows && n <= 64) {
+            vgl_small8 s;
+            s.init();
+            for (int64_t i = 0; i < n; i++) s.insert(adj[b + i]);
+            int32_t out[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) out[k] = s.a[k] == INT32_MAX ? -1 : s.a[k];
+            head0[r] = make_int4(out[0], out[1], out[2], out[3]);
+            head1[r] = make_int4(out[4], out[5], out[6], out[7]);
+            has_more = s.overflow;
+        }
+        const unsigned long long m = __ballot(has_more);
+        if (lane == 0) long_bits[(row_base + (grp << 6)) >> 6] = m;
     }
 }
 
