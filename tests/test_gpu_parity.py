@@ -847,9 +847,11 @@ def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
         ref = O.bfs_top_down(rowptr, adj, source)[0]
         for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
             seen = []
-            # (edge bound of the list kernel, frontier bound of the bitmap-driven level at the bottom-up -> top-down switch)
-            for cap, bm in (("0", None), (None, None), ("1000000", None), (None, "0"), (None, "1000000000"), ("256", "1000000000")):
-                for name, val in (("VGL_BFS_SMALL_M", cap), ("VGL_BFS_BM_EXPAND", bm)):
+            # (edge bound of the list kernel, frontier bound of the bitmap-driven level at the bottom-up -> top-down switch, edge bound of the
+            # top-down levels that emit their discoveries into the bitmap)
+            for cap, bm, emit in (("0", None, None), (None, None, None), ("1000000", None, None), (None, "0", None), (None, "1000000000", None),
+                                  ("256", "1000000000", None), (None, None, "0"), (None, None, "1000000000000"), ("0", "0", "0")):
+                for name, val in (("VGL_BFS_SMALL_M", cap), ("VGL_BFS_BM_EXPAND", bm), ("VGL_TD_EMIT_EDGES", emit)):
                     if val is None:
                         os.environ.pop(name, None)
                     else:
@@ -857,9 +859,9 @@ def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
                 try:
                     lv, st = api.bfs(g, source, mode)
                 finally:
-                    os.environ.pop("VGL_BFS_SMALL_M", None)
-                    os.environ.pop("VGL_BFS_BM_EXPAND", None)
-                assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap, bm)
+                    for name in ("VGL_BFS_SMALL_M", "VGL_BFS_BM_EXPAND", "VGL_TD_EMIT_EDGES"):
+                        os.environ.pop(name, None)
+                assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap, bm, emit)
                 seen.append((st["levels"], st["edges_examined"], st["frontier_total"], st["discovered"], st["td_steps"], st["bu_steps"]))
             assert all(x == seen[0] for x in seen), (source, mode, seen)
 
