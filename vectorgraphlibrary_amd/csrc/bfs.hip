@@ -727,9 +727,10 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_heavy(int32_t row_base, in
     // handed to the host (when it listens: host != nullptr)
     if (!vgl_last_block(ticket, dep)) return;
     int64_t f = 0, p = 0;
-    for (int b = threadIdx.x; b < VGL_BU_BLOCKS; b += VGL_BLOCK) {
-        f += partials[b * 4 + 0] + vgl_load_agent(partials + b * 4 + 2);
-        p += partials[b * 4 + 1] + vgl_load_agent(partials + b * 4 + 3);
+    for (int b = threadIdx.x; b < VGL_BU_BLOCKS; b += VGL_BLOCK) {      // (this pass may run with fewer workgroups than the probe pass)
+        f += partials[b * 4 + 0];
+        p += partials[b * 4 + 1];
+        if (b < (int)gridDim.x) { f += vgl_load_agent(partials + b * 4 + 2); p += vgl_load_agent(partials + b * 4 + 3); }
     }
     f = vgl_block_reduce_add(f, s64);
     p = vgl_block_reduce_add(p, s64);
@@ -937,8 +938,11 @@ static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *fron
 
 // one bottom-up step over the owned rows: probe (+ deferred-list offsets) and the balanced heavy pass (+ fold of the counters
 // C_BU_FOUND / C_BU_EDGES, published to the host under sequence number *seq_out: vgl_wait_counters when they are needed)
+// heavy_blocks: workgroups of the deferred pass.  A bottom-up phase defers rows on its first level (when the frontier is still small
+// against the unvisited rows); on the levels after it the pass finds nothing to do in almost every launch and costs what its launch
+// costs -- 9 us with 2048 workgroups, so those levels run it with a small grid (correct for any number of deferred rows, only slower).
 static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, int32_t next_level, const uint64_t *visited,
-                             const uint64_t *front, uint64_t *next, int64_t *seq_out)
+                             const uint64_t *front, uint64_t *next, int64_t *seq_out, int heavy_blocks = VGL_BU_BLOCKS)
 {
     const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
     {
@@ -950,7 +954,7 @@ static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, 
     const int64_t seq = vgl_next_seq(c);
     {
         vgl_timed_launch tl(c, "bfs_bottom_up_heavy");
-        hipLaunchKernelGGL(vgl_k_bu_heavy, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,
+        hipLaunchKernelGGL(vgl_k_bu_heavy, dim3((unsigned)heavy_blocks), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,
                            g->in.adj, front, next, levels, next_level, g->heavy, g->heavy_off, g->bu_partials, c->d_counters, g->tickets + 2 * VGL_TICKET_WORDS,
                            (volatile int64_t *)c->h_counters, seq);
     }
@@ -1032,6 +1036,9 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     // 16 M edges 0.392 ms, 4 M 0.377, 2 M 0.381, 1 M 0.366, 512 K 0.361, 256 K 0.364.
     int64_t VGL_TD_EMIT_EDGES = std::max<int64_t>(65536, (int64_t)V / 24);
     if (const char *e = getenv("VGL_TD_EMIT_EDGES")) VGL_TD_EMIT_EDGES = atoll(e);
+    int bu_in_a_row = 0;                                 // bottom-up levels since the last top-down one
+    int later_heavy_blocks = 256;                        // RMAT-24 traversal: 0.376 ms with 2048, 0.368-0.370 with 512 / 256 / 128
+    if (const char *e = getenv("VGL_BU_LATER_HEAVY_BLOCKS")) later_heavy_blocks = std::max(1, std::min(VGL_BU_BLOCKS, atoi(e)));
     double blocked_share = 0.1;                          // top-down levels with at least this share of the edges take the blocked pass (when prepared;
                                                          // RMAT-24 top-down traversal: 1.83 ms at 0.2, 1.67 at 0.1, 1.66 at 0.05, 1.69 at 0.02)
     if (const char *e = getenv("VGL_BFS_BLOCKED_SHARE")) blocked_share = atof(e);
@@ -1112,7 +1119,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         // direction for this level (gpu_change_state, change_state.hpp:100-141, evaluated with the frontier about to be expanded)
         if (mode == VGL_HIP_BFS_DIRECTION_OPT) {
             if (!bottom_up) {
-                if (F > prevF && M >= ((V - visited_total) * factor + V) / VGL_DO_ALPHA) bottom_up = true;
+                if (F > prevF && M >= ((V - visited_total) * factor + V) / VGL_DO_ALPHA) { bottom_up = true; bu_in_a_row = 0; }
             } else if (F <= prevF && F < ((V - visited_total) * factor + V) / (factor * VGL_DO_BETA)) {      // "shrinking phase" = not growing (change_state.hpp:106,121)
                 bottom_up = false;
                 if (small_m > 0 && F <= bm_expand_f) {
@@ -1166,7 +1173,8 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         } else {
             if (!front_valid) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
             int64_t seq = 0;
-            VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next, &seq));
+            VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next, &seq, bu_in_a_row > 0 ? later_heavy_blocks : VGL_BU_BLOCKS));
+            bu_in_a_row++;
             hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
                                g->bm_front, g->bm_next);
             VGL_HIP_TRY(hipGetLastError());
