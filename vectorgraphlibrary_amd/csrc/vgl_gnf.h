@@ -57,10 +57,15 @@ struct vgl_pred_nonzero_i32 {               // flags[v] != 0
 // front_bytes (optional): bitmap of active vertices (byte v>>3, bit v&7; little-endian uint64 words).
 // visited_bytes (optional): bitmap of the predicate's auxiliary bits (fused BFS: values[v] != -1).
 // flags_out (optional): int32 0/1 per vertex (VGL frontier flags).
+// ticket (optional): the last workgroup to finish also does the scan pass (exclusive offsets per tile, totals, offs[size], hand-over to the
+// host when `host` is given) -- a scan kernel of its own, however small, waits for this kernel's caches to be written back and
+// invalidated before it starts: 18 us per frontier generation on RMAT-24, in every super-step of every frontier-driven algorithm.
 template <class Pred>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_count(Pred pred, int32_t nrows, int32_t row_base, const int64_t *rowptr,
                                                              int32_t *vt_cnt, int64_t *vt_deg, uint8_t *front_bytes,
-                                                             uint8_t *visited_bytes, int32_t *flags_out)
+                                                             uint8_t *visited_bytes, int32_t *flags_out, uint32_t *ticket,
+                                                             int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *counters, int64_t *offs,
+                                                             volatile int64_t *host, int64_t seq)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
@@ -84,39 +89,117 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_count(Pred pred, int32_t 
     }
     const int tc = vgl_block_reduce_add(cnt, s32);
     const int64_t td = vgl_block_reduce_add(deg, s64);
-    if (threadIdx.x == 0) { vt_cnt[blockIdx.x] = tc; vt_deg[blockIdx.x] = td; }
+    if (!ticket) {
+        if (threadIdx.x == 0) { vt_cnt[blockIdx.x] = tc; vt_deg[blockIdx.x] = td; }
+        return;
+    }
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) dep = vgl_put_agent(vt_cnt + blockIdx.x, tc) ^ vgl_put_agent(vt_deg + blockIdx.x, td);
+    if (!vgl_last_block(ticket, dep)) return;
+    // last workgroup: a contiguous run of tiles per thread, eight loads in flight at a time
+    const int nt = (int)gridDim.x;
+    const int per = (nt + VGL_BLOCK - 1) / VGL_BLOCK;
+    const int lo = min(nt, (int)threadIdx.x * per), hi = min(nt, lo + per);
+    int c = 0;
+    int64_t d = 0;
+    for (int t0 = lo; t0 < hi; t0 += 8) {
+        int cv[8];
+        int64_t dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int t = min(t0 + j, hi - 1);
+            cv[j] = vgl_load_agent(vt_cnt + t);
+            dv[j] = vgl_load_agent(vt_deg + t);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (t0 + j < hi) { c += cv[j]; d += dv[j]; }
+    }
+    int ctot;
+    int64_t dtot;
+    int cpre = vgl_block_excl_add(c, s32, &ctot);
+    int64_t dpre = vgl_block_excl_add(d, s64, &dtot);
+    for (int t0 = lo; t0 < hi; t0 += 8) {
+        int cv[8];
+        int64_t dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int t = min(t0 + j, hi - 1);
+            cv[j] = vgl_load_agent(vt_cnt + t);
+            dv[j] = vgl_load_agent(vt_deg + t);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (t0 + j < hi) { vt_cnt_off[t0 + j] = cpre; vt_deg_off[t0 + j] = dpre; cpre += cv[j]; dpre += dv[j]; }
+    }
+    if (threadIdx.x == 0) {
+        if (offs) offs[ctot] = dtot;
+        counters[C_FRONT] = ctot; counters[C_NEIGH] = dtot;
+    }
+    if (host) {                                             // all slots, as vgl_k_publish would (callers read more than these two)
+        if (threadIdx.x < C_NSLOTS)
+            host[threadIdx.x] = threadIdx.x == C_FRONT ? (int64_t)ctot : threadIdx.x == C_NEIGH ? dtot : counters[threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) { host[C_NSLOTS] = seq; __threadfence_system(); }
+    }
 }
 
 // scan pass: single workgroup of 1024 threads; exclusive offsets per tile; totals to counters[C_FRONT], counters[C_NEIGH];
-// also terminates the edge-offset array: offs[size] = neighbours.
+// also terminates the edge-offset array: offs[size] = neighbours.  A thread takes eight consecutive tiles per round and loads them before
+// it adds anything (one entry per loop iteration was a chain of 2 x ntiles / 1024 dependent L2 round trips: 19 us for the 8192 tiles of
+// RMAT-24, in every super-step of every frontier-driven algorithm); rounds of 8192 tiles carry their totals forward.  host (optional):
+// all counter slots and then the sequence number go to the pinned mirror from here, instead of from a vgl_k_publish launch of their own.
 constexpr int VGL_SCAN_THREADS = 1024;
+constexpr int VGL_SCAN_PER = 8;
 static __global__ __launch_bounds__(VGL_SCAN_THREADS) void vgl_k_gnf_scan(int64_t ntiles, const int32_t *vt_cnt, const int64_t *vt_deg,
                                                                    int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *counters,
-                                                                   int64_t *offs)
+                                                                   int64_t *offs, volatile int64_t *host, int64_t seq)
 {
     __shared__ int64_t s_c[VGL_SCAN_THREADS / 64], s_d[VGL_SCAN_THREADS / 64];
-    const int64_t per = (ntiles + VGL_SCAN_THREADS - 1) / VGL_SCAN_THREADS;
-    const int64_t lo = min(ntiles, (int64_t)threadIdx.x * per), hi = min(ntiles, lo + per);
-    int64_t c = 0, d = 0;
-    for (int64_t t = lo; t < hi; t++) { c += vt_cnt[t]; d += vt_deg[t]; }
-    const int64_t ci = vgl_wave_incl_add(c), di = vgl_wave_incl_add(d);
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) { s_c[w] = ci; s_d[w] = di; }
-    __syncthreads();
-    int64_t cb = 0, db = 0, ctot = 0, dtot = 0;
+    int64_t ccarry = 0, dcarry = 0;
+    for (int64_t r0 = 0; r0 < ntiles; r0 += (int64_t)VGL_SCAN_THREADS * VGL_SCAN_PER) {
+        const int64_t lo = r0 + (int64_t)threadIdx.x * VGL_SCAN_PER;
+        int32_t cv[VGL_SCAN_PER];
+        int64_t dv[VGL_SCAN_PER];
 #pragma unroll
-    for (int i = 0; i < VGL_SCAN_THREADS / 64; i++) {
-        if (i < w) { cb += s_c[i]; db += s_d[i]; }
-        ctot += s_c[i]; dtot += s_d[i];
-    }
-    int64_t cpre = cb + ci - c, dpre = db + di - d;
-    for (int64_t t = lo; t < hi; t++) {
-        vt_cnt_off[t] = (int32_t)cpre; vt_deg_off[t] = dpre;
-        cpre += vt_cnt[t]; dpre += vt_deg[t];
+        for (int j = 0; j < VGL_SCAN_PER; j++) {            // (the tables have room for ntiles entries only: no vector loads across the end)
+            const bool in = lo + j < ntiles;
+            cv[j] = in ? vt_cnt[lo + j] : 0;
+            dv[j] = in ? vt_deg[lo + j] : 0;
+        }
+        int64_t c = 0, d = 0;
+#pragma unroll
+        for (int j = 0; j < VGL_SCAN_PER; j++) { c += cv[j]; d += dv[j]; }
+        const int64_t ci = vgl_wave_incl_add(c), di = vgl_wave_incl_add(d);
+        __syncthreads();                                    // (s_c / s_d of the round before have been read)
+        if ((threadIdx.x & 63) == 63) { s_c[w] = ci; s_d[w] = di; }
+        __syncthreads();
+        int64_t cb = 0, db = 0, ctot = 0, dtot = 0;
+#pragma unroll
+        for (int i = 0; i < VGL_SCAN_THREADS / 64; i++) {
+            if (i < w) { cb += s_c[i]; db += s_d[i]; }
+            ctot += s_c[i]; dtot += s_d[i];
+        }
+        int64_t cpre = ccarry + cb + ci - c, dpre = dcarry + db + di - d;
+#pragma unroll
+        for (int j = 0; j < VGL_SCAN_PER; j++) {
+            if (lo + j < ntiles) { vt_cnt_off[lo + j] = (int32_t)cpre; vt_deg_off[lo + j] = dpre; }
+            cpre += cv[j]; dpre += dv[j];
+        }
+        ccarry += ctot; dcarry += dtot;
     }
     if (threadIdx.x == 0) {
-        counters[C_FRONT] = ctot; counters[C_NEIGH] = dtot;
-        if (offs) offs[ctot] = dtot;
+        counters[C_FRONT] = ccarry; counters[C_NEIGH] = dcarry;
+        if (offs) offs[ccarry] = dcarry;
+    }
+    if (host) {                                             // what vgl_k_publish does (context.hip)
+        __syncthreads();
+        if (threadIdx.x < C_NSLOTS) host[threadIdx.x] = threadIdx.x == C_FRONT ? ccarry : threadIdx.x == C_NEIGH ? dcarry : counters[threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) { host[C_NSLOTS] = seq; __threadfence_system(); }
     }
 }
 
@@ -169,20 +252,29 @@ static int vgl_gnf_run(vgl_hip_ctx *c, vgl_hip_graph *g, Pred pred, int32_t *ids
                        bool write_ids, bool read_back)
 {
     const int64_t nt = g->nvtiles;
+    // up to 16384 tiles (32 M owned vertices) the count kernel's last workgroup scans (64 tiles per thread at most); beyond that the
+    // 1024-thread scan kernel does.  Either hands F and M to the host itself when they are wanted (read_back) -- the host then has them
+    // while the write pass is still running.
+    const bool fused_scan = nt <= 16384;
+    const int64_t seq = read_back ? vgl_next_seq(c) : 0;
+    volatile int64_t *host = read_back ? (volatile int64_t *)c->h_counters : (volatile int64_t *)nullptr;
     {
         vgl_timed_launch tl(c, "gnf");
         hipLaunchKernelGGL(vgl_k_gnf_count<Pred>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows, g->row_begin,
-                           g->out.rowptr, g->vt_cnt, g->vt_deg, front_bytes, visited_bytes, flags_out);
+                           g->out.rowptr, g->vt_cnt, g->vt_deg, front_bytes, visited_bytes, flags_out,
+                           fused_scan ? g->tickets + 0 * VGL_TICKET_WORDS : (uint32_t *)nullptr, g->vt_cnt_off, g->vt_deg_off, c->d_counters, offs,
+                           host, seq);
     }
-    hipLaunchKernelGGL(vgl_k_gnf_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, nt, g->vt_cnt, g->vt_deg, g->vt_cnt_off,
-                       g->vt_deg_off, c->d_counters, offs);
+    if (!fused_scan)
+        hipLaunchKernelGGL(vgl_k_gnf_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, nt, g->vt_cnt, g->vt_deg, g->vt_cnt_off,
+                           g->vt_deg_off, c->d_counters, offs, host, seq);
     if (write_ids) {
         vgl_timed_launch tl(c, "gnf");
         hipLaunchKernelGGL(vgl_k_gnf_write<Pred>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows, g->row_begin,
                            g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, ids, offs);
     }
     VGL_HIP_TRY(hipGetLastError());
-    if (read_back) VGL_TRY(vgl_read_counters(c, false));
+    if (read_back) VGL_TRY(vgl_wait_counters(c, seq));
     return 0;
 }
 #endif
