@@ -44,3 +44,30 @@ def test_bench_sharded_pagerank_and_cc_legs_one_rank(ctx):
     pr, cc = line["pagerank_uniform16_sharded"], line["cc_rmat_symmetrised_sharded"]
     assert abs(pr["ranks_sum"] - 1.0) < 1e-3 and pr["teps"] > 0 and pr["shard_edges"] == (1 << 16) * 32
     assert cc["labels_idempotent"] and cc["hook_passes"] >= 1 and cc["shard_edges"] == cc["stored_edges"] == (1 << 15) * 32
+
+
+def test_bench_single_gpu_line_contract(ctx):
+    """the one-GPU bench line at a small scale (RMAT-18, CPU baseline on, SSSP leg on): one JSON line on stdout with the contract's keys,
+    the roofline object of the dominant kernel measured with HIP events, the CPU port timed beside it, and the built-in verification"""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "18", "--steps", "4", "--warmup", "1", "--cpu-sources", "2",
+                          "--no-pr-cc"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [x for x in out.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and "workload" in line["config"] and line["data"].startswith("synthetic")
+    r = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-4
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    v = line["verified"]
+    assert v["bfs_do_equals_top_down"] and v["bfs_equals_cpu_oracle"] and v["sssp_equals_cpu_oracle"]
+    td = line["bfs_top_down_reference_algorithm"]
+    assert td["ms"] > 0 and td["blocked_levels"]["ms"] > 0
