@@ -24,7 +24,16 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         ref_levels,_ = O.bfs_top_down(rowptr, adj, source)
         for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
             assert (api.bfs(g, source, mode)[0].cpu().numpy() == ref_levels).all(), f"bfs {mode}"
+        if seed % 2:                                       # blocked top-down levels (every level: share 0), pull / direction-optimising SSSP
+            g.prepare_blocked_bfs()
+            os.environ["VGL_BFS_BLOCKED_SHARE"] = "0" if seed % 4 == 1 else "0.1"
+            for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+                assert (api.bfs(g, source, mode)[0].cpu().numpy() == ref_levels).all(), f"blocked bfs {mode}"
+            os.environ.pop("VGL_BFS_BLOCKED_SHARE", None)
         ref_dist,_ = O.sssp_bellman_ford(rowptr, adj, w, source)
+        for mode in (api.SSSP_PULL, api.SSSP_DIRECTION_OPT):
+            d,_ = api.sssp(g, w_d, source, mode)
+            assert (d.cpu().numpy().view(np.int32) == ref_dist.view(np.int32)).all(), f"sssp {mode}"
         for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
             d,_ = api.sssp(g, w_d, source, mode, delta=float(rng.choice([0.5, 7.0, 16.0, 40.0])))
             assert (d.cpu().numpy().view(np.int32) == ref_dist.view(np.int32)).all(), f"sssp {mode}"
