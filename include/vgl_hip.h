@@ -188,7 +188,9 @@ int vgl_hip_sswp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capaciti
                      float *d_widths, vgl_hip_sssp_stats *stats);
 /* The pull steps work on a blocked copy of (outgoing adjacency, edge values) -- vgl_blocked.h -- built once per (graph, weights)
  * like the reference's graph import and reusable for any number of sources; vgl_hip_sssp_run / vgl_hip_sswp_run with mode PULL or
- * DIRECTION_OPT = create + run + destroy.  mode: VGL_HIP_SSSP_PULL or VGL_HIP_SSSP_DIRECTION_OPT. */
+ * DIRECTION_OPT = create + run + destroy.  mode: VGL_HIP_SSSP_PULL or VGL_HIP_SSSP_DIRECTION_OPT.
+ * A plan holds a reordered COPY of the edge values: the caller must not rewrite d_weights in place while the plan exists (rebuild the plan
+ * after set_all_random or any other writer), and must destroy the plan before the graph handle; a plan is refused for any other handle. */
 typedef struct vgl_hip_sssp_pull_plan vgl_hip_sssp_pull_plan;
 int vgl_hip_sssp_pull_plan_create(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan **out);
 int vgl_hip_sssp_pull_plan_destroy(vgl_hip_ctx *ctx, vgl_hip_sssp_pull_plan *plan);
@@ -334,6 +336,77 @@ int vgl_hip_apply_pairs_u32(vgl_hip_ctx *ctx, int parts, int64_t stride, int ski
                             void *d_values, int *changed);
 /* in-degree without self loops from an out-CSR shard (adds into d_indeg; zero it first; allreduce(sum) across shards) */
 int vgl_hip_indegree_noloops_add(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_indeg);
+
+/* ---- multi-GPU behind the boundary: communicator, exchanges and the super-step loops (one process per GPU).
+ *      Replaces GraphAbstractions::exchange_vertices_array (common/graph_abstractions.h:157-168) and its MPI implementation
+ *      common/mpi_exchange.hpp:110-150 (EXCHANGE_RECENTLY_CHANGED), :156-187 (EXCHANGE_ALL with a merge operator), :222-271
+ *      (EXCHANGE_PRIVATE_DATA); the library_data MPI rank / size of vgl_runtime/helpers/library_data/library_data.h.
+ *      Transport RCCL: collectives over xGMI, enqueued on the context's stream -- kernels and collectives of a super-step are
+ *      stream-ordered, the host waits only where it has to decide something (one pinned-memory poll per super-step).
+ *      Transport HOSTED: the same collectives staged through a POSIX shared-memory segment; ranks are processes of one host and
+ *      may share one GPU (RCCL refuses two ranks on one device) -- rehearsals and multi-rank tests on fewer GPUs than ranks. ---- */
+typedef struct vgl_hip_comm vgl_hip_comm;
+#define VGL_HIP_COMM_ID_BYTES 128
+#define VGL_HIP_COMM_RCCL 0
+#define VGL_HIP_COMM_HOSTED 1
+/* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any means (file, socket, MPI, torch store) */
+int vgl_hip_comm_unique_id(void *id_out);
+int vgl_hip_comm_create(vgl_hip_ctx *ctx, int rank, int world, const void *unique_id, vgl_hip_comm **out);
+/* name: shared-memory object name common to the ranks ("/vgl_job42"); slot_bytes: staging capacity per rank (larger payloads go in pieces) */
+int vgl_hip_comm_create_hosted(vgl_hip_ctx *ctx, int rank, int world, const char *name, size_t slot_bytes, vgl_hip_comm **out);
+int vgl_hip_comm_destroy(vgl_hip_comm *comm);
+int vgl_hip_comm_info(vgl_hip_comm *comm, int *rank, int *world, int *transport);
+int vgl_hip_comm_barrier(vgl_hip_comm *comm);            /* drains the stream, meets the other ranks */
+/* EXCHANGE_ALL with the merge operators the algorithms use (shortest_paths.hpp:136-141 min_op; widest paths: max; pr.hpp:58 sum):
+ * in-place all-reduce of a replicated device array, asynchronous on the context's stream */
+int vgl_hip_exchange_allreduce_min_i32(vgl_hip_comm *comm, int32_t *d_values, int64_t n);
+int vgl_hip_exchange_allreduce_min_f32(vgl_hip_comm *comm, float *d_values, int64_t n);
+int vgl_hip_exchange_allreduce_max_f32(vgl_hip_comm *comm, float *d_values, int64_t n);
+int vgl_hip_exchange_allreduce_sum_i32(vgl_hip_comm *comm, int32_t *d_values, int64_t n);
+int vgl_hip_exchange_allreduce_sum_i64(vgl_hip_comm *comm, int64_t *d_values, int64_t n);
+int vgl_hip_exchange_allreduce_sum_f32(vgl_hip_comm *comm, float *d_values, int64_t n);
+int vgl_hip_exchange_allreduce_sum_f64(vgl_hip_comm *comm, double *d_values, int64_t n);
+/* d_recv[p * bytes .. ) = rank p's d_send; asynchronous */
+int vgl_hip_exchange_allgather(vgl_hip_comm *comm, const void *d_send, void *d_recv, int64_t bytes_per_rank);
+/* EXCHANGE_PRIVATE_DATA (mpi_exchange.hpp:222-271, MPI_Allgatherv in place): rank p owns elements [bounds[p], bounds[p+1]) of the
+ * replicated array (host array of world+1 entries, the same on every rank); afterwards every rank holds every owner's slice */
+int vgl_hip_exchange_allgather_slices(vgl_hip_comm *comm, void *d_array, const int64_t *bounds_host, int elem_bytes);
+/* every rank ends with the OR of all ranks' bitmaps (in place): all-to-all of the word slices, OR, all-gather -- 2 x words x 8 bytes per
+ * rank instead of world x words x 8 */
+int vgl_hip_exchange_bitmap_or(vgl_hip_comm *comm, uint64_t *d_bits, int64_t words);
+/* EXCHANGE_RECENTLY_CHANGED in one call (diff -> counts -> lists -> merge; mpi_exchange.hpp:110-150): d_values is this rank's copy after its
+ * super-step, d_before the copy before it; afterwards d_values holds the merge (min or max on the 4-byte patterns of non-negative values)
+ * of every rank's changes.  One small all-gather when every rank changed at most 2048 entries (the counts ride in the payload), a second,
+ * sized one otherwise, the whole-array all-reduce when some rank changed more than n / (2 world).  *changed_anywhere (synchronises): 1 if
+ * any rank changed anything -- the loop condition of shortest_paths.hpp:143-152 without a flag reduction. */
+int vgl_hip_exchange_changed_u32(vgl_hip_comm *comm, int32_t n, const void *d_before, void *d_values, int take_min, int *changed_anywhere);
+
+/* The super-step loops over edge-cut shards (g owns rows [row_begin, row_end) of a graph of V vertices; vertex arrays are replicated,
+ * V entries on every rank).  comm == NULL or a world of one: no exchange, same code path.  Results are bit-identical to the single-GPU
+ * drivers (fixed points / owner-computed sums).
+ *   bfs : direction-optimising (mode DIRECTION_OPT needs the incoming CSR of the owned rows and global_edges = E of the whole graph) or
+ *         top-down; every rank must own a 64-aligned row range.  d_levels is complete on the OWNED rows when it returns; pass
+ *         gather_levels != 0 to have the slices all-gathered (EXCHANGE_PRIVATE_DATA) so that every rank holds all levels.
+ *   sssp / sswp : all-active push over the owned rows + changed-entries exchange (min / max)
+ *   cc  : Shiloach-Vishkin hook over the owned rows + changed-entries exchange (min) + replicated pointer jumping
+ *   pr  : owner-computes pull + all-gather of the owned slices; mode as vgl_hip_pr_run_mode, AUTO is resolved from the GLOBAL edge count
+ *         and the GLOBAL longest row so that every rank takes the same path */
+int vgl_hip_bfs_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, int32_t source, int mode, int64_t global_edges,
+                            int gather_levels, int32_t *d_levels, vgl_hip_bfs_stats *stats);
+int vgl_hip_sssp_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, const float *d_weights, int32_t source,
+                             float *d_dist, vgl_hip_sssp_stats *stats);
+int vgl_hip_sswp_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, const float *d_capacities, int32_t source,
+                             float *d_widths, vgl_hip_sssp_stats *stats);
+int vgl_hip_cc_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc_stats *stats);
+int vgl_hip_pr_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, int iterations, int mode, float *d_ranks,
+                           vgl_hip_pr_stats *stats);
+/* exchange statistics of the last *_run_sharded on this communicator: collectives issued, bytes this rank received, super-steps that
+ * used pair lists / the whole-array all-reduce / id lists (BFS) */
+typedef struct {
+    int64_t collectives, bytes_received;
+    int32_t list_steps, dense_steps, sparse_levels, reserved;
+} vgl_hip_exchange_stats;
+int vgl_hip_comm_stats(vgl_hip_comm *comm, vgl_hip_exchange_stats *out);
 
 /* ---- kernel timing hooks for bench.py's roofline line: when enabled every launch of the named dominant kernels
  *      is bracketed by hipEvents on the context stream; totals are read back afterwards. ---- */

@@ -1,0 +1,150 @@
+"""The multi-GPU path behind the C ABI (vgl_hip_comm_*, vgl_hip_exchange_*, vgl_hip_*_run_sharded) on the one-GPU box:
+  * a world of one without a communicator: the sharded loops reproduce the fused single-GPU results (same code path, no exchange);
+  * ONE rank with a real RCCL communicator and VGL_SHARD_FORCE_COLLECTIVES=1: every collective of every driver and every exported
+    exchange runs through RCCL (ncclAllReduce / AllGather / AllToAll / Broadcast groups on the context's stream);
+  * TWO and FOUR ranks sharing the GPU through the host-staged transport (RCCL refuses two ranks on one device): the genuine N > 1
+    protocol -- foreign pair lists merged on the device, slices from other owners, id lists of other ranks -- with real kernels,
+    equal and edge-balanced row ranges, bit-identical to the single-GPU results.
+(world-size-2 semantics of the earlier Python protocol model stay covered on CPU with gloo, tests/test_distributed_cpu.py.)"""
+import os
+import subprocess
+import sys
+import uuid
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HELPER = os.path.join(ROOT, "tests", "sharded_ranks.py")
+
+
+def _run_ranks(transport, world, env_extra=None, timeout=900):
+    token = ("/vgl_t_%s" % uuid.uuid4().hex[:12]) if transport == "hosted" else os.path.join("/tmp", "vgl_id_%s" % uuid.uuid4().hex[:12])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, HELPER, transport, str(r), str(world), token], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        if transport != "hosted" and os.path.exists(token):
+            os.remove(token)
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "SHARDED_RANK_OK" in o, "rank %d failed:\n%s\n%s" % (r, o[-3000:], e[-3000:])
+
+
+def test_sharded_loops_world_of_one_equal_fused(ctx):
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import sharded as vs
+    scale, ef, seed = 14, 16, 5
+    V, E = 1 << scale, (1 << scale) * ef
+    src, dst = ctx.gen_rmat(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True, renumber="total")
+    w = ctx.gather_u32(g.perm, ctx.gen_weights(E, seed))
+    source = int(torch.argmax(g.out_rowptr[1:] - g.out_rowptr[:-1]))
+    ref, ref_st = api.bfs(g, source, api.BFS_DIRECTION_OPT, raw=True)
+    for mode in (api.BFS_DIRECTION_OPT, api.BFS_TOP_DOWN):
+        levels, st = vs.bfs_run_sharded(g, None, source, mode, global_edges=E)
+        assert torch.equal(levels, ref)
+        assert st["levels"] == ref_st["levels"] and st["discovered"] == ref_st["discovered"]
+    assert st["bu_steps"] == 0
+    d, st = vs.sssp_run_sharded(g, None, w, source)
+    d_ref, st_ref = api.sssp(g, w, source, api.SSSP_ALL_ACTIVE, raw=True)
+    assert torch.equal(d.view(torch.int32), d_ref.view(torch.int32)) and st["iterations"] == st_ref["iterations"]
+    wd, _ = vs.sswp_run_sharded(g, None, w, source)
+    assert torch.equal(wd.view(torch.int32), api.sswp(g, w, source, raw=True)[0].view(torch.int32))
+    comp, st = vs.cc_run_sharded(g, None)
+    comp_ref, st_ref = api.connected_components(g, raw=True)
+    assert torch.equal(comp, comp_ref) and st["hook_passes"] == st_ref["hook_passes"]
+    for mode in (api.PR_EXACT_ORDER, api.PR_BLOCKED):
+        ranks, _ = vs.pr_run_sharded(g, None, 4, mode)
+        assert torch.equal(ranks.view(torch.int32), api.page_rank(g, 4, raw=True, mode=mode)[0].view(torch.int32))
+    # argument checks fail loudly
+    from vectorgraphlibrary_amd.lib import VglHipError
+    with pytest.raises(VglHipError):
+        vs.bfs_run_sharded(g, None, V, api.BFS_TOP_DOWN)
+    with pytest.raises(VglHipError):
+        vs.bfs_run_sharded(g.shard(0, V // 2), None, source, api.BFS_TOP_DOWN)        # a world of one must own all rows
+
+
+def test_sharded_loops_one_rank_rccl_through_the_c_abi(ctx):
+    _run_ranks("rccl", 1, {"VGL_SHARD_FORCE_COLLECTIVES": "1"})
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_loops_ranks_sharing_the_gpu_hosted_transport(ctx, world):
+    _run_ranks("hosted", world)
+
+
+def test_pagerank_auto_is_resolved_globally(ctx):
+    """AUTO must not be resolved per shard.  A shard that alone would pick the blocked sum (>= 2^25 stored edges... here forced
+    through VGL_PR_MODE) and the env override are validated: anything but 0 / 1 is refused."""
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import sharded as vs
+    from vectorgraphlibrary_amd.lib import VglHipError
+    scale, ef = 12, 8
+    V = 1 << scale
+    src, dst = ctx.gen_uniform(scale, ef, 3)
+    g = api.Graph.from_coo(ctx, V, src, dst)
+    for bad in ("2", "x", "10"):
+        os.environ["VGL_PR_MODE"] = bad
+        try:
+            with pytest.raises(VglHipError):
+                vs.pr_run_sharded(g, None, 2, api.PR_AUTO)
+            with pytest.raises(VglHipError):
+                api.page_rank(g, 2, raw=True)
+        finally:
+            os.environ.pop("VGL_PR_MODE")
+    os.environ["VGL_PR_MODE"] = "1"
+    try:
+        a, _ = vs.pr_run_sharded(g, None, 3, api.PR_AUTO)
+    finally:
+        os.environ.pop("VGL_PR_MODE")
+    b, _ = api.page_rank(g, 3, raw=True, mode=api.PR_BLOCKED)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_apply_pairs_clamps_an_overflowing_list(ctx):
+    """diff_to_pairs keeps counting past its capacity; the merge must never read past a list's slot.  parts > 1, no skipped part,
+    min and max, checked against numpy."""
+    import ctypes as C
+    import numpy as np
+    from vectorgraphlibrary_amd import lib as L
+    from vectorgraphlibrary_amd.api import _ptr
+    n, cap, parts = 5000, 100, 3
+    rng = np.random.default_rng(7)
+    for take_min in (1, 0):
+        base = np.full(n, 10 ** 6 if take_min else 0, dtype=np.int32)
+        values = torch.from_numpy(base.copy()).to(ctx.device)
+        lists = torch.zeros(parts * (1 + 2 * cap), dtype=torch.int32, device=ctx.device)
+        want = base.copy()
+        for p in range(parts):
+            after_np = base.copy()
+            k = 40 if p == 0 else 400                                  # parts 1, 2 overflow the capacity of 100 pairs
+            idx = rng.choice(n, k, replace=False)
+            after_np[idx] = rng.integers(1, 1000, k)
+            out = lists[p * (1 + 2 * cap):(p + 1) * (1 + 2 * cap)]
+            before = torch.from_numpy(base).to(ctx.device)
+            after = torch.from_numpy(after_np).to(ctx.device)
+            L.check(ctx.L.vgl_hip_diff_to_pairs_u32(ctx.h, n, _ptr(before), _ptr(after), cap, _ptr(out)))
+            ctx.sync()
+            got = out.cpu().numpy()
+            assert got[0] == k
+            kept = min(k, cap)
+            pi, pv = got[1:1 + 2 * kept:2], got[2:2 + 2 * kept:2]
+            assert (after_np[pi] == pv).all() and len(set(pi.tolist())) == kept
+            if take_min:
+                np.minimum.at(want, pi, pv)
+            else:
+                np.maximum.at(want, pi, pv)
+        # poison what follows the last list: a count that is not clamped would read it
+        ch = C.c_int()
+        L.check(ctx.L.vgl_hip_apply_pairs_u32(ctx.h, parts, 1 + 2 * cap, -1, _ptr(lists), take_min, n, _ptr(values), C.byref(ch)))
+        assert ch.value == 1
+        assert (values.cpu().numpy() == want).all()

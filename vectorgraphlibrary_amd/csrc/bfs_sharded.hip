@@ -1,0 +1,265 @@
+// bfs_sharded.hip -- breadth-first search over edge-cut shards behind the C ABI (one process per GPU).  The operators are those of
+// algorithms/bfs/bfs.hpp:12-49, the switch rule gpu_change_state (change_state.hpp:100-141, ALPHA 15 / BETA 18) evaluated by every
+// rank on the same all-gathered counters; the partition is the reference's contiguous row ranges (vect_csr/get_api.hpp:66-94).
+//
+// What lives where (V vertices, rank r owns the 64-aligned rows [b_r, b_r+1)):
+//   levels            V entries per rank, AUTHORITATIVE on the owned rows only (elsewhere: this rank's private "already reported" marks)
+//   visited bitmap    authoritative on the owned words only -- nobody rewrites V bits per level
+//   frontier bitmap   replicated (bottom-up probes test arbitrary in-neighbours): it is what the exchange of a level produces
+// Per level, all on the context's stream, ONE host wait (the 2 P counters that ride behind the bitmap in the same RCCL group):
+//   bottom-up  probe + deferred pass over the owned unvisited rows -> owned words of the next frontier; owned visited |= them;
+//              all-gather of the owned slices (V/8 bytes in total)
+//   top-down   owned frontier rows expand into a candidate bitmap (any vertex); all-to-all of the candidate slices, the owner ORs
+//              what it received, masks with its visited words, writes levels; all-gather of the owned slices (2 V/8 bytes per rank)
+//   tiny top-down levels (frontier <= 4096): the candidates travel as id lists (16 KiB per rank) instead of bitmaps; the owner resolves
+//              its ids exactly, the others only mark them in their frontier copy -- a superset by already-visited vertices, which no
+//              probe can tell from the exact set (an unvisited vertex has no in-neighbour visited before the current level).
+#include "vgl_comm.h"
+#include <cstdlib>
+
+constexpr int VGL_SHARD_NB = 512;              // workgroups of the owned-range passes (their partial counters are folded by the last one)
+
+// owned words: candidates (OR of `parts` inputs) minus visited = the owned part of the next frontier.  WALK: the new vertices get
+// their level and their out-degrees are summed (top-down levels); bottom-up levels wrote the levels themselves and need no degree sum.
+template <bool WALK>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_shard_resolve(int64_t w0, int64_t nw, int parts, const uint64_t *in, int64_t part_stride, int64_t in_off,
+                                                                 uint64_t *visited, uint64_t *front_new, int32_t *levels, int32_t level,
+                                                                 const int64_t *rowptr, int32_t row_begin, int32_t row_end, int64_t *partials,
+                                                                 uint32_t *ticket, int64_t *counts_out)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    int64_t cnt = 0, deg = 0;
+    const int lane = vgl_lane();
+    const int64_t nround = (nw + 63) & ~(int64_t)63;
+    for (int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; wi < nround; wi += (int64_t)gridDim.x * VGL_BLOCK) {
+        uint64_t w = 0;
+        if (wi < nw) {
+            for (int p = 0; p < parts; p++) w |= in[(int64_t)p * part_stride + in_off + wi];
+            const uint64_t vis = visited[w0 + wi];
+            w &= ~vis;
+            if (w) visited[w0 + wi] = vis | w;
+            front_new[w0 + wi] = w;
+            cnt += __popcll(w);
+        }
+        if (WALK) {
+            unsigned long long todo = __ballot(w != 0);
+            while (todo) {                                       // the wavefront walks its non-zero words together: one coalesced row of levels each
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const uint64_t ww = __shfl(w, l);
+                const int64_t v = ((w0 + wi - lane + l) << 6) + lane;
+                if (((ww >> lane) & 1ULL) && v < row_end) {
+                    levels[v] = level;
+                    const int64_t r = v - row_begin;
+                    deg += rowptr[r + 1] - rowptr[r];
+                }
+            }
+        }
+    }
+    cnt = vgl_block_reduce_add(cnt, s64);
+    deg = vgl_block_reduce_add(deg, s64);
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) dep = vgl_put_agent(partials + 2 * blockIdx.x, cnt) ^ vgl_put_agent(partials + 2 * blockIdx.x + 1, deg);
+    if (!vgl_last_block(ticket, dep)) return;
+    int64_t a = 0, b = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += VGL_BLOCK) { a += vgl_load_agent(partials + 2 * i); b += vgl_load_agent(partials + 2 * i + 1); }
+    a = vgl_block_reduce_add(a, s64);
+    b = vgl_block_reduce_add(b, s64);
+    if (threadIdx.x == 0) { counts_out[0] = a; counts_out[1] = b; counts_out[2] = 0; counts_out[3] = 0; }
+}
+
+// `parts` id lists (stride 1 + cap): owned ids are claimed on the visited bitmap (a vertex reported by several ranks is taken once), get
+// their level and count; every listed id is marked in the frontier copy.  A list that overflowed (count > cap) voids the level's sparse
+// exchange for everybody: counts_out[2] = 1 and nothing is touched.
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_shard_apply_ids(int parts, int32_t cap, const int32_t *lists, int32_t V, int32_t row_begin, int32_t row_end,
+                                                                   uint64_t *visited, uint64_t *front_new, int32_t *levels, int32_t level,
+                                                                   const int64_t *rowptr, int64_t *partials, uint32_t *ticket, int64_t *counts_out)
+{
+    __shared__ int64_t s64[VGL_WAVES];
+    bool overflow = false;
+    for (int p = 0; p < parts; p++) overflow |= lists[(int64_t)p * (1 + cap)] > cap;      // the same answer in every workgroup
+    int64_t cnt = 0, deg = 0;
+    const int64_t total = overflow ? 0 : (int64_t)parts * cap;
+    for (int64_t t = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * VGL_BLOCK) {
+        const int p = (int)(t / cap), i = (int)(t % cap);
+        const int32_t *list = lists + (int64_t)p * (1 + cap);
+        if (i >= list[0]) continue;
+        const int32_t v = list[1 + i];
+        if (v < 0 || v >= V) continue;
+        const unsigned long long bit = 1ULL << (v & 63);
+        if (v >= row_begin && v < row_end) {
+            const unsigned long long old = atomicOr((unsigned long long *)&visited[v >> 6], bit);
+            if (old & bit) continue;
+            levels[v] = level;
+            cnt++;
+            deg += rowptr[v - row_begin + 1] - rowptr[v - row_begin];
+        }
+        atomicOr((unsigned long long *)&front_new[v >> 6], bit);
+    }
+    cnt = vgl_block_reduce_add(cnt, s64);
+    deg = vgl_block_reduce_add(deg, s64);
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) dep = vgl_put_agent(partials + 2 * blockIdx.x, cnt) ^ vgl_put_agent(partials + 2 * blockIdx.x + 1, deg);
+    if (!vgl_last_block(ticket, dep)) return;
+    int64_t a = 0, b = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += VGL_BLOCK) { a += vgl_load_agent(partials + 2 * i); b += vgl_load_agent(partials + 2 * i + 1); }
+    a = vgl_block_reduce_add(a, s64);
+    b = vgl_block_reduce_add(b, s64);
+    if (threadIdx.x == 0) { counts_out[0] = a; counts_out[1] = b; counts_out[2] = overflow ? 1 : 0; counts_out[3] = 0; }
+}
+
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_shard_bfs_init(int64_t words, int32_t source, uint64_t *visited, uint64_t *front, uint64_t *front_new,
+                                                                  uint32_t *ticket)
+{
+    for (int64_t w = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; w < words; w += (int64_t)gridDim.x * VGL_BLOCK) {
+        const uint64_t bit = (w == (source >> 6)) ? (1ULL << (source & 63)) : 0ULL;
+        visited[w] = bit; front[w] = bit; front_new[w] = 0;
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < VGL_TICKET_WORDS; i += VGL_BLOCK) ticket[i] = 0;
+}
+
+extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g, int32_t source, int mode, int64_t global_edges,
+                                       int gather_levels, int32_t *d_levels, vgl_hip_bfs_stats *stats)
+{
+    if (!c || !g || !d_levels) VGL_FAIL("bfs_run_sharded: null argument");
+    if (mode != VGL_HIP_BFS_TOP_DOWN && mode != VGL_HIP_BFS_DIRECTION_OPT) VGL_FAIL("bfs_run_sharded: unknown mode");
+    if (mode == VGL_HIP_BFS_DIRECTION_OPT && !g->in.rowptr) VGL_FAIL("bfs_run_sharded: direction-optimising mode needs the incoming CSR of the owned rows");
+    const int32_t V = g->V;
+    if (source < 0 || source >= V) VGL_FAIL("bfs_run_sharded: source vertex out of range");
+    if ((g->row_begin & 63) || (g->row_end != V && (g->row_end & 63))) VGL_FAIL("bfs_run_sharded: the owned row range must start and end on multiples of 64");
+    // (the solo communicator of sharded.hip, inlined: a world of one needs only the hand-over buffers)
+    vgl_hip_comm local;
+    vgl_hip_comm *m = given;
+    if (!m) {
+        m = &local;
+        m->ctx = c;
+        VGL_HIP_TRY(hipMalloc((void **)&m->d_small, sizeof(int64_t) * VGL_COMM_SMALL));
+        VGL_HIP_TRY(hipHostMalloc((void **)&m->h_small, sizeof(int64_t) * (VGL_COMM_SMALL + 8), hipHostMallocDefault));
+        for (int i = 0; i < VGL_COMM_SMALL + 8; i++) m->h_small[i] = 0;
+    }
+    struct cleanup {
+        vgl_hip_comm *l; bool on;
+        ~cleanup()
+        {
+            if (!on) return;
+            hipStreamSynchronize(l->ctx->stream);
+            for (int i = 0; i < VGL_COMM_SCRATCH_SLOTS; i++) if (l->scratch[i]) hipFree(l->scratch[i]);
+            hipFree(l->d_small); hipHostFree(l->h_small);
+        }
+    } guard{&local, given == nullptr};
+    if (m->ctx != c) VGL_FAIL("bfs_run_sharded: the communicator belongs to another context");
+    const int P = m->world, rank = m->rank;
+    if (P == 1 && (g->row_begin != 0 || g->row_end != V)) VGL_FAIL("bfs_run_sharded: a world of one must own all rows");
+    if (P > 64) VGL_FAIL("bfs_run_sharded: at most 64 ranks");
+    m->stats = {0, 0, 0, 0, 0, 0};
+    const int64_t words = vgl_ceil_div(V, 64);
+    const int64_t w0 = g->row_begin >> 6, nw = vgl_ceil_div(g->row_end, 64) - w0;
+    const int64_t *bounds = nullptr;
+    std::vector<int64_t> word_bb((size_t)P + 1, 0), level_bb((size_t)P + 1, 0);
+    bool equal = true;
+    const bool active = vgl_comm_active(m);
+    if (active) {
+        VGL_TRY(vgl_comm_row_bounds(m, g, &bounds));
+        for (int p = 0; p <= P; p++) {
+            if (p < P && (bounds[p] & 63)) VGL_FAIL("bfs_run_sharded: every rank's first row must be a multiple of 64");
+            word_bb[(size_t)p] = (p == P ? words : bounds[p] / 64) * 8;
+            level_bb[(size_t)p] = bounds[p] * 4;
+        }
+        for (int p = 0; p < P; p++) equal = equal && (word_bb[(size_t)p + 1] - word_bb[(size_t)p]) == (int64_t)(words / P) * 8;
+        equal = equal && words % P == 0;
+    }
+    int32_t sparse_cap = 4096;
+    if (const char *e = getenv("VGL_SHARD_SPARSE_CAP")) sparse_cap = std::max(0, atoi(e));
+    if (!active) sparse_cap = 0;
+
+    // one block of scratch, carved: visited | front A | front B | candidates | tickets | partials | counts (mine, all) | id lists
+    const size_t bm = sizeof(uint64_t) * (size_t)(words + 1);
+    const size_t lists_bytes = sizeof(int32_t) * (size_t)(1 + sparse_cap) * (size_t)(P + 1);
+    const size_t fixed = sizeof(uint32_t) * VGL_TICKET_WORDS + sizeof(int64_t) * (2 * VGL_SHARD_NB + 4 + 4 * (size_t)P) + 256;
+    char *base = nullptr;
+    VGL_TRY(vgl_comm_scratch(m, 3, 4 * bm + fixed + lists_bytes + 64, (void **)&base));
+    uint64_t *visited = reinterpret_cast<uint64_t *>(base), *front = visited + (words + 1), *front_new = front + (words + 1), *cand = front_new + (words + 1);
+    int64_t *partials = reinterpret_cast<int64_t *>(cand + (words + 1));
+    int64_t *my_counts = partials + 2 * VGL_SHARD_NB, *all_counts = my_counts + 4;
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(all_counts + 4 * (size_t)P);
+    int32_t *my_list = reinterpret_cast<int32_t *>(ticket + VGL_TICKET_WORDS + 16), *all_lists = my_list + (1 + sparse_cap);
+    uint64_t *recv = nullptr;
+    if (active) VGL_TRY(vgl_comm_scratch(m, 4, sizeof(uint64_t) * (size_t)(equal ? words : words * P), (void **)&recv));
+
+    VGL_TRY(vgl_hip_bfs_init(c, V, source, d_levels));
+    hipLaunchKernelGGL(vgl_k_shard_bfs_init, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, vgl_ceil_div(words, VGL_BLOCK)))), dim3(VGL_BLOCK), 0,
+                       c->stream, words, source, visited, front, front_new, ticket);
+    VGL_HIP_TRY(hipGetLastError());
+
+    vgl_hip_bfs_stats st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool direction_opt = mode == VGL_HIP_BFS_DIRECTION_OPT;
+    const int64_t E = global_edges > 0 ? global_edges : g->out.edges;
+    const int64_t factor = std::max<int64_t>(1, (E / V) / 2);                   // change_state.hpp:104
+    int64_t F = 1, M = 0, prevF = 0, visited_total = 0;
+    bool bottom_up = false;
+    const unsigned nb_own = (unsigned)std::max<int64_t>(1, std::min<int64_t>(VGL_SHARD_NB, vgl_ceil_div(nw, VGL_BLOCK)));
+    int64_t h_counts[4 * 64];
+    for (int32_t level = 1;; level++) {
+        visited_total += F;
+        st.levels++; st.frontier_total += F;
+        if (direction_opt) {                                                    // gpu_change_state on the frontier about to be expanded
+            if (!bottom_up) {
+                if (F > prevF && M >= ((V - visited_total) * factor + V) / 15) bottom_up = true;
+            } else if (F <= prevF && F < ((V - visited_total) * factor + V) / (factor * 18)) bottom_up = false;
+        }
+        prevF = F;
+        bool exchanged_sparse = false;
+        if (bottom_up) {
+            // owned unvisited rows look for a parent in the replicated frontier; the owned words of front_new = what they found
+            int64_t found = 0, probed = 0;
+            VGL_TRY(vgl_hip_bfs_step_bottom_up(c, g, d_levels, level, visited, front, front_new, stats ? &found : nullptr, stats ? &probed : nullptr));
+            st.bu_steps++; st.bu_edges += probed; st.bu_found += found; st.edges_examined += probed;
+            hipLaunchKernelGGL(vgl_k_shard_resolve<false>, dim3(nb_own), dim3(VGL_BLOCK), 0, c->stream, w0, nw, 1, (const uint64_t *)front_new, (int64_t)0, w0,
+                               visited, front_new, d_levels, level + 1, g->out.rowptr, g->row_begin, g->row_end, partials, ticket, my_counts);
+        } else {
+            int64_t Fl = 0, Ml = 0;
+            VGL_TRY(vgl_hip_bfs_step_top_down_bits(c, g, d_levels, level, visited, front, cand, &Fl, &Ml));
+            st.td_steps++; st.td_frontier += Fl; st.td_edges += Ml; st.edges_examined += Ml;
+            if (sparse_cap > 0 && F <= sparse_cap) {
+                VGL_TRY(vgl_hip_bitmap_to_ids(c, words, cand, sparse_cap, my_list));
+                VGL_TRY(vgl_comm_allgather(m, my_list, all_lists, sizeof(int32_t) * (size_t)(1 + sparse_cap)));
+                VGL_HIP_TRY(hipMemsetAsync(front_new, 0, sizeof(uint64_t) * (size_t)words, c->stream));
+                hipLaunchKernelGGL(vgl_k_shard_apply_ids, dim3(64), dim3(VGL_BLOCK), 0, c->stream, P, sparse_cap, (const int32_t *)all_lists, V, g->row_begin,
+                                   g->row_end, visited, front_new, d_levels, level + 1, g->out.rowptr, partials, ticket, my_counts);
+                VGL_TRY(vgl_comm_allgather(m, my_counts, all_counts, sizeof(int64_t) * 4));
+                VGL_TRY(vgl_comm_read_small(m, all_counts, 4 * P, h_counts));
+                if (h_counts[2] == 0) { exchanged_sparse = true; m->stats.sparse_levels++; }      // (every rank computed the same overflow flag)
+            }
+            if (!exchanged_sparse) {
+                const uint64_t *in = cand;
+                int64_t stride = 0, off = w0;
+                if (active) {
+                    if (equal) { VGL_TRY(vgl_comm_alltoall(m, cand, recv, (words / P) * 8)); in = recv; stride = words / P; off = 0; }
+                    else { VGL_TRY(vgl_comm_allgather(m, cand, recv, words * 8)); in = recv; stride = words; off = w0; }
+                }
+                hipLaunchKernelGGL(vgl_k_shard_resolve<true>, dim3(nb_own), dim3(VGL_BLOCK), 0, c->stream, w0, nw, P, in, stride, off, visited, front_new,
+                                   d_levels, level + 1, g->out.rowptr, g->row_begin, g->row_end, partials, ticket, my_counts);
+            }
+        }
+        VGL_HIP_TRY(hipGetLastError());
+        if (!exchanged_sparse) {
+            // the owned slices of the next frontier and the two counters of every rank, one fused RCCL launch
+            vgl_comm_group_begin(m);
+            if (active) VGL_TRY(vgl_comm_allgatherv_inplace(m, front_new, word_bb.data()));
+            VGL_TRY(vgl_comm_allgather(m, my_counts, all_counts, sizeof(int64_t) * 4));
+            VGL_TRY(vgl_comm_group_end(m));
+            VGL_TRY(vgl_comm_read_small(m, all_counts, 4 * P, h_counts));
+        }
+        F = 0; M = 0;
+        for (int p = 0; p < P; p++) { F += h_counts[4 * p]; M += h_counts[4 * p + 1]; }
+        std::swap(front, front_new);
+        if (F == 0) break;
+    }
+    (void)rank;
+    if (gather_levels && active) VGL_TRY(vgl_comm_allgatherv_inplace(m, d_levels, level_bb.data()));
+    st.discovered = visited_total;
+    st.algorithmic_bytes = 8 * st.edges_examined + 20 * st.td_frontier + 4 * (int64_t)(g->row_end - g->row_begin) + (int64_t)st.bu_steps * (nw * 8);
+    if (stats) *stats = st;
+    return 0;
+}

@@ -6,6 +6,7 @@
 // The loop ends when a hook pass changes nothing; the fixed point comp[v] = min{u : u reaches v} is unique, so labels are
 // bit-identical to the reference under identity (CSR) numbering.  Algorithmic bytes: 8*E + 12*V per hook, 12*V per jump.
 #include "vgl_hip_internal.h"
+#include "vgl_comm.h"
 #include "vgl_blocked.h"
 #include <cstdlib>
 
@@ -164,7 +165,7 @@ static bool vgl_cc_use_blocked(const vgl_hip_graph *g)
     return g->out.edges >= (1LL << 25);
 }
 
-static int vgl_cc_hook_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *comp)
+int vgl_cc_hook_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *comp)
 {
     if (g->out.ntiles == 0) return 0;
     if (vgl_cc_use_blocked(g)) {

@@ -1,6 +1,7 @@
 // graph_frontier.hip -- graph handle (borrowed CSR + derived tile tables), frontier object,
 // generate_new_frontier entry points and the reduce primitive.
 #include "vgl_hip_internal.h"
+#include <atomic>
 #include "vgl_gnf.h"
 #include "vgl_blocked.h"
 
@@ -251,6 +252,8 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     if (out_edges < 0 || in_edges < 0) VGL_FAIL("graph_create: negative edge count");
     VGL_HIP_TRY(hipSetDevice(c->device));
     vgl_hip_graph *g = new vgl_hip_graph();
+    static std::atomic<uint64_t> next_uid{1};
+    g->uid = next_uid.fetch_add(1);
     // a failure below (an allocation, a launch) must not leave the half-built handle and its device arrays behind
     struct rollback { vgl_hip_ctx *c; vgl_hip_graph *g; ~rollback() { if (g) vgl_hip_graph_destroy(c, g); } } undo{c, g};
     g->V = V; g->row_begin = row_begin; g->row_end = row_end; g->nrows = row_end - row_begin;

@@ -12,6 +12,7 @@
 // Algorithmic bytes per iteration: 8*E + 28*V.
 #include "vgl_pull.h"
 #include "vgl_blocked.h"
+#include "vgl_comm.h"
 #include <queue>
 #include <cstdlib>
 
@@ -267,13 +268,16 @@ struct vgl_pr_blk_op {
     }
 };
 
-static int vgl_pr_mode_resolve(const vgl_hip_graph *g, int mode)
+// VGL_PR_MODE=0|1 overrides AUTO (anything else is refused)
+int vgl_pr_env_mode(int mode, int *out)
 {
-    if (mode == VGL_HIP_PR_AUTO) {
-        const char *s = getenv("VGL_PR_MODE");
-        if (s && *s) mode = atoi(s);
-    }
-    return mode;
+    *out = mode;
+    if (mode != VGL_HIP_PR_AUTO) return 0;
+    const char *s = getenv("VGL_PR_MODE");
+    if (!s || !*s) return 0;
+    if ((s[0] != '0' && s[0] != '1') || s[1] != 0) VGL_FAIL("VGL_PR_MODE must be 0 (ordered chain) or 1 (blocked exact sums)");
+    *out = s[0] - '0';
+    return 0;
 }
 
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_max_row(int32_t nrows, const int64_t *rowptr, unsigned long long *out)
@@ -285,16 +289,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_max_row(int32_t nrows, const 
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned long long)__shfl_xor(m, o));
     if (vgl_lane() == 0) s[vgl_wave()] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, max(max(s[0], s[1]), max(s[2], s[3])));
+    if (threadIdx.x == 0) { unsigned long long t = s[0]; for (int w = 1; w < VGL_WAVES; w++) t = max(t, s[w]); atomicMax(out, t); }
 }
 
 // AUTO: blocked for large graphs whose rows are all short (the exact sum then stays well inside 1e-6 of the ordered chain)
-static int vgl_pr_mode_auto(vgl_hip_ctx *c, vgl_hip_graph *g, int *mode)
+int vgl_pr_longest_row(vgl_hip_ctx *c, vgl_hip_graph *g, int64_t *out)
 {
-    *mode = vgl_pr_mode_resolve(g, *mode);
-    if (*mode != VGL_HIP_PR_AUTO) return 0;
-    *mode = VGL_HIP_PR_EXACT_ORDER;
-    if (g->out.edges < (1LL << 25)) return 0;
     if (g->out.max_row < 0) {
         VGL_TRY(vgl_zero_counters(c, C_TMP0, 1));
         hipLaunchKernelGGL(vgl_k_max_row, dim3(vgl_grid3(g->nrows, 1024)), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->out.rowptr,
@@ -302,12 +302,24 @@ static int vgl_pr_mode_auto(vgl_hip_ctx *c, vgl_hip_graph *g, int *mode)
         VGL_TRY(vgl_read_counters(c, false));
         g->out.max_row = c->h_counters[C_TMP0];
     }
-    if (g->out.max_row <= 256) *mode = VGL_HIP_PR_BLOCKED;
+    *out = g->out.max_row;
     return 0;
 }
 
-static int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *indeg, const float *rdeg, float *ranks, float *contrib,
-                            float *ranks_out, int mode)
+static int vgl_pr_mode_auto(vgl_hip_ctx *c, vgl_hip_graph *g, int *mode)
+{
+    VGL_TRY(vgl_pr_env_mode(*mode, mode));
+    if (*mode != VGL_HIP_PR_AUTO) return 0;
+    *mode = VGL_HIP_PR_EXACT_ORDER;
+    if (g->out.edges < (1LL << 25)) return 0;
+    int64_t longest = 0;
+    VGL_TRY(vgl_pr_longest_row(c, g, &longest));
+    if (longest <= 256) *mode = VGL_HIP_PR_BLOCKED;
+    return 0;
+}
+
+int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *indeg, const float *rdeg, float *ranks, float *contrib,
+                     float *ranks_out, int mode)
 {
     VGL_TRY(vgl_pr_mode_auto(c, g, &mode));
     if (mode == VGL_HIP_PR_BLOCKED) {

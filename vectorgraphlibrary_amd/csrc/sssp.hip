@@ -16,6 +16,7 @@
 // is a template parameter -- (min, +) with "smaller is better" for SSSP, (max, min) with "larger is better" for SSWP.  Widths
 // are non-negative too, so the integer atomic-max on the f32 bits is exact; only min / max of inputs occur (no rounding).
 #include "vgl_hip_internal.h"
+#include "vgl_comm.h"
 #include "vgl_blocked.h"
 #include "vgl_gnf.h"
 #include <cfloat>
@@ -257,6 +258,7 @@ struct vgl_hip_sssp_pull_plan {
     vgl_blocked_plan *blk = nullptr;
     const float *weights = nullptr;
     vgl_hip_graph *g = nullptr;
+    uint64_t g_uid = 0;              // the handle's uid: a destroyed graph whose address was reused is not mistaken for the plan's graph
 };
 
 template <class Path>
@@ -265,7 +267,7 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
 {
     auto fail = [&](const char *what) { return vgl_set_error(__FILE__, __LINE__, (std::string(who) + ": " + what).c_str()); };
     if (!c || !g || !d_weights || !d_dist || !plan || !plan->blk) return fail("null argument");
-    if (plan->g != g || plan->weights != d_weights) return fail("the pull plan was built for another graph or weight array");
+    if (plan->g != g || plan->g_uid != g->uid || plan->weights != d_weights) return fail("the pull plan was built for another graph or weight array");
     if (g->row_begin != 0 || g->row_end != g->V) return fail("graph handle must own all rows");
     if (source < 0 || source >= g->V) return fail("source vertex out of range");
     if (mode != VGL_HIP_SSSP_PULL && mode != VGL_HIP_SSSP_DIRECTION_OPT) return fail("unknown mode");
@@ -310,7 +312,7 @@ static int vgl_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d
 {
     if (!c || !g || !d_weights || !out) VGL_FAIL("sssp_pull_plan_create: null argument");
     vgl_hip_sssp_pull_plan *p = new vgl_hip_sssp_pull_plan();
-    p->g = g; p->weights = d_weights;
+    p->g = g; p->g_uid = g->uid; p->weights = d_weights;
     const int rc = vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, d_weights, VGL_BLK_BITS, &p->blk);
     if (rc) { delete p; return rc; }
     *out = p;
@@ -352,6 +354,13 @@ static int vgl_path_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights
     st.algorithmic_bytes = 12 * st.edges_relaxed + 28 * (int64_t)g->V * st.iterations;
     if (stats) *stats = st;
     return 0;
+}
+
+// one all-active push relaxation over the owned rows, enqueued only (the sharded loop learns what changed from its exchange)
+int vgl_sssp_relax_enqueue(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, float *d_values, bool widest)
+{
+    return widest ? vgl_sssp_launch<vgl_path_widest>(c, g, d_weights, d_values, false, 1)
+                  : vgl_sssp_launch<vgl_path_shortest>(c, g, d_weights, d_values, false, 1);
 }
 
 extern "C" {

@@ -78,6 +78,7 @@ struct vgl_dir_csr {                 // one direction of the graph (borrowed) + 
 };
 
 struct vgl_hip_graph {
+    uint64_t uid = 0;                // unique per created handle (a freed handle's address may be reused: caches key on this, not on the pointer)
     int32_t V = 0, row_begin = 0, row_end = 0, nrows = 0;
     vgl_dir_csr out, in;
     // scratch shared by the fused algorithms (allocated at creation, sized by V / nrows / edges)

@@ -39,6 +39,11 @@ class CcStats(C.Structure):
     _fields_ = [("hook_passes", C.c_int32), ("algorithmic_bytes", C.c_int64)]
 
 
+class ExchangeStats(C.Structure):
+    _fields_ = [("collectives", C.c_int64), ("bytes_received", C.c_int64), ("list_steps", C.c_int32), ("dense_steps", C.c_int32),
+                ("sparse_levels", C.c_int32), ("reserved", C.c_int32)]
+
+
 _lib = None
 
 _p, _i32, _i64, _u64, _int, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_int, C.c_double
@@ -122,6 +127,29 @@ _SIGNATURES = {
     "vgl_hip_indegree_noloops_add": [_p, _p, _p],
     "vgl_hip_diff_to_pairs_u32": [_p, _i32, _p, _p, _i32, _p],
     "vgl_hip_apply_pairs_u32": [_p, _int, _i64, _int, _p, _int, _i32, _p, C.POINTER(_int)],
+    "vgl_hip_comm_unique_id": [_p],
+    "vgl_hip_comm_create": [_p, _int, _int, _p, _pp],
+    "vgl_hip_comm_create_hosted": [_p, _int, _int, C.c_char_p, C.c_size_t, _pp],
+    "vgl_hip_comm_destroy": [_p],
+    "vgl_hip_comm_info": [_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
+    "vgl_hip_comm_barrier": [_p],
+    "vgl_hip_comm_stats": [_p, C.POINTER(ExchangeStats)],
+    "vgl_hip_exchange_allreduce_min_i32": [_p, _p, _i64],
+    "vgl_hip_exchange_allreduce_min_f32": [_p, _p, _i64],
+    "vgl_hip_exchange_allreduce_max_f32": [_p, _p, _i64],
+    "vgl_hip_exchange_allreduce_sum_i32": [_p, _p, _i64],
+    "vgl_hip_exchange_allreduce_sum_i64": [_p, _p, _i64],
+    "vgl_hip_exchange_allreduce_sum_f32": [_p, _p, _i64],
+    "vgl_hip_exchange_allreduce_sum_f64": [_p, _p, _i64],
+    "vgl_hip_exchange_allgather": [_p, _p, _p, _i64],
+    "vgl_hip_exchange_allgather_slices": [_p, _p, C.POINTER(_i64), _int],
+    "vgl_hip_exchange_bitmap_or": [_p, _p, _i64],
+    "vgl_hip_exchange_changed_u32": [_p, _i32, _p, _p, _int, C.POINTER(_int)],
+    "vgl_hip_bfs_run_sharded": [_p, _p, _p, _i32, _int, _i64, _int, _p, C.POINTER(BfsStats)],
+    "vgl_hip_sssp_run_sharded": [_p, _p, _p, _p, _i32, _p, C.POINTER(SsspStats)],
+    "vgl_hip_sswp_run_sharded": [_p, _p, _p, _p, _i32, _p, C.POINTER(SsspStats)],
+    "vgl_hip_cc_run_sharded": [_p, _p, _p, _p, C.POINTER(CcStats)],
+    "vgl_hip_pr_run_sharded": [_p, _p, _p, _int, _int, _p, C.POINTER(PrStats)],
     "vgl_hip_timing_enable": [_p, _int],
     "vgl_hip_timing_only": [_p, C.c_char_p],
     "vgl_hip_timing_reset": [_p],
