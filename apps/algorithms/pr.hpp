@@ -26,6 +26,10 @@ struct PageRank {
             if (src_id != dst_id) atomicAdd(&incoming_degrees_without_loops[dst_id], 1);
         };
         graph_API.scatter(graph, frontier, count_incoming);
+        if (vgl_library_data.get_mpi_proc_num() > 1) {      // every rank counted the edges of its vertex range (the exchange at pr.hpp:58)
+            auto sum_op = [] __device__ (int a, int b) -> int { return a + b; };
+            graph_API.exchange_vertices_array(EXCHANGE_ALL, graph, incoming_degrees_without_loops, sum_op);
+        }
         auto calculate_reversed_degrees = [reversed_degrees, incoming_degrees_without_loops] __VGL_COMPUTE_ARGS__ {
             const int dg = incoming_degrees_without_loops[src_id];
             reversed_degrees[src_id] = (dg == 0) ? (_T)0 : (_T)(1.0 / dg);
@@ -50,6 +54,7 @@ struct PageRank {
                 page_ranks[src_id] = k + d * (page_ranks[src_id] + dangling_input);
             };
             graph_API.scatter(graph, frontier, edge_op, EMPTY_VERTEX_OP, vertex_postprocess_op, edge_op, EMPTY_VERTEX_OP, vertex_postprocess_op);
+            graph_API.exchange_vertices_array(EXCHANGE_PRIVATE_DATA, graph, page_ranks);       // pr.hpp:127: the ranks of every owner's vertex range
         }
         tm.end();
         auto reduce_ranks_sum = [page_ranks] __VGL_REDUCE_FLT_ARGS__ { return page_ranks[src_id]; };

@@ -22,9 +22,18 @@ struct ShortestPaths {
         int *changes;
         MemoryAPI::allocate_array(&changes, 1);
         int iterations_count = 0;
+        // several ranks (the reference's __USE_MPI__ flavour, shortest_paths.hpp:112-154): every rank relaxes the edges of its vertex range,
+        // the copies of the distances are merged through exchange_vertices_array(EXCHANGE_RECENTLY_CHANGED, ..., min_op) and the loop
+        // condition is a reduce over the merged (replicated) arrays, so that every rank takes the same decision
+        const bool several_ranks = vgl_library_data.get_mpi_proc_num() > 1;
+        VerticesArray<_T> prev_distances(graph, SCATTER);
         do {
             changes[0] = 0;
             iterations_count++;
+            if (several_ranks) {
+                auto save_old_distances = [prev_distances, distances] __VGL_COMPUTE_ARGS__ { prev_distances[src_id] = distances[src_id]; };
+                graph_API.compute(graph, frontier, save_old_distances);
+            }
             auto edge_op_push = [distances, weights, changes, inf_val] __VGL_SCATTER_ARGS__ {
                 const _T src_weight = distances[src_id];
                 if (src_weight < inf_val) {
@@ -36,6 +45,12 @@ struct ShortestPaths {
                 }
             };
             graph_API.scatter(graph, frontier, edge_op_push);
+            if (several_ranks) {
+                auto min_op = [] __device__ (_T a, _T b) -> _T { return a < b ? a : b; };
+                graph_API.exchange_vertices_array(EXCHANGE_RECENTLY_CHANGED, graph, distances, prev_distances, min_op);      // shortest_paths.hpp:136-141
+                auto reduce_changes = [prev_distances, distances] __VGL_REDUCE_INT_ARGS__ { return prev_distances[src_id] != distances[src_id] ? 1 : 0; };
+                changes[0] = graph_API.template reduce<int>(graph, frontier, reduce_changes, REDUCE_SUM) > 0;                 // shortest_paths.hpp:143-152
+            }
         } while (changes[0]);
         MemoryAPI::free_array(changes);
         tm.end();

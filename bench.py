@@ -285,9 +285,49 @@ def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# the drop-in path: the reference's operator API (GraphAbstractionsHIP + user lambdas, apps/algorithms/*.hpp, NOT the fused C-ABI
+# drivers), run as the apps a VGL user would build (apps/bin/*_hip without -fused), beside the same apps with -fused
+# ------------------------------------------------------------------------------------------------------------------------
+def leg_operator_api(scale, ef, extra):
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    runs = {
+        "bfs_top_down": ("bfs_hip", ["-s", str(scale), "-e", str(ef), "-type", "rmat", "-it", "8", "-format", "vcsr"], ["-fused", "-td"]),
+        "sssp_bellman_ford_all_active_push": ("sssp_hip", ["-s", str(scale), "-e", str(ef), "-type", "rmat", "-it", "2", "-format", "vcsr"], ["-fused", "-do"]),
+        "pagerank_5_iterations": ("pr_hip", ["-s", str(scale + 1), "-e", str(ef), "-type", "ru", "-it", "5", "-format", "csr"], ["-fused"]),
+        "cc_shiloach_vishkin": ("cc_hip", ["-s", str(scale), "-e", str(ef // 2), "-type", "rmat", "-it", "2", "-format", "vcsr"], ["-fused"]),
+    }
+    out = {"note": "AVG_PERF (MTEPS, E / time) of apps/bin/*_hip WITHOUT -fused: user lambdas through GraphAbstractionsHIP::scatter / compute / "
+                   "reduce / generate_new_frontier; `fused` = the same app with -fused (its fastest library schedule), for scale"}
+    for name, (app, argv, fused) in runs.items():
+        exe = os.path.join(root, "apps", "bin", app)
+        if not os.path.exists(exe):
+            out[name] = {"error": "apps/bin/%s not built" % app}
+            continue
+        row = {"command": " ".join([app] + argv)}
+        for label, more in (("operator_api", []), ("fused", fused)):
+            try:
+                r = subprocess.run([exe] + argv + more, capture_output=True, text=True, timeout=600)
+                m = re.search(r"AVG_PERF: ([0-9.eE+-]+) MTEPS", r.stdout)
+                row[label + "_mteps"] = float(m.group(1)) if (m and r.returncode == 0) else None
+                if label == "operator_api":
+                    for prim in ("Advance", "Compute", "Reduce", "GNF"):
+                        pm = re.search(prim + r"\s*: ([0-9.eE+-]+) \(ms\), ([0-9.eE+-]+) %", r.stdout)
+                        if pm:
+                            row.setdefault("wall_share_percent", {})[prim.lower()] = float(pm.group(2))
+            except subprocess.TimeoutExpired:
+                row[label + "_mteps"] = None
+        if row.get("operator_api_mteps") and row.get("fused_mteps"):
+            row["operator_api_over_fused"] = round(row["operator_api_mteps"] / row["fused_mteps"], 3)
+        out[name] = row
+    extra["operator_api"] = out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # multi-GPU legs (PageRank / CC over edge-cut shards; the BFS leg is in main)
 # ------------------------------------------------------------------------------------------------------------------------
-def leg_pr_sharded(api, vd, ctx, dist, world, rank, pscale, ef, seed, chunk_edges, extra):
+def leg_pr_sharded(api, vd, vs, comm, ctx, dist, world, rank, pscale, ef, seed, chunk_edges, extra):
     """BASELINE configs[3]: PageRank pull on uniform-random scale 25 cut `world` ways, owned slices all-gathered per iteration"""
     import torch
     iters = 10
@@ -297,15 +337,14 @@ def leg_pr_sharded(api, vd, ctx, dist, world, rank, pscale, ef, seed, chunk_edge
                                                 placement="ranges", with_incoming=False)
     ctx.sync()
     t_build = time.perf_counter() - t1
-    ops = vd.HipShardOps(shard)
-    vd.page_rank_sharded(ops, 2, bounds[rank], bounds[rank + 1])
-    st = {}
+    vs.pr_run_sharded(shard, comm, 2, api.PR_AUTO)                 # warm-up; builds the blocked layout of the shard when AUTO picks it
     ctx.timing(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    ranks = vd.page_rank_sharded(ops, iters, bounds[rank], bounds[rank + 1], stats=st)
+    ranks, _ = vs.pr_run_sharded(shard, comm, iters, api.PR_AUTO)   # the C++ super-step loop: owner-computes pull + in-place all-gather (RCCL)
+    st = comm.stats() if comm is not None else {}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -322,18 +361,18 @@ def leg_pr_sharded(api, vd, ctx, dist, world, rank, pscale, ef, seed, chunk_edge
     alg = 8 * int(shard.E) + 28 * pV                              # this shard's edges; the V-proportional passes are replicated
     extra[f"pagerank_uniform{pscale}_sharded"] = {
         "teps": round(iters * pE / dtp, 1), "ms_per_iteration": round(dtp / iters * 1e3, 3), "iterations": iters, "ranks_sum": mass,
-        "shard_edges": int(shard.E), "graph_build_s": round(t_build, 2), "exchange": "all-gather of owned rank slices",
-        "gathered_bytes_per_iteration": st.get("gathered_bytes", 0) // iters,
+        "shard_edges": int(shard.E), "graph_build_s": round(t_build, 2), "exchange": "vgl_hip_pr_run_sharded: all-gather of owned rank slices (RCCL, in place)",
+        "received_bytes_per_iteration": st.get("bytes_received", 0) // iters, "collectives": st.get("collectives", 0),
         "rank0_pull_pass": {"ms": round(pass_ms, 4), "algorithmic_GBps": round(alg / (pass_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (pass_ms * 1e-3) / 1e9),
                             "path": "blocked" if blocked else "adjacency-order chain"}}
     if abs(mass - 1.0) > 1e-3:
         sys.exit(f"bench.py: sharded PageRank lost mass ({mass})")
     shard.close()
-    del shard, ops, ranks
+    del shard, ranks
     torch.cuda.empty_cache()
 
 
-def leg_cc_sharded(api, vd, ctx, dist, world, rank, cc_scale, seed, chunk_edges, renumber, extra):
+def leg_cc_sharded(api, vd, vs, comm, ctx, dist, world, rank, cc_scale, seed, chunk_edges, renumber, extra):
     """BASELINE configs[4]: Shiloach-Vishkin on the symmetrised RMAT graph (edge factor 16 generated, 32 stored), edge-cut, labels merged
     by the changed-only exchange (whole-array all-reduce while most labels change)"""
     import torch
@@ -343,15 +382,15 @@ def leg_cc_sharded(api, vd, ctx, dist, world, rank, cc_scale, seed, chunk_edges,
                                                 placement="ranges", symmetric=True, with_incoming=False)
     ctx.sync()
     t_build = time.perf_counter() - t1
-    ops = vd.HipShardOps(shard)
-    vd.cc_sharded(ops)
-    st = {}
+    vs.cc_run_sharded(shard, comm)
     ctx.timing(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    comp, passes = vd.cc_sharded(ops, stats=st)
+    comp, cst = vs.cc_run_sharded(shard, comm)                      # the C++ super-step loop (hook over owned rows, changed-entries exchange, jump)
+    passes = cst["hook_passes"]
+    st = comm.stats() if comm is not None else {}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -372,7 +411,7 @@ def leg_cc_sharded(api, vd, ctx, dist, world, rank, cc_scale, seed, chunk_edges,
     if not ok:
         sys.exit("bench.py: sharded CC labels are not idempotent")
     shard.close()
-    del shard, ops, comp
+    del shard, comp
     torch.cuda.empty_cache()
 
 
@@ -387,6 +426,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sssp", action="store_true")
     ap.add_argument("--no-pr-cc", action="store_true", help="skip the PageRank (uniform-25) and CC (symmetrised RMAT) extras")
+    ap.add_argument("--no-operator-api", action="store_true", help="skip the drop-in (operator API) apps leg")
     ap.add_argument("--cpu-sources", type=int, default=10)
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU super-step path even with one rank (debug)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -421,7 +461,8 @@ def main():
     import torch
     import torch.distributed as dist
     from vectorgraphlibrary_amd import api
-    from vectorgraphlibrary_amd import distributed as vd
+    from vectorgraphlibrary_amd import distributed as vd           # streaming shard builder
+    from vectorgraphlibrary_amd import sharded as vs               # the C-ABI super-step loops and exchanges (RCCL inside libvgl_hip.so)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -431,6 +472,13 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = api.Context(local_rank if world > 1 else 0)
+    # the library's own RCCL communicator: torch.distributed only carries rank 0's 128-byte id to the other ranks (and the barriers /
+    # max-over-ranks of the timing contract); every data-path collective is issued by libvgl_hip.so on the context's stream
+    comm = None
+    if world > 1:
+        comm = vs.Comm.from_torch_group(ctx)
+    elif args.force_sharded and os.environ.get("VGL_SHARD_FORCE_COLLECTIVES") == "1":
+        comm = vs.Comm.rccl(ctx, 0, 1, vs.Comm.unique_id())
 
     scale, ef, seed = args.scale, args.edge_factor, args.seed
     renumber = None if args.renumber == "none" else args.renumber
@@ -642,6 +690,8 @@ def main():
             g.out_adj = g.in_adj = g.perm = None
             torch.cuda.empty_cache()
             leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu)
+        if not args.no_operator_api and not args.no_pr_cc and scale == 24:     # (the apps build their own graphs: the bench's are freed by now)
+            leg_operator_api(scale, ef, extra)
         workload = f"BFS direction-optimising on RMAT scale-{scale} (edge factor {ef}), 1xMI355X"
         scaling = "none"
     else:
@@ -653,13 +703,15 @@ def main():
             if world > 1:
                 g.close()
                 g.out_adj = g.in_adj = None                                   # keep only the shard resident
-        ops = vd.HipShardOps(shard)
+        # vgl_hip_bfs_run_sharded: the per-level loop, the switch rule and every collective run in C++ / RCCL on the context's stream;
+        # levels stay with their owners (no gather inside the timed region, like the fused single-GPU call returns device levels)
+        levels_buf = torch.empty(V, dtype=torch.int32, device=ctx.device)
         for s in sources[:args.warmup]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, owned_levels=True)
+            vs.bfs_run_sharded(shard, comm, s, api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=False, levels=levels_buf, want_stats=False)
         barrier()
         t0 = time.perf_counter()
         for s in sources[args.warmup:]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, owned_levels=True)
+            vs.bfs_run_sharded(shard, comm, s, api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=False, levels=levels_buf, want_stats=False)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -671,8 +723,23 @@ def main():
         ctx.timing(True)
         st = {}
         for s in sources[args.warmup:]:
-            vd.bfs_sharded(ops, s, degrees=degrees, edges=E, equal_ranges=weak and world > 1, stats=st, owned_levels=True)
+            _, one = vs.bfs_run_sharded(shard, comm, s, api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=False, levels=levels_buf, want_stats=True)
+            for k in ("levels", "td_steps", "bu_steps", "td_edges", "td_frontier", "bu_edges", "bu_found"):
+                st[k] = st.get(k, 0) + one[k]
         barrier()
+        # the result of the last traversal: every owner's levels are consistent over its out-edges (level[dst] <= level[src] + 1, and a
+        # reached source never has an unreached destination) -- checked on the all-gathered levels
+        if comm is not None:
+            vs.bfs_run_sharded(shard, comm, sources[-1], api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=True, levels=levels_buf, want_stats=False)
+        lv = levels_buf.long()
+        rows = torch.repeat_interleave(torch.arange(shard.row_begin, shard.row_end, device=ctx.device), (shard.out_rowptr[1:] - shard.out_rowptr[:-1]))
+        ls, ld = lv[rows], lv[shard.out_adj.long()]
+        reached = ls > 0
+        levels_ok = bool(((ld[reached] > 0) & (ld[reached] <= ls[reached] + 1)).all()) and int(lv[sources[-1]]) == 1
+        del lv, rows, ls, ld, reached
+        extra["verified_sharded_levels_consistent_over_owned_edges"] = levels_ok
+        if not levels_ok:
+            sys.exit("bench.py: sharded BFS levels violate the level property on rank %d" % rank)
         kern = {}
         for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "bfs_small_levels", "bfs_bitmap_expand", "gnf"):
             n, ms = ctx.timing_get(name)
@@ -691,18 +758,19 @@ def main():
                         "ms_per_launch": round(per_launch_ms, 5), "launches": kern[dom]["launches"], "rank": 0,
                         "note": "rank 0's shard, measured in an untimed repeat of the timed traversals"}
         extra["bfs"] = {"kernels_rank0": kern, "levels_per_bfs": st.get("levels", 0) / max(1, args.steps), "td_steps": st.get("td_steps", 0),
-                        "bu_steps": st.get("bu_steps", 0)}
+                        "bu_steps": st.get("bu_steps", 0), "driver": "vgl_hip_bfs_run_sharded (C++ loop, RCCL on the context's stream)",
+                        "exchange_last_traversal": comm.stats() if comm is not None else None}
         extra["shard_edges"] = int(shard.E)
-        workload = (f"BFS direction-optimising super-steps (bitmap all-gather per level) on RMAT scale-{scale} "
+        workload = (f"BFS direction-optimising super-steps (frontier slices all-gathered per level) on RMAT scale-{scale} "
                     f"(edge factor {ef}), edge-cut over {world} GPUs")
         scaling = "weak" if weak else "strong"
         if not args.no_pr_cc:
             # BASELINE configs[3] and [4]: PageRank on uniform-25 and Shiloach-Vishkin on the symmetrised RMAT graph over the same ranks
             shard.close()
-            del shard, ops, degrees
+            del shard, degrees, levels_buf
             torch.cuda.empty_cache()
-            leg_pr_sharded(api, vd, ctx, dist, world, rank, args.pr_scale, ef, seed, args.chunk_edges, extra)
-            leg_cc_sharded(api, vd, ctx, dist, world, rank, args.cc_scale or scale, seed, args.chunk_edges, renumber, extra)
+            leg_pr_sharded(api, vd, vs, comm, ctx, dist, world, rank, args.pr_scale, ef, seed, args.chunk_edges, extra)
+            leg_cc_sharded(api, vd, vs, comm, ctx, dist, world, rank, args.cc_scale or scale, seed, args.chunk_edges, renumber, extra)
 
     if rank == 0:
         out = {
@@ -719,6 +787,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline
         out.update(extra)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -129,7 +129,14 @@ int vgl_hip_gnf_equal_i32(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_v
 int vgl_hip_graph_tile_rows(vgl_hip_graph *g, int direction, const int32_t **d_tile_row, int64_t *ntiles);
 int vgl_hip_frontier_advance_plan(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f, int direction,
                                   const int64_t **d_offs, const int32_t **d_tile_first, int64_t *edges);
-/* device buffer of V doubles owned by the context, used by the operator class to materialise reduce_op values */
+/* generate_new_frontier with a USER predicate (the C++ operator class): the count pass -- predicate, flags, per-tile counts, totals --
+ * runs in the caller's translation unit (vgl_k_gnf_count of csrc/vgl_gnf.h instantiated with the user's lambda; it may write the
+ * terminator of the edge-offset array returned by vgl_hip_frontier_plan_offsets), vgl_hip_gnf_complete does the rest: size / neighbours /
+ * sparsity choice (generate_new_frontier.hpp:67-91,113-164) and, for a SPARSE result, the ascending-id compaction -- with the exclusive
+ * out-edge offsets of the ids when want_plan != 0, which vgl_hip_frontier_advance_plan(direction 0) then reuses. */
+int64_t *vgl_hip_frontier_plan_offsets(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f);
+int vgl_hip_gnf_complete(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f, double dense_threshold, int want_plan);
+/* sums n doubles on the device in a fixed order (the operator class folds its per-workgroup reduce partials with it) */
 int vgl_hip_reduce_sum_f64_buffer(vgl_hip_ctx *ctx, int64_t n, const double *d_values, double *result);
 
 /* ---- reduce (reduce_worker_sum, multicore/reduce.hpp:6-60; only REDUCE_SUM is live).

@@ -148,3 +148,34 @@ def test_apply_pairs_clamps_an_overflowing_list(ctx):
         L.check(ctx.L.vgl_hip_apply_pairs_u32(ctx.h, parts, 1 + 2 * cap, -1, _ptr(lists), take_min, n, _ptr(values), C.byref(ch)))
         assert ch.value == 1
         assert (values.cpu().numpy() == want).all()
+
+
+def _run_app_ranks(app, args, world, timeout=600):
+    name = "/vgl_app_%s" % uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, VGL_WORLD=str(world), VGL_RANK=str(r), VGL_COMM_HOSTED=name, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([os.path.join(ROOT, "apps", "bin", app)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d of %s:\n%s" % (r, app, o[-3000:])
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_operator_api_apps_with_exchange_vertices_array(ctx, world):
+    """the drop-in seam under several ranks: the operator-API SSSP (EXCHANGE_RECENTLY_CHANGED with a user merge operator + reduce) and
+    PageRank (EXCHANGE_ALL sum of the in-degrees, EXCHANGE_PRIVATE_DATA of the ranks) apps, every rank advancing over its vertex range of
+    the replicated graph (the reference's MPI flavour), checked by each rank against the sequential checkers"""
+    for fmt in ("csr", "vcsr"):
+        for out in _run_app_ranks("sssp_hip", ["-s", "12", "-e", "16", "-it", "2", "-check", "-format", fmt], world):
+            assert out.count("error count: 0") == 2 and "AVG_PERF" in out, out[-2000:]
+        for out in _run_app_ranks("pr_hip", ["-s", "12", "-e", "16", "-it", "1", "-check", "-format", fmt], world):
+            assert "error count: 0" in out and "AVG_PERF" in out, out[-2000:]

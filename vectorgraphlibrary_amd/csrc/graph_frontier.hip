@@ -350,14 +350,14 @@ int vgl_hip_frontier_set_all_active(vgl_hip_ctx *c, vgl_hip_frontier *f)
     hipLaunchKernelGGL(vgl_k_iota_flags, dim3((unsigned)std::min<int64_t>(4096, vgl_ceil_div(V, VGL_BLOCK))), dim3(VGL_BLOCK), 0,
                        c->stream, V, f->ids, f->flags, 1);
     VGL_HIP_TRY(hipGetLastError());
-    f->size = V; f->neighbours = f->g->out.edges; f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE;
+    f->size = V; f->neighbours = f->g->out.edges; f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE; f->plan_dir = -1;
     return 0;
 }
 int vgl_hip_frontier_clear(vgl_hip_ctx *c, vgl_hip_frontier *f)
 {
     if (!c || !f) VGL_FAIL("null argument");
     VGL_HIP_TRY(hipMemsetAsync(f->flags, 0, sizeof(int32_t) * (size_t)f->g->V, c->stream));
-    f->size = 0; f->neighbours = 0; f->sparsity = VGL_HIP_FRONTIER_SPARSE;
+    f->size = 0; f->neighbours = 0; f->sparsity = VGL_HIP_FRONTIER_SPARSE; f->plan_dir = -1;
     return 0;
 }
 int vgl_hip_frontier_add_vertex(vgl_hip_ctx *c, vgl_hip_frontier *f, int32_t v)
@@ -367,7 +367,7 @@ int vgl_hip_frontier_add_vertex(vgl_hip_ctx *c, vgl_hip_frontier *f, int32_t v)
     if (v < 0 || v >= f->g->V) VGL_FAIL("frontier_add_vertex: vertex id out of range");
     hipLaunchKernelGGL(vgl_k_add_vertex, dim3(1), dim3(1), 0, c->stream, v, f->ids, f->flags);
     VGL_HIP_TRY(hipGetLastError());
-    f->size = 1; f->sparsity = VGL_HIP_FRONTIER_SPARSE;
+    f->size = 1; f->sparsity = VGL_HIP_FRONTIER_SPARSE; f->plan_dir = -1;
     int64_t rp[2] = {0, 0};
     if (v >= f->g->row_begin && v < f->g->row_end)
         VGL_TRY(vgl_hip_memcpy_d2h(c, rp, f->g->out.rowptr + (v - f->g->row_begin), sizeof(rp)));
@@ -391,6 +391,54 @@ int vgl_hip_graph_tile_rows(vgl_hip_graph *g, int direction, const int32_t **d_t
     return 0;
 }
 
+}  // extern "C"
+
+// plan buffers of a frontier (edge offsets of its ids, tile table, per-block sums), allocated on first use
+static int vgl_frontier_reserve(vgl_hip_graph *g, vgl_hip_frontier *f)
+{
+    if (f->offs) return 0;
+    const int64_t emax = std::max(g->out.edges, g->in.edges);
+    VGL_TRY(vgl_alloc(&f->offs, (size_t)g->V + 1));
+    VGL_TRY(vgl_alloc(&f->tile_first, (size_t)vgl_ceil_div(emax, VGL_TILE) + 2));
+    VGL_TRY(vgl_alloc(&f->blk_sum, (size_t)vgl_ceil_div(g->V, VGL_TILE) + 1));
+    VGL_TRY(vgl_alloc(&f->blk_off, (size_t)vgl_ceil_div(g->V, VGL_TILE) + 1));
+    return 0;
+}
+
+extern "C" {
+
+int64_t *vgl_hip_frontier_plan_offsets(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f)
+{
+    if (!c || !g || !f || vgl_frontier_reserve(g, f)) return nullptr;
+    return f->offs;
+}
+
+// second half of a frontier generation whose count pass ran in the caller's translation unit (the C++ operator class evaluates the
+// user's predicate in vgl_k_gnf_count itself: flags, per-tile counts, totals in the context's pinned counters): size / neighbours /
+// sparsity, and for a SPARSE result the ascending-id compaction -- with the exclusive out-edge offsets of the ids when want_plan, so
+// that the advance that follows needs no offset pass of its own.
+int vgl_hip_gnf_complete(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, double dense_threshold, int want_plan)
+{
+    if (!c || !g || !f) VGL_FAIL("gnf_complete: null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("generate_new_frontier: graph handle must own all rows");
+    f->size = (int32_t)c->h_counters[C_FRONT];
+    f->neighbours = c->h_counters[C_NEIGH];
+    f->plan_dir = -1;
+    if (f->size == g->V) { f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE; return 0; }
+    if (dense_threshold > 0.0 && (double)f->size / g->V > dense_threshold) { f->sparsity = VGL_HIP_FRONTIER_DENSE; return 0; }
+    f->sparsity = VGL_HIP_FRONTIER_SPARSE;
+    if (want_plan) VGL_TRY(vgl_frontier_reserve(g, f));
+    {
+        vgl_timed_launch tl(c, "gnf");
+        const vgl_pred_nonzero_i32 pred{f->flags};
+        hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_nonzero_i32>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows, g->row_begin,
+                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, f->ids, want_plan ? f->offs : (int64_t *)nullptr);
+    }
+    VGL_HIP_TRY(hipGetLastError());
+    if (want_plan) f->plan_dir = 0;
+    return 0;
+}
+
 int vgl_hip_frontier_advance_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, int direction, const int64_t **d_offs,
                                   const int32_t **d_tile_first, int64_t *edges)
 {
@@ -400,23 +448,24 @@ int vgl_hip_frontier_advance_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_fron
     if (f->sparsity != VGL_HIP_FRONTIER_SPARSE) VGL_FAIL("frontier_advance_plan: only sparse frontiers need a plan");
     const int32_t F = f->size;
     const int64_t nblk = vgl_ceil_div(std::max<int64_t>(F, 1), VGL_TILE);
-    if (!f->offs) {
-        const int64_t emax = std::max(g->out.edges, g->in.edges);
-        VGL_TRY(vgl_alloc(&f->offs, (size_t)g->V + 1));
-        VGL_TRY(vgl_alloc(&f->tile_first, (size_t)vgl_ceil_div(emax, VGL_TILE) + 2));
-        VGL_TRY(vgl_alloc(&f->blk_sum, (size_t)vgl_ceil_div(g->V, VGL_TILE) + 1));
-        VGL_TRY(vgl_alloc(&f->blk_off, (size_t)vgl_ceil_div(g->V, VGL_TILE) + 1));
-    }
+    VGL_TRY(vgl_frontier_reserve(g, f));
     *d_offs = f->offs; *d_tile_first = f->tile_first; *edges = 0;
     if (F == 0) return 0;
+    const int grid = (int)std::min<int64_t>(4096, vgl_ceil_div(F, VGL_BLOCK));
+    if (f->plan_dir == direction) {              // the frontier generation left ids' edge offsets behind: only the tile table is missing
+        hipLaunchKernelGGL(vgl_k_plan_tile_first, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, F, f->offs, f->tile_first);
+        VGL_HIP_TRY(hipGetLastError());
+        *edges = f->neighbours;
+        return 0;
+    }
     hipLaunchKernelGGL(vgl_k_plan_sums, dim3((unsigned)nblk), dim3(VGL_BLOCK), 0, c->stream, F, f->ids, g->row_begin, d.rowptr, f->blk_sum);
     hipLaunchKernelGGL(vgl_k_plan_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, nblk, f->blk_sum, f->blk_off, c->d_counters, f->offs, F);
     hipLaunchKernelGGL(vgl_k_plan_write, dim3((unsigned)nblk), dim3(VGL_BLOCK), 0, c->stream, F, f->ids, g->row_begin, d.rowptr, f->blk_off, f->offs);
-    const int grid = (int)std::min<int64_t>(4096, vgl_ceil_div(F, VGL_BLOCK));
     hipLaunchKernelGGL(vgl_k_plan_tile_first, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, F, f->offs, f->tile_first);
     VGL_HIP_TRY(hipGetLastError());
     VGL_TRY(vgl_read_counters(c, false));
     *edges = c->h_counters[C_NEIGH];
+    f->plan_dir = direction;
     return 0;
 }
 
@@ -445,6 +494,7 @@ static int vgl_gnf_frontier(vgl_hip_ctx *c, vgl_hip_graph *g, Pred pred, double 
     // pass 1+2: flags, counts, totals
     VGL_TRY(vgl_gnf_run(c, g, pred, f->ids, nullptr, nullptr, nullptr, flags_out, false, true));
     f->size = (int32_t)c->h_counters[C_FRONT];
+    f->plan_dir = -1;
     f->neighbours = c->h_counters[C_NEIGH];
     if (f->size == g->V) { f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE; }
     else if (dense_threshold > 0.0 && (double)f->size / g->V > dense_threshold) { f->sparsity = VGL_HIP_FRONTIER_DENSE; }

@@ -84,8 +84,13 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_count(Pred pred, int32_t 
         }
         if (front_bytes) front_bytes[v0 >> 3] = (uint8_t)bits;
         if (visited_bytes) visited_bytes[v0 >> 3] = (uint8_t)aux;
-        if (flags_out)
-            for (int j = 0; j < nvalid; j++) flags_out[v0 + j] = (bits >> j) & 1;
+        if (flags_out) {
+            if (nvalid == 8 && (v0 & 7) == 0) {         // 32-byte aligned: two 16-byte stores
+                *reinterpret_cast<int4 *>(flags_out + v0) = make_int4(bits & 1, (bits >> 1) & 1, (bits >> 2) & 1, (bits >> 3) & 1);
+                *reinterpret_cast<int4 *>(flags_out + v0 + 4) = make_int4((bits >> 4) & 1, (bits >> 5) & 1, (bits >> 6) & 1, (bits >> 7) & 1);
+            } else
+                for (int j = 0; j < nvalid; j++) flags_out[v0 + j] = (bits >> j) & 1;
+        }
     }
     const int tc = vgl_block_reduce_add(cnt, s32);
     const int64_t td = vgl_block_reduce_add(deg, s64);

@@ -27,8 +27,11 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
+#include <utility>
 #include "../../include/vgl_hip.h"
 #include "../csrc/vgl_hip_internal.h"
+#include "../csrc/vgl_gnf.h"
 
 // ------------------------------------------------------------------------------------------------------------------
 // architecture macros (architecture_independent_api.h:19-43, GPU flavour)
@@ -92,6 +95,7 @@ enum TraversalDirection { SCATTER = 0, GATHER = 1, ORIGINAL = 2 };
 enum REDUCE_TYPE { REDUCE_SUM = 0, REDUCE_MAX = 1, REDUCE_MIN = 1, REDUCE_AVG = 3 };
 enum FrontierSparsityType { ALL_ACTIVE_FRONTIER = 2, SPARSE_FRONTIER = 1, DENSE_FRONTIER = 0 };
 enum DirectionType { UNDIRECTED_GRAPH = 0, DIRECTED_GRAPH = 1 };
+enum DataExchangePolicy { EXCHANGE_ALL = 0, EXCHANGE_RECENTLY_CHANGED = 1, EXCHANGE_PRIVATE_DATA = 2 };   // library_data.h:5-10
 // degree classes of the VectCSR advance (settings.h:57-58,99-109; apps override VECTOR_CORE_THRESHOLD_VALUE before the include): rows with
 // fewer entries than the threshold form the reference's "collective" range and get the collective functor set
 #ifndef VECTOR_LENGTH
@@ -113,17 +117,73 @@ enum DirectionType { UNDIRECTED_GRAPH = 0, DIRECTED_GRAPH = 1 };
 // ------------------------------------------------------------------------------------------------------------------
 struct VGL_RUNTIME {
     static vgl_hip_ctx *&ctx() { static vgl_hip_ctx *c = nullptr; return c; }
+    static vgl_hip_comm *&comm() { static vgl_hip_comm *m = nullptr; return m; }
     static hipStream_t stream() { return (hipStream_t)vgl_hip_ctx_stream(ctx()); }
-    static void init_library(int, char **, int device = 0) { if (!ctx()) VGL_HIP_CALL(vgl_hip_ctx_create(device, nullptr, &ctx())); }
-    static void finalize_library() { if (ctx()) { vgl_hip_ctx_destroy(ctx()); ctx() = nullptr; } }
+    // One process per GPU, started by any launcher that sets VGL_RANK / VGL_WORLD (the reference reads them from MPI_Init,
+    // library_data/init.hpp) plus how the ranks meet: VGL_COMM_ID_FILE = a path rank 0 writes its 128-byte RCCL id to (collectives over
+    // xGMI), or VGL_COMM_HOSTED = a shared-memory name (ranks may then share one GPU: tests, rehearsals).  VGL_DEVICE overrides the
+    // device index (default: VGL_RANK for RCCL, 0 for the hosted transport).  Without VGL_WORLD: a world of one, no communicator.
+    static void init_library(int, char **, int device = -1)
+    {
+        if (ctx()) return;
+        const char *w = getenv("VGL_WORLD"), *r = getenv("VGL_RANK"), *idf = getenv("VGL_COMM_ID_FILE"), *hosted = getenv("VGL_COMM_HOSTED");
+        const int world = w ? atoi(w) : 1, rank = r ? atoi(r) : 0;
+        if (world < 1 || rank < 0 || rank >= world) throw "Error in VGL_RUNTIME::init_library : VGL_RANK / VGL_WORLD out of range";
+        if (device < 0) device = getenv("VGL_DEVICE") ? atoi(getenv("VGL_DEVICE")) : (world > 1 && !hosted ? rank : 0);
+        VGL_HIP_CALL(vgl_hip_ctx_create(device, nullptr, &ctx()));
+        if (world > 1 || idf || hosted) {
+            if (hosted) VGL_HIP_CALL(vgl_hip_comm_create_hosted(ctx(), rank, world, hosted, (size_t)4 << 20, &comm()));
+            else {
+                if (!idf) throw "Error in VGL_RUNTIME::init_library : VGL_WORLD > 1 needs VGL_COMM_ID_FILE or VGL_COMM_HOSTED";
+                unsigned char id[VGL_HIP_COMM_ID_BYTES];
+                const std::string path = idf, tmp = path + ".tmp";
+                if (rank == 0) {
+                    VGL_HIP_CALL(vgl_hip_comm_unique_id(id));
+                    FILE *f = fopen(tmp.c_str(), "wb");
+                    if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw "Error in VGL_RUNTIME::init_library : cannot write VGL_COMM_ID_FILE";
+                    fclose(f);
+                    rename(tmp.c_str(), path.c_str());
+                } else {
+                    FILE *f = nullptr;
+                    for (int tries = 0; !(f = fopen(path.c_str(), "rb")); tries++) {
+                        if (tries > 12000) throw "Error in VGL_RUNTIME::init_library : rank 0's RCCL id did not appear";
+                        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+                    }
+                    const size_t got = fread(id, 1, sizeof(id), f);
+                    fclose(f);
+                    if (got != sizeof(id)) throw "Error in VGL_RUNTIME::init_library : short RCCL id file";
+                }
+                VGL_HIP_CALL(vgl_hip_comm_create(ctx(), rank, world, id, &comm()));
+            }
+        }
+    }
+    static void finalize_library()
+    {
+        if (comm()) { vgl_hip_comm_destroy(comm()); comm() = nullptr; }
+        if (ctx()) { vgl_hip_ctx_destroy(ctx()); ctx() = nullptr; }
+    }
     static void sync() { VGL_HIP_CALL(vgl_hip_ctx_sync(ctx())); }
+    static int get_mpi_rank() { int r = 0; if (comm()) VGL_HIP_CALL(vgl_hip_comm_info(comm(), &r, nullptr, nullptr)); return r; }
+    static int get_mpi_proc_num() { int w = 1; if (comm()) VGL_HIP_CALL(vgl_hip_comm_info(comm(), nullptr, &w, nullptr)); return w; }
 };
+// LibraryData (vgl_runtime/helpers/library_data/library_data.h:17-57): the rank / size accessors the reference's sources use
+struct LibraryData {
+    int get_mpi_rank() const { return VGL_RUNTIME::get_mpi_rank(); }
+    int get_mpi_proc_num() const { return VGL_RUNTIME::get_mpi_proc_num(); }
+};
+static LibraryData vgl_library_data;
 
 // MemoryAPI (memory_API.hpp:4-15): allocate_array gives HOST-VISIBLE, device-writable memory for the small flag / counter
 // words the reference keeps in managed memory (e.g. `changes[0]`, gpu_shortest_paths.hpp:92-113)
 struct MemoryAPI {
-    template <class T> static void allocate_array(T **p, size_t n) { VGL_HIP_RT(hipHostMalloc((void **)p, sizeof(T) * (n ? n : 1), hipHostMallocDefault)); }
-    template <class T> static void free_array(T *p) { if (p) hipHostFree(p); }
+    // host-visible arrays alive right now: while there are any, the host may read what a primitive's operators wrote (the reference's
+    // `changes[0]` pattern over managed memory), so every primitive ends with a stream synchronisation, as the reference's GPU backend does
+    // (gpu/advance_csr.hpp:204).  With none alive nothing a primitive writes can be seen by the host before it calls a primitive that
+    // returns a value (reduce, generate_new_frontier, frontier.size()) -- those synchronise themselves -- and advance / compute are left
+    // enqueued (bfs.hpp:6-51 runs that way).  VGL_SYNC_PRIMITIVES=1 forces the synchronous behaviour (per-abstraction timers need it).
+    static int &live_host_arrays() { static int n = 0; return n; }
+    template <class T> static void allocate_array(T **p, size_t n) { VGL_HIP_RT(hipHostMalloc((void **)p, sizeof(T) * (n ? n : 1), hipHostMallocDefault)); live_host_arrays()++; }
+    template <class T> static void free_array(T *p) { if (p) { hipHostFree(p); live_host_arrays()--; } }
     template <class T> static void allocate_device_array(T **p, size_t n) { VGL_HIP_CALL(vgl_hip_malloc(VGL_RUNTIME::ctx(), sizeof(T) * n, (void **)p)); }
     template <class T> static void free_device_array(T *p) { if (p) vgl_hip_free(VGL_RUNTIME::ctx(), p); }
 };
@@ -455,6 +515,7 @@ private:
         handle = nullptr; out_rowptr = in_rowptr = out_perm = in_perm = nullptr; out_adj = in_adj = nullptr; d_fwd = d_bwd = nullptr;
         h_fwd.clear(); h_bwd.clear();
         mirrored = false; host_in_rowptr.clear(); host_out_adj.clear(); host_in_adj.clear();
+        mpi_bounds[0].clear(); mpi_bounds[1].clear();
     }
     template <class T> static T *upload(const std::vector<T> &h)
     {
@@ -587,6 +648,26 @@ public:
     int get_vertices_count() const { return vertices_count; }
     long long get_edges_count() const { return edges_count; }
     vgl_hip_graph *get_handle() const { return handle; }
+    // VectorCSRGraph::get_mpi_thresholds (vect_csr/get_api.hpp:66-94): contiguous vertex ranges with ~E / ranks edges of the traversed
+    // direction each (bounds on multiples of 64); every rank holds the whole graph, like the reference's MPI processes, and advances over
+    // its range only.  world + 1 entries, identical on every rank.
+    const std::vector<int64_t> &get_mpi_bounds(TraversalDirection d)
+    {
+        const int world = VGL_RUNTIME::get_mpi_proc_num(), k = d == GATHER ? 1 : 0;
+        if ((int)mpi_bounds[k].size() != world + 1) {
+            std::vector<int32_t> b((size_t)world + 1);
+            VGL_HIP_CALL(vgl_hip_partition_rows(VGL_RUNTIME::ctx(), vertices_count, k ? in_rowptr : out_rowptr, world, b.data()));
+            mpi_bounds[k].assign(b.begin(), b.end());
+        }
+        return mpi_bounds[k];
+    }
+    std::pair<int, int> get_mpi_thresholds(TraversalDirection d)
+    {
+        if (VGL_RUNTIME::get_mpi_proc_num() == 1) return {0, vertices_count};
+        const std::vector<int64_t> &b = get_mpi_bounds(d);
+        const int r = VGL_RUNTIME::get_mpi_rank();
+        return {(int)b[(size_t)r], (int)b[(size_t)r + 1]};
+    }
     vgl_csr_view get_direction_view(TraversalDirection d) const
     {
         return d == GATHER ? vgl_csr_view{(const long long *)in_rowptr, in_adj, edges_count}
@@ -616,6 +697,7 @@ public:
     size_t get_incoming_edges_array_index(int v, int edge_pos) { mirror(); return (size_t)(edges_count + host_in_rowptr[(size_t)v] + edge_pos); }
 private:
     std::vector<long long> host_in_rowptr; std::vector<int> host_out_adj, host_in_adj; bool mirrored = false;
+    std::vector<int64_t> mpi_bounds[2];
     void mirror()
     {
         if (mirrored) return;
@@ -787,7 +869,8 @@ public:
 // advance over ALL edges of a direction (ALL_ACTIVE) or over the rows flagged in a DENSE frontier: static edge tiles
 template <bool DENSE, class EdgeOp>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_static(const long long *rowptr, const int *adj, const int32_t *tile_row,
-                                                                  long long E, long long process_shift, const int *flags, EdgeOp edge_op)
+                                                                  long long E, long long process_shift, const int *flags, int row_lo, int row_hi,
+                                                                  EdgeOp edge_op)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int s_w[VGL_WAVES];
@@ -795,85 +878,189 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_static(const long lon
     const int n = (int)min((int64_t)VGL_TILE, (int64_t)E - e0);
     const int r_first = tile_row[blockIdx.x];
     const int r_last = tile_row[blockIdx.x + 1];
+    if (r_last < row_lo || r_first >= row_hi) return;       // (several ranks: tiles outside this rank's vertex range)
     vgl_tile_row_map(s_map, s_w, (const int64_t *)rowptr, e0, r_first, r_last);
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) {
         const int i = threadIdx.x + j * VGL_BLOCK;
         if (i < n) {
             const int src = r_first + s_map[i];
-            if (!DENSE || flags[src] > 0) {
+            if (src >= row_lo && src < row_hi && (!DENSE || flags[src] > 0)) {
                 const long long e = e0 + i;
                 edge_op(src, adj[e], (int)(e - rowptr[src]), process_shift + e, (int)(threadIdx.x & 63));
             }
         }
     }
 }
-// advance over a SPARSE frontier: tiles of the frontier's own edge list (plan = offs + tile_first)
-template <class EdgeOp>
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_sparse(const int *ids, const int64_t *offs, const int32_t *tile_first, int F,
-                                                                  long long M, const long long *rowptr, const int *adj,
-                                                                  long long process_shift, EdgeOp edge_op)
+// advance over a SPARSE frontier: tiles of the frontier's own edge list (plan = offs + tile_first).  Per frontier position of the tile
+// the source id, the offset of its first edge inside the tile and (row start - frontier edge offset) are staged in LDS, so that an edge
+// costs LDS lookups plus its adjacency load instead of three dependent global loads (ids[p], offs[p], rowptr[src]); tiles spanning more
+// than VGL_ADV_STAGE positions (thousands of empty or one-edge rows) read them from memory.
+constexpr int VGL_ADV_STAGE = 1024;
+#ifndef VGL_ADV_THREADS_VALUE
+#define VGL_ADV_THREADS_VALUE 512
+#endif
+constexpr int VGL_ADV_THREADS = VGL_ADV_THREADS_VALUE;   // threads per 2048-edge tile: four edges each -- the per-edge chains (adjacency, then whatever the
+                                               // user's operator gathers and stores) of a thread cannot overlap (its stores may alias its next
+                                               // loads), so more, shorter chains per tile keep more requests in flight than 256 threads x 8
+// vgl_tile_row_map (csrc/vgl_hip_internal.h) for a workgroup of THREADS threads
+template <int THREADS>
+__device__ __forceinline__ void vgl_tile_row_map_wide(int *s_map, int *s_w, const int64_t *starts, int64_t e0, int r_first, int r_last)
 {
+    constexpr int EPT = VGL_TILE / THREADS, WAVES = THREADS / 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) s_map[tid + j * THREADS] = 0;
+    __syncthreads();
+    for (int r = r_first + 1 + tid; r <= r_last; r += THREADS) {
+        const int64_t q = starts[r] - e0;          // > 0 because r_first contains e0
+        if (q < VGL_TILE) atomicMax(&s_map[(int)q], r - r_first);
+    }
+    __syncthreads();
+    int m[EPT];
+    int run = 0;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) { run = max(run, s_map[tid * EPT + j]); m[j] = run; }
+    const int inc = vgl_wave_incl_max(run);
+    if ((tid & 63) == 63) s_w[tid >> 6] = inc;
+    __syncthreads();
+    int pre = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) if (w < (tid >> 6)) pre = max(pre, s_w[w]);
+    int up = __shfl_up(inc, 1);
+    if ((tid & 63) == 0) up = 0;
+    pre = max(pre, up);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) s_map[tid * EPT + j] = max(m[j], pre);
+    __syncthreads();
+}
+template <class EdgeOp>
+__global__ __launch_bounds__(VGL_ADV_THREADS) void vgl_k_advance_sparse(const int *ids, const int64_t *offs, const int32_t *tile_first, int F,
+                                                                        long long M, const long long *rowptr, const int *adj,
+                                                                        long long process_shift, int row_lo, int row_hi, EdgeOp edge_op)
+{
+    constexpr int EPT = VGL_TILE / VGL_ADV_THREADS;
     __shared__ int s_map[VGL_TILE];
-    __shared__ int s_w[VGL_WAVES];
+    __shared__ int s_w[VGL_ADV_THREADS / 64];
+    __shared__ int s_src[VGL_ADV_STAGE];
+    __shared__ int s_first[VGL_ADV_STAGE];
+    __shared__ long long s_base[VGL_ADV_STAGE];
     const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
     const int n = (int)min((int64_t)VGL_TILE, (int64_t)M - e0);
     const int p_first = tile_first[blockIdx.x];
     const int p_last = tile_first[blockIdx.x + 1];      // last tile: owner of the last edge (written by the plan)
-    vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);
-#pragma unroll
-    for (int j = 0; j < VGL_EPT; j++) {
-        const int i = threadIdx.x + j * VGL_BLOCK;
-        if (i < n) {
-            const int p = p_first + s_map[i];
+    const int np = p_last - p_first + 1;
+    const bool staged = np <= VGL_ADV_STAGE;
+    if (staged)
+        for (int k = threadIdx.x; k < np; k += VGL_ADV_THREADS) {
+            const int p = p_first + k;
             const int src = ids[p];
-            const int local = (int)(e0 + i - offs[p]);
-            const long long e = rowptr[src] + local;
-            edge_op(src, adj[e], local, process_shift + e, (int)(threadIdx.x & 63));
+            const int64_t o = offs[p];
+            s_src[k] = src; s_first[k] = (int)(o - e0); s_base[k] = rowptr[src] - o;
+        }
+    vgl_tile_row_map_wide<VGL_ADV_THREADS>(s_map, s_w, offs, e0, p_first, p_last);      // ends with a barrier: the staged arrays are visible too
+    int srcs[EPT], locals[EPT], dsts[EPT];
+    long long es[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {                     // every adjacency load of the thread is issued before the first operator call
+        const int i = threadIdx.x + j * VGL_ADV_THREADS;
+        srcs[j] = -1;
+        if (i < n) {
+            const int k = s_map[i];
+            if (staged) { srcs[j] = s_src[k]; locals[j] = i - s_first[k]; es[j] = s_base[k] + e0 + i; }
+            else { const int p = p_first + k; srcs[j] = ids[p]; locals[j] = (int)(e0 + i - offs[p]); es[j] = rowptr[srcs[j]] + locals[j]; }
+            if (srcs[j] < row_lo || srcs[j] >= row_hi) srcs[j] = -1;
+            else dsts[j] = adj[es[j]];
         }
     }
+#pragma unroll
+    for (int j = 0; j < EPT; j++)
+        if (srcs[j] >= 0) edge_op(srcs[j], dsts[j], locals[j], process_shift + es[j], (int)(threadIdx.x & 63));
 }
 // per-vertex operator over all vertices / flagged vertices / listed vertices (compute_worker, multicore/compute.hpp:6-58)
 template <int MODE, class Op>     // 0 all-active, 1 dense (flags), 2 sparse (ids)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_vertex_op(int n, const long long *rowptr, const int *flags, const int *ids, Op op)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_vertex_op(int n, const long long *rowptr, const int *flags, const int *ids, int row_lo, int row_hi, Op op)
 {
     for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
         if (MODE == 1 && flags[i] <= 0) continue;
         const int src = (MODE == 2) ? ids[i] : i;
+        if (src < row_lo || src >= row_hi) continue;
         op(src, (int)(rowptr[src + 1] - rowptr[src]), (int)(threadIdx.x & 63));
     }
 }
-template <int MODE, class Op>     // reduce_op values materialised as doubles (exact for int / float operands)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_reduce_values(int n, const long long *rowptr, const int *flags, const int *ids, Op op, double *out)
-{
-    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
-        double v = 0.0;
-        if (!(MODE == 1 && flags[i] <= 0)) {
-            const int src = (MODE == 2) ? ids[i] : i;
-            v = (double)op(src, (int)(rowptr[src + 1] - rowptr[src]), (int)(threadIdx.x & 63));
-        }
-        out[i] = v;
-    }
-}
-// REDUCE_MAX: maximum of the materialised values per workgroup (the host folds the 256 partial results)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_max_partials(int n, const double *values, double *partials)
+// reduce_worker (multicore/reduce.hpp:6-152) in ONE pass: every workgroup folds the reduce_op values of its vertices (f64: exact for int /
+// float operands) in a fixed tree and leaves one partial; MAX = max(0, values), the reference's definition (reduce.hpp:80).
+template <int MODE, bool IS_MAX, class Op>     // 0 all-active, 1 dense (flags), 2 sparse (ids)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_reduce_partials(int n, const long long *rowptr, const int *flags, const int *ids, Op op, double *partials)
 {
     __shared__ double s[VGL_BLOCK / 64];
-    double m = 0.0;                                   // the reference's maximum starts from 0 (multicore/reduce.hpp:80)
-    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) m = values[i] > m ? values[i] : m;
+    double acc = 0.0;
+    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
+        if (MODE == 1 && flags[i] <= 0) continue;
+        const int src = (MODE == 2) ? ids[i] : i;
+        const double v = (double)op(src, (int)(rowptr[src + 1] - rowptr[src]), (int)(threadIdx.x & 63));
+        if (IS_MAX) acc = v > acc ? v : acc; else acc += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(acc, o); if (IS_MAX) acc = t > acc ? t : acc; else acc += t; }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < VGL_BLOCK / 64; w++) { if (IS_MAX) acc = s[w] > acc ? s[w] : acc; else acc += s[w]; }
+        partials[blockIdx.x] = acc;
+    }
+}
+// REDUCE_MAX: the maximum of the partials, folded on the device by one workgroup
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_max_fold(int n, const double *partials, double *out)
+{
+    __shared__ double s[VGL_BLOCK / 64];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += VGL_BLOCK) m = partials[i] > m ? partials[i] : m;
     for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(m, o); m = t > m ? t : m; }
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < VGL_BLOCK / 64; w++) m = s[w] > m ? s[w] : m;
-        partials[blockIdx.x] = m;
+    if (threadIdx.x == 0) { for (int w = 1; w < VGL_BLOCK / 64; w++) m = s[w] > m ? s[w] : m; out[0] = m; }
+}
+// generate_new_frontier: the user's filter condition as a predicate of the frontier-generation kernels (csrc/vgl_gnf.h)
+template <class Cond>
+struct vgl_pred_user {
+    Cond cond; const long long *rowptr;
+    __device__ uint32_t bits8(int32_t v0, int nvalid, uint32_t *aux) const
+    {
+        uint32_t b = 0;
+        *aux = 0;
+        for (int j = 0; j < nvalid; j++) b |= (uint32_t)(cond(v0 + j, (int)(rowptr[v0 + j + 1] - rowptr[v0 + j])) > 0) << j;
+        return b;
+    }
+};
+// exchange_vertices_array helpers (common/mpi_exchange.hpp:78-150): the merge of the other ranks' copies / changed entries with the user's operator
+template <class T, class MergeOp>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_merge_copies(int n, int parts, int self, const T *all, T *data, MergeOp merge_op)
+{
+    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
+        T acc = data[i];
+        for (int p = 0; p < parts; p++)
+            if (p != self) acc = merge_op(all[(size_t)p * n + i], acc);      // _new_data[i] = _merge_op(received_data[i], _new_data[i])  (mpi_exchange.hpp:146-149)
+        data[i] = acc;
     }
 }
-template <class Cond>
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_filter_flags(int n, const long long *rowptr, Cond cond, int *flags)
+// one rank's (index, value bits) list: its indexes are distinct, so plain stores are safe (the lists of different ranks are applied one after the other)
+template <class T, class MergeOp>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_merge_pairs(const int *list, long long max_pairs, int n, T *data, MergeOp merge_op)
 {
-    for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK)
-        flags[i] = cond(i, (int)(rowptr[i + 1] - rowptr[i])) > 0 ? 1 : 0;
+    static_assert(sizeof(T) == 4, "pair lists carry 4-byte values");
+    const long long count = list[0] < max_pairs ? list[0] : max_pairs;
+    for (long long k = (long long)blockIdx.x * VGL_BLOCK + threadIdx.x; k < count; k += (long long)gridDim.x * VGL_BLOCK) {
+        const int idx = list[1 + 2 * k];
+        if (idx < 0 || idx >= n) continue;
+        T v;
+        const int bits = list[2 + 2 * k];
+        memcpy(&v, &bits, 4);
+        data[idx] = merge_op(v, data[idx]);
+    }
+}
+__global__ void vgl_k_list_heads(const int *lists, long long stride, int parts, int *out)
+{
+    if ((int)threadIdx.x < parts) out[threadIdx.x] = lists[(long long)threadIdx.x * stride];
 }
 
 // VECTOR_CSR_GRAPH: the reference's advance (multicore/advance_worker.hpp:204-319) hands rows of at least VECTOR_CORE_THRESHOLD_VALUE
@@ -908,26 +1095,32 @@ static const vgl_empty_edge_op EMPTY_EDGE_OP;
 // ------------------------------------------------------------------------------------------------------------------
 class GraphAbstractionsHIP {
     VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
-    double *reduce_buffer = nullptr, *reduce_partials = nullptr;
+    double *reduce_partials = nullptr;          // one per workgroup of a reduce (+ the folded maximum)
 
     static int active_count(VGL_Graph &g, VGL_Frontier &f) { return f.get_sparsity_type() == ALL_ACTIVE_FRONTIER ? g.get_vertices_count() : f.size(); }
     static unsigned grid_for(long long n) { long long b = (n + VGL_BLOCK - 1) / VGL_BLOCK; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
     template <class T> static constexpr bool is_empty_vertex_op() { return std::is_same<typename std::decay<T>::type, vgl_empty_vertex_op>::value; }
 
+    // see MemoryAPI::live_host_arrays
+    static bool sync_after_primitive()
+    {
+        static const bool forced = getenv("VGL_SYNC_PRIMITIVES") && getenv("VGL_SYNC_PRIMITIVES")[0] == '1';
+        return forced || MemoryAPI::live_host_arrays() > 0;
+    }
     void set_correct_direction() {}
     template <typename _T, typename... Types>
     void set_correct_direction(_T &first, Types &...rest) { first.reorder(current_traversal_direction); first.set_direction(current_traversal_direction); set_correct_direction(rest...); }
 
     template <class Op>
-    void vertex_pass(VGL_Graph &g, VGL_Frontier &f, TraversalDirection dir, Op &&op)
+    void vertex_pass(VGL_Graph &g, VGL_Frontier &f, TraversalDirection dir, Op &&op, int row_lo = 0, int row_hi = 0x7fffffff)
     {
         const vgl_csr_view v = g.get_direction_view(dir);
         const FrontierSparsityType t = f.get_sparsity_type();
         hipStream_t st = VGL_RUNTIME::stream();
         const int V = g.get_vertices_count();
-        if (t == ALL_ACTIVE_FRONTIER) hipLaunchKernelGGL((vgl_k_vertex_op<0, typename std::decay<Op>::type>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), op);
-        else if (t == DENSE_FRONTIER) hipLaunchKernelGGL((vgl_k_vertex_op<1, typename std::decay<Op>::type>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), op);
-        else if (f.size() > 0) hipLaunchKernelGGL((vgl_k_vertex_op<2, typename std::decay<Op>::type>), dim3(grid_for(f.size())), dim3(VGL_BLOCK), 0, st, f.size(), v.rowptr, f.get_flags(), f.get_ids(), op);
+        if (t == ALL_ACTIVE_FRONTIER) hipLaunchKernelGGL((vgl_k_vertex_op<0, typename std::decay<Op>::type>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), row_lo, row_hi, op);
+        else if (t == DENSE_FRONTIER) hipLaunchKernelGGL((vgl_k_vertex_op<1, typename std::decay<Op>::type>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), row_lo, row_hi, op);
+        else if (f.size() > 0) hipLaunchKernelGGL((vgl_k_vertex_op<2, typename std::decay<Op>::type>), dim3(grid_for(f.size())), dim3(VGL_BLOCK), 0, st, f.size(), v.rowptr, f.get_flags(), f.get_ids(), row_lo, row_hi, op);
         VGL_HIP_RT(hipGetLastError());
     }
 
@@ -942,7 +1135,10 @@ class GraphAbstractionsHIP {
         long long work = 0;                                 // edges the frontier touches (advance_worker.hpp:140-149)
         const vgl_csr_view v = g.get_direction_view(dir);
         const long long process_shift = (dir == GATHER) ? g.get_edges_count() : 0;     // compute_process_shift (graph_abstractions.hpp:19-28)
-        if (!is_empty_vertex_op<PreOp>()) vertex_pass(g, f, dir, pre_op);
+        // several ranks (inner_mpi_processing, common/advance.hpp:28-31, nec/advance_worker.hpp:239-251): this rank's vertex range only
+        const std::pair<int, int> range = g.get_mpi_thresholds(dir);
+        const int row_lo = range.first, row_hi = range.second;
+        if (!is_empty_vertex_op<PreOp>()) vertex_pass(g, f, dir, pre_op, row_lo, row_hi);
         const FrontierSparsityType t = f.get_sparsity_type();
         using E = typename std::decay<EdgeOp>::type;
         if (t == SPARSE_FRONTIER) {
@@ -951,21 +1147,21 @@ class GraphAbstractionsHIP {
             work = M;
             if (M > 0) {
                 const unsigned nt = (unsigned)((M + VGL_TILE - 1) / VGL_TILE);
-                hipLaunchKernelGGL((vgl_k_advance_sparse<E>), dim3(nt), dim3(VGL_BLOCK), 0, st, f.get_ids(), offs, tile_first, f.size(), (long long)M,
-                                   v.rowptr, v.adj, process_shift, edge_op);
+                hipLaunchKernelGGL((vgl_k_advance_sparse<E>), dim3(nt), dim3(VGL_ADV_THREADS), 0, st, f.get_ids(), offs, tile_first, f.size(), (long long)M,
+                                   v.rowptr, v.adj, process_shift, row_lo, row_hi, edge_op);
             }
         } else if (v.edges > 0) {
             work = t == ALL_ACTIVE_FRONTIER ? v.edges : f.get_neighbours_count();
             const int32_t *tile_row; int64_t ntiles;
             VGL_HIP_CALL(vgl_hip_graph_tile_rows(g.get_handle(), dir == GATHER, &tile_row, &ntiles));
             if (t == DENSE_FRONTIER)
-                hipLaunchKernelGGL((vgl_k_advance_static<true, E>), dim3((unsigned)ntiles), dim3(VGL_BLOCK), 0, st, v.rowptr, v.adj, tile_row, v.edges, process_shift, f.get_flags(), edge_op);
+                hipLaunchKernelGGL((vgl_k_advance_static<true, E>), dim3((unsigned)ntiles), dim3(VGL_BLOCK), 0, st, v.rowptr, v.adj, tile_row, v.edges, process_shift, f.get_flags(), row_lo, row_hi, edge_op);
             else
-                hipLaunchKernelGGL((vgl_k_advance_static<false, E>), dim3((unsigned)ntiles), dim3(VGL_BLOCK), 0, st, v.rowptr, v.adj, tile_row, v.edges, process_shift, f.get_flags(), edge_op);
+                hipLaunchKernelGGL((vgl_k_advance_static<false, E>), dim3((unsigned)ntiles), dim3(VGL_BLOCK), 0, st, v.rowptr, v.adj, tile_row, v.edges, process_shift, f.get_flags(), row_lo, row_hi, edge_op);
         }
         VGL_HIP_RT(hipGetLastError());
-        if (!is_empty_vertex_op<PostOp>()) vertex_pass(g, f, dir, post_op);
-        VGL_RUNTIME::sync();                 // primitives are synchronous, like the reference GPU backend (advance_csr.hpp:204)
+        if (!is_empty_vertex_op<PostOp>()) vertex_pass(g, f, dir, post_op, row_lo, row_hi);
+        if (sync_after_primitive()) VGL_RUNTIME::sync();     // synchronous like the reference GPU backend (advance_csr.hpp:204) whenever the host could see a result
         performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, dir == GATHER);
     }
 
@@ -998,8 +1194,12 @@ public:
     template <typename _T> void attach_data(VerticesArray<_T> &array) { user_data_containers.push_back((void *)&array); }
 
     GraphAbstractionsHIP(VGL_Graph &g, TraversalDirection initial = SCATTER) : processed_graph_ptr(&g), current_traversal_direction(initial)
-    { MemoryAPI::allocate_device_array(&reduce_buffer, (size_t)g.get_vertices_count()); MemoryAPI::allocate_device_array(&reduce_partials, 256); }
-    ~GraphAbstractionsHIP() { MemoryAPI::free_device_array(reduce_buffer); MemoryAPI::free_device_array(reduce_partials); }
+    { MemoryAPI::allocate_device_array(&reduce_partials, 1024 + 8); }
+    ~GraphAbstractionsHIP()
+    {
+        MemoryAPI::free_device_array(reduce_partials);
+        MemoryAPI::free_device_array((char *)exchange_scratch); MemoryAPI::free_array(exchange_heads);
+    }
 
     // change_traversal_direction (graph_abstractions.hpp:87-125): tags and permutes every passed container; with identity
     // numbering only the tag changes
@@ -1040,7 +1240,7 @@ public:
     {
         const vgl_stopwatch watch;
         vertex_pass(g, f, current_traversal_direction, compute_op);
-        VGL_RUNTIME::sync();
+        if (sync_after_primitive()) VGL_RUNTIME::sync();
         performance_stats.update_compute_stats(watch.seconds(), (size_t)active_count(g, f));
     }
 
@@ -1054,24 +1254,27 @@ public:
         hipStream_t st = VGL_RUNTIME::stream();
         using R = typename std::decay<ReduceOperation>::type;
         const int V = g.get_vertices_count();
-        int n = V;
-        if (t == ALL_ACTIVE_FRONTIER) hipLaunchKernelGGL((vgl_k_reduce_values<0, R>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_buffer);
-        else if (t == DENSE_FRONTIER) hipLaunchKernelGGL((vgl_k_reduce_values<1, R>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_buffer);
-        else { n = f.size(); if (n > 0) hipLaunchKernelGGL((vgl_k_reduce_values<2, R>), dim3(grid_for(n)), dim3(VGL_BLOCK), 0, st, n, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_buffer); }
+        const int n = t == SPARSE_FRONTIER ? f.size() : V;
+        if (n <= 0) return (_T)0;
+        const int nb = (int)std::min<long long>(1024, ((long long)n + VGL_BLOCK - 1) / VGL_BLOCK);
+        const bool mx = type == REDUCE_MAX;
+#define VGL_REDUCE_LAUNCH(MODE)                                                                                                                          \
+        do {                                                                                                                                             \
+            if (mx) hipLaunchKernelGGL((vgl_k_reduce_partials<MODE, true, R>), dim3(nb), dim3(VGL_BLOCK), 0, st, n, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_partials); \
+            else hipLaunchKernelGGL((vgl_k_reduce_partials<MODE, false, R>), dim3(nb), dim3(VGL_BLOCK), 0, st, n, v.rowptr, f.get_flags(), f.get_ids(), reduce_op, reduce_partials); \
+        } while (0)
+        if (t == ALL_ACTIVE_FRONTIER) VGL_REDUCE_LAUNCH(0);
+        else if (t == DENSE_FRONTIER) VGL_REDUCE_LAUNCH(1);
+        else VGL_REDUCE_LAUNCH(2);
+#undef VGL_REDUCE_LAUNCH
         VGL_HIP_RT(hipGetLastError());
         double r = 0.0;
-        if (type == REDUCE_MAX) {                         // max(0, values of the active vertices), the reference's definition
-            if (n <= 0) return (_T)0;
-            constexpr int NP = 256;
-            hipLaunchKernelGGL(vgl_k_max_partials, dim3(NP), dim3(VGL_BLOCK), 0, st, n, reduce_buffer, reduce_partials);
+        if (mx) {
+            hipLaunchKernelGGL(vgl_k_max_fold, dim3(1), dim3(VGL_BLOCK), 0, st, nb, (const double *)reduce_partials, reduce_partials + 1024);
             VGL_HIP_RT(hipGetLastError());
-            double h[NP];
-            VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h, reduce_partials, sizeof(h)));
-            for (int i = 0; i < NP; i++) r = h[i] > r ? h[i] : r;
-            performance_stats.update_reduce_stats(watch.seconds(), (size_t)n);
-            return (_T)r;
-        }
-        VGL_HIP_CALL(vgl_hip_reduce_sum_f64_buffer(VGL_RUNTIME::ctx(), n, reduce_buffer, &r));
+            VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), &r, reduce_partials + 1024, sizeof(double)));
+        } else
+            VGL_HIP_CALL(vgl_hip_reduce_sum_f64_buffer(VGL_RUNTIME::ctx(), nb, reduce_partials, &r));      // fixed-order fold of the partials
         performance_stats.update_reduce_stats(watch.seconds(), (size_t)n);
         return (_T)r;
     }
@@ -1083,16 +1286,126 @@ public:
         using C = typename std::decay<FilterCondition>::type;
         const int V = g.get_vertices_count();
         const vgl_stopwatch watch;
-        hipLaunchKernelGGL((vgl_k_filter_flags<C>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), V, v.rowptr, filter_cond, f.get_flags());
-        VGL_HIP_RT(hipGetLastError());
         f.set_direction(current_traversal_direction);
         // CSR_GRAPH frontiers are ALL_ACTIVE or SPARSE (generate_new_frontier.hpp:113-164); VECTOR_CSR_GRAPH ones turn DENSE (flags only)
         // above FRONTIER_TYPE_CHANGE_THRESHOLD = 0.7 of the vertices (generate_new_frontier.hpp:67-91, settings.h)
         const double dense_threshold = g.get_format() == VECTOR_CSR_GRAPH ? 0.7 : 0.0;
-        VGL_HIP_CALL(vgl_hip_gnf_from_flags(VGL_RUNTIME::ctx(), g.get_handle(), f.get_flags(), dense_threshold, f.get_handle()));
+        // ONE pass evaluates the condition, writes the flags and counts (the last workgroup scans the per-tile counts and hands size and
+        // neighbour count to the host); the compaction then reads the flags and leaves the ids' out-edge offsets behind for scatter
+        vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+        vgl_hip_frontier *fh = f.get_handle();
+        const bool plan = current_traversal_direction == SCATTER;
+        int64_t *offs = plan ? vgl_hip_frontier_plan_offsets(c, g.get_handle(), fh) : nullptr;
+        if (plan && !offs) throw vgl_hip_last_error();
+        const vgl_pred_user<C> pred{filter_cond, v.rowptr};
+        if (vgl_gnf_run(c, g.get_handle(), pred, fh->ids, offs, nullptr, nullptr, fh->flags, false, true)) throw vgl_hip_last_error();
+        VGL_HIP_CALL(vgl_hip_gnf_complete(c, g.get_handle(), fh, dense_threshold, plan ? 1 : 0));
         performance_stats.update_gnf_stats(watch.seconds(), (size_t)V);
     }
 
+    // ---- exchange_vertices_array (common/graph_abstractions.h:157-168, common/mpi_exchange.hpp:300-365): the three policies of the
+    //      reference over the library's communicator (RCCL on the context's stream).  merge_op must be callable on the device
+    //      ([] __device__ (T received, T mine) -> T); a world of one returns at once, like the reference. ----
+    template <typename _TGraph, typename _T>
+    void exchange_vertices_array(DataExchangePolicy policy, _TGraph &g, VerticesArray<_T> &data)
+    {
+        if (VGL_RUNTIME::get_mpi_proc_num() == 1) return;
+        if (policy == EXCHANGE_RECENTLY_CHANGED)
+            throw "Error in GraphAbstractionsHIP::exchange_vertices_array : old data must be provided for EXCHANGE_RECENTLY_CHANGED";
+        if (policy != EXCHANGE_PRIVATE_DATA) throw "Currently not supported";
+        // every rank computed the entries of its own vertex range: all-gather of the owned slices in place (exchange_data_private)
+        const std::vector<int64_t> &bounds = g.get_mpi_bounds(current_traversal_direction);
+        VGL_HIP_CALL(vgl_hip_exchange_allgather_slices(VGL_RUNTIME::comm(), data.get_ptr(), bounds.data(), (int)sizeof(_T)));
+        VGL_RUNTIME::sync();
+    }
+    template <typename _TGraph, typename _T, typename MergeOp>
+    void exchange_vertices_array(DataExchangePolicy policy, _TGraph &g, VerticesArray<_T> &data, MergeOp &&merge_op)
+    {
+        if (VGL_RUNTIME::get_mpi_proc_num() == 1) return;
+        if (policy != EXCHANGE_ALL)
+            throw "Error in GraphAbstractionsHIP::exchange_vertices_array : old data is NOT provided for NON EXCHANGE_RECENTLY_CHANGED";
+        exchange_all(data, merge_op);
+        VGL_RUNTIME::sync();
+    }
+    template <typename _TGraph, typename _T, typename MergeOp>
+    void exchange_vertices_array(DataExchangePolicy policy, _TGraph &g, VerticesArray<_T> &data, VerticesArray<_T> &old_data, MergeOp &&merge_op)
+    {
+        if (VGL_RUNTIME::get_mpi_proc_num() == 1) return;
+        if (policy != EXCHANGE_RECENTLY_CHANGED)
+            throw "Error in GraphAbstractionsHIP::exchange_vertices_array : old data is provided for NON EXCHANGE_RECENTLY_CHANGED";
+        exchange_changed(data, old_data, merge_op);
+        VGL_RUNTIME::sync();
+    }
+
+private:
+    void *exchange_scratch = nullptr; size_t exchange_scratch_bytes = 0; int *exchange_heads = nullptr;
+    void *exchange_buffer(size_t bytes)
+    {
+        if (exchange_scratch_bytes < bytes) {
+            MemoryAPI::free_device_array((char *)exchange_scratch);
+            exchange_scratch = nullptr; exchange_scratch_bytes = 0;
+            char *p = nullptr;
+            MemoryAPI::allocate_device_array(&p, bytes);
+            exchange_scratch = p; exchange_scratch_bytes = bytes;
+        }
+        return exchange_scratch;
+    }
+    // EXCHANGE_ALL: every rank receives every copy and folds them with merge_op in rank order
+    template <typename _T, typename MergeOp>
+    void exchange_all(VerticesArray<_T> &data, MergeOp &&merge_op)
+    {
+        const int P = VGL_RUNTIME::get_mpi_proc_num(), rank = VGL_RUNTIME::get_mpi_rank(), n = data.size();
+        _T *all = (_T *)exchange_buffer(sizeof(_T) * (size_t)n * (size_t)P);
+        VGL_HIP_CALL(vgl_hip_exchange_allgather(VGL_RUNTIME::comm(), data.get_ptr(), all, (int64_t)sizeof(_T) * n));
+        using M = typename std::decay<MergeOp>::type;
+        hipLaunchKernelGGL((vgl_k_merge_copies<_T, M>), dim3(grid_for(n)), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), n, P, rank, (const _T *)all, data.get_ptr(), merge_op);
+        VGL_HIP_RT(hipGetLastError());
+    }
+    // EXCHANGE_RECENTLY_CHANGED: (index, value) pairs of the entries that differ from old_data, from every rank; the heads of the lists
+    // (count + 2048 pairs) travel first and are the whole exchange when nobody changed more; beyond n / (2 ranks) changed entries on some
+    // rank the whole arrays are exchanged instead (fewer bytes than the lists)
+    template <typename _T, typename MergeOp>
+    typename std::enable_if<sizeof(_T) == 4>::type exchange_changed(VerticesArray<_T> &data, VerticesArray<_T> &old_data, MergeOp &&merge_op)
+    {
+        const int P = VGL_RUNTIME::get_mpi_proc_num(), rank = VGL_RUNTIME::get_mpi_rank(), n = data.size();
+        constexpr long long SMALL = 2048;
+        const long long cap = std::max<long long>(SMALL, n / (2 * P)), small_stride = 1 + 2 * SMALL;
+        const size_t mine_ints = (size_t)(1 + 2 * cap);
+        int *mine = (int *)exchange_buffer(sizeof(int) * (mine_ints + (size_t)P * mine_ints));
+        int *all = mine + mine_ints;
+        vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+        if (!exchange_heads) MemoryAPI::allocate_array(&exchange_heads, 64);
+        VGL_HIP_CALL(vgl_hip_diff_to_pairs_u32(c, n, old_data.get_ptr(), data.get_ptr(), (int32_t)cap, mine));
+        VGL_HIP_CALL(vgl_hip_exchange_allgather(VGL_RUNTIME::comm(), mine, all, small_stride * 4));
+        hipLaunchKernelGGL(vgl_k_list_heads, dim3(1), dim3(64), 0, VGL_RUNTIME::stream(), (const int *)all, small_stride, P, exchange_heads);
+        VGL_HIP_RT(hipGetLastError());
+        VGL_RUNTIME::sync();
+        long long most = 0;
+        for (int p = 0; p < P; p++) most = std::max<long long>(most, exchange_heads[p]);
+        if (most == 0) return;
+        if (most > cap) { exchange_all(data, merge_op); return; }
+        long long stride = small_stride, pairs = SMALL;
+        if (most > SMALL) {
+            pairs = 1;
+            while (pairs < most) pairs <<= 1;
+            pairs = std::min(pairs, cap);
+            stride = 1 + 2 * pairs;
+            VGL_HIP_CALL(vgl_hip_exchange_allgather(VGL_RUNTIME::comm(), mine, all, stride * 4));
+        }
+        using M = typename std::decay<MergeOp>::type;
+        for (int p = 0; p < P; p++)
+            if (p != rank && exchange_heads[p] > 0)
+                hipLaunchKernelGGL((vgl_k_merge_pairs<_T, M>), dim3(grid_for(exchange_heads[p])), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), (const int *)(all + (size_t)p * stride),
+                                   pairs, n, data.get_ptr(), merge_op);
+        VGL_HIP_RT(hipGetLastError());
+    }
+    template <typename _T, typename MergeOp>
+    typename std::enable_if<sizeof(_T) != 4>::type exchange_changed(VerticesArray<_T> &data, VerticesArray<_T> &, MergeOp &&merge_op)
+    {
+        exchange_all(data, merge_op);       // pair lists carry 4-byte values: wider types take the whole-array exchange
+    }
+
+public:
     void enable_safe_stores() {}         // no-op off NEC (graph_abstractions_multicore.h:295-296)
     void disable_safe_stores() {}
 };
