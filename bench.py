@@ -71,7 +71,8 @@ def cc_hook_pass(ctx):
         return n, ms, "atomic-min kernel"
     ng, msg = ctx.timing_get("cc_hook_gather")
     na, msa = ctx.timing_get("cc_hook_accumulate")
-    return ng, msg + msa, "blocked (LDS windows)"
+    nf, msf = ctx.timing_get("cc_hook_fused")
+    return max(ng, nf), msg + msa + msf, "blocked (LDS windows; dense block pairs as fused tiles)" if nf else "blocked (LDS windows)"
 
 
 # ------------------------------------------------------------------------------------------------------------------------

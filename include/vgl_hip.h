@@ -37,6 +37,9 @@ const char *vgl_hip_last_error(void);
 int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out);
 int vgl_hip_ctx_destroy(vgl_hip_ctx *ctx);
 int vgl_hip_ctx_sync(vgl_hip_ctx *ctx);
+/* plan builders take their scratch and plan arrays from the device's stream-ordered memory pool, which keeps freed memory cached (a
+ * second build of the same size then pays no allocator or first-touch cost); this hands the cached memory back to the driver */
+int vgl_hip_ctx_trim(vgl_hip_ctx *ctx);
 void *vgl_hip_ctx_stream(vgl_hip_ctx *ctx);
 
 /* ---- device memory (replaces MemoryAPI::allocate_array / move_array_to_device, memory_API.hpp:4-15,100-110) ---- */

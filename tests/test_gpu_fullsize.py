@@ -7,6 +7,8 @@ oracle's (tests/test_gpu_parity.py::build_case; config 1 below repeats that proo
 the oracle, whose OpenMP team is sized to the CPUs the box grants (oracle.host_cpus()).  Reference entry points:
 apps/bfs/bfs.cpp:41-46 (-check), algorithms/sssp/shortest_paths.hpp:85-163, algorithms/pr/pr.hpp:7-149,
 algorithms/cc/shiloach_vishkin.hpp:7-88."""
+import os
+
 import numpy as np
 import pytest
 
@@ -93,17 +95,33 @@ def test_config3_bellman_ford_sssp_rmat24(rmat24, ctx, oracle):
     """configs[2]: Bellman-Ford SSSP on RMAT-24 x 32 with f32 weights: every schedule reaches the oracle's f32 bits"""
     from vectorgraphlibrary_amd import api
     g, w, host = rmat24
-    s = _sources(host["rowptr"], 1, 240)[0]
-    ref, iters = oracle.sssp_bellman_ford(host["rowptr"], host["adj"], host["w"], s, parallel=True)
-    ref_bits = ref.view(np.int32)
-    assert iters > 2 and int((ref < 3.0e38).sum()) > (1 << 22)
-    for mode in (api.SSSP_ALL_ACTIVE, api.SSSP_ACTIVE_TILES, api.SSSP_DELTA_STEPPING):
-        dist, st = api.sssp(g, w, s, mode, raw=True, delta=10.0)
-        assert (dist.cpu().numpy().view(np.int32) == ref_bits).all(), f"SSSP mode {mode}: distances differ from the oracle"
-    for name in ("SSSP_PULL", "SSSP_DIRECTION_OPT"):
-        if hasattr(api, name):
-            dist, st = api.sssp(g, w, s, getattr(api, name), raw=True)
-            assert (dist.cpu().numpy().view(np.int32) == ref_bits).all(), f"{name}: distances differ from the oracle"
+    # the pull / direction-optimising schedules run on ONE blocked plan (dense block pairs as fused tiles), as a caller would keep it
+    plan = api.SsspPullPlan(g, w)
+    nofuse = None
+    for k, s in enumerate(_sources(host["rowptr"], 3, 240)):
+        ref, iters = oracle.sssp_bellman_ford(host["rowptr"], host["adj"], host["w"], s, parallel=True)
+        ref_bits = ref.view(np.int32)
+        assert iters > 2 and int((ref < 3.0e38).sum()) > (1 << 22)
+        modes = [("ALL_ACTIVE", dict(mode=api.SSSP_ALL_ACTIVE)), ("ACTIVE_TILES", dict(mode=api.SSSP_ACTIVE_TILES)),
+                 ("DELTA_STEPPING", dict(mode=api.SSSP_DELTA_STEPPING, delta=10.0)), ("PULL", dict(mode=api.SSSP_PULL, plan=plan)),
+                 ("DIRECTION_OPT", dict(mode=api.SSSP_DIRECTION_OPT, plan=plan))]
+        if k > 0:
+            modes = modes[1:]                        # the all-active sweep (16+ passes over all edges) once is enough
+        for name, kw in modes:
+            dist, st = api.sssp(g, w, s, raw=True, **kw)
+            assert (dist.cpu().numpy().view(np.int32) == ref_bits).all(), f"source {s}, SSSP {name}: distances differ from the oracle"
+            if name == "DIRECTION_OPT":
+                assert st["pull_steps"] > 0 and st["push_steps"] > 0
+        if k == 0:                                    # the two-pass layout without fused tiles reaches the same bits
+            os.environ["VGL_BLK_FUSE_MIN"] = "0"
+            try:
+                nofuse = api.SsspPullPlan(g, w)
+            finally:
+                os.environ.pop("VGL_BLK_FUSE_MIN")
+            dist, _ = api.sssp(g, w, s, raw=True, mode=api.SSSP_PULL, plan=nofuse)
+            assert (dist.cpu().numpy().view(np.int32) == ref_bits).all()
+            nofuse.close()
+    plan.close()
 
 
 def test_config4_pagerank_uniform25(ctx, oracle):
@@ -118,14 +136,11 @@ def test_config4_pagerank_uniform25(ctx, oracle):
     rowptr, adj = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy()
     ref = oracle.pagerank(rowptr, adj, it, 1, parallel=True)
     del rowptr, adj
-    for name in ("PR_EXACT_ORDER", "PR_BLOCKED"):
-        kw = {"mode": getattr(api, name)} if hasattr(api, name) else {}
-        ranks, st = api.page_rank(g, it, **kw)
+    for name, mode in (("PR_EXACT_ORDER", api.PR_EXACT_ORDER), ("PR_BLOCKED", api.PR_BLOCKED)):
+        ranks, st = api.page_rank(g, it, mode=mode)
         rk = ranks.cpu().numpy()
         assert _relerr(rk, ref) <= PR_RTOL, f"{name}: {_relerr(rk, ref)}"
         assert abs(st["ranks_sum"] - float(rk.astype(np.float64).sum())) < 1e-9
-        if not kw:
-            break
     g.close()
     torch.cuda.empty_cache()
 

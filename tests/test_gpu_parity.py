@@ -1043,13 +1043,18 @@ def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, orac
     g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True, renumber=renumber)
     w_d = ctx.gather_u32(g.perm, ctx.gen_weights(src.numel(), seed))
     rowptr, adj, w = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy(), w_d.cpu().numpy()
-    for unit in ("", "64"):
+    # layouts: default (two-pass at these sizes), blocks cut into 64-chunk units, and dense block pairs as FUSED TILES -- forced down to
+    # pairs of 64 edges, with 64-chunk pieces so that a pair is spread over several workgroups (what RMAT-24's hub pairs go through)
+    for unit, fuse in (("", ""), ("64", ""), ("", "64"), ("64", "64")):
         if unit:
-            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = unit
+            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = os.environ["VGL_BLK_FUSED_UNIT"] = unit
+        if fuse:
+            os.environ["VGL_BLK_FUSE_MIN"] = fuse
         try:
             plan = api.SsspPullPlan(g, w_d)
         finally:
-            os.environ.pop("VGL_BLK_GATHER_UNIT", None), os.environ.pop("VGL_BLK_ACCUM_UNIT", None)
+            for name in ("VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BLK_FUSED_UNIT", "VGL_BLK_FUSE_MIN"):
+                os.environ.pop(name, None)
         for k in range(2):
             s = O.pick_source(rowptr, seed, k)
             ref, _ = O.sssp_bellman_ford(rowptr, adj, w, s)
@@ -1061,8 +1066,8 @@ def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, orac
                     wd, wst = api.sswp(g, w_d, s, api.SSSP_DIRECTION_OPT, raw=True, plan=plan)
                 finally:
                     del os.environ["VGL_SSSP_PULL_SHARE"]
-                assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all(), (unit, k, share)
-                assert (wd.cpu().numpy().view(np.int32) == refw.view(np.int32)).all(), (unit, k, share)
+                assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all(), (unit, fuse, k, share)
+                assert (wd.cpu().numpy().view(np.int32) == refw.view(np.int32)).all(), (unit, fuse, k, share)
                 assert st["push_steps"] + st["pull_steps"] == st["iterations"]
                 if share == "2":
                     assert st["pull_steps"] == 0
@@ -1084,14 +1089,18 @@ def test_cc_blocked_hook(kind, scale, ef, symmetric, ctx, oracle):
     O = oracle
     g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, kind, scale, ef, 17, symmetric=symmetric)
     ref, _ = O.cc_sv(rowptr, adj)
-    for unit in ("", "64"):
+    # layouts: default (dense pairs of 16384-id blocks become fused tiles from 16384 edges: most pairs of these graphs), everything two-pass,
+    # and both with 64-chunk units / pieces
+    for unit, fuse in (("", ""), ("64", ""), ("", "0"), ("64", "0"), ("64", "64")):
         os.environ["VGL_CC_BLOCKED"] = "1"
         if unit:
-            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = unit
+            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = os.environ["VGL_BLK_FUSED_UNIT"] = unit
+        if fuse:
+            os.environ["VGL_BLK_FUSE_MIN"] = fuse
         try:
             g2 = api.Graph(ctx, V, g.out_rowptr, g.out_adj, g.in_rowptr, g.in_adj)
             comp, st = api.connected_components(g2)
-            assert (comp.cpu().numpy() == ref).all(), (unit, "whole graph")
+            assert (comp.cpu().numpy() == ref).all(), (unit, fuse, "whole graph")
             bounds = ctx.partition_rows(g.out_rowptr, 3)
             shards = [g.shard(bounds[p], bounds[p + 1]) for p in range(3)]
             comps = torch.arange(V, dtype=torch.int32, device=ctx.device)
@@ -1107,7 +1116,7 @@ def test_cc_blocked_hook(kind, scale, ef, symmetric, ctx, oracle):
                 s.close()
             g2.close()
         finally:
-            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT"):
+            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BLK_FUSED_UNIT", "VGL_BLK_FUSE_MIN"):
                 os.environ.pop(k, None)
     g.close()
 

@@ -13,25 +13,61 @@
 namespace {
 
 struct dev_bufs {                                   // frees whatever the build still holds when it leaves, error or not
+    hipStream_t st = nullptr;
     std::vector<void *> ptrs;
     template <class T> hipError_t alloc(T **p, size_t n)
     {
-        hipError_t e = hipMalloc((void **)p, sizeof(T) * std::max<size_t>(n, 1));
+        hipError_t e = vgl_pool_alloc(st, (void **)p, sizeof(T) * std::max<size_t>(n, 1));
         if (e == hipSuccess) ptrs.push_back(*p);
         return e;
     }
     void release(void *p)
     {
-        for (auto &q : ptrs) if (q == p) { hipFree(q); q = nullptr; }
+        for (auto &q : ptrs) if (q == p) { vgl_pool_free(st, q); q = nullptr; }
     }
-    void free_all() { for (auto &q : ptrs) if (q) { hipFree(q); q = nullptr; } }
+    void free_all() { for (auto &q : ptrs) if (q) { vgl_pool_free(st, q); q = nullptr; } }
     ~dev_bufs() { free_all(); }
 };
 
-// key = ab * nG + gb (sentinel nseg for dropped self loops), value = g_lo | a_lo << 16
+// edges per (gather block, accumulate block) pair of VGL_FBLK x VGL_FBLK ids: count16[gb16 * nA16 + ab16].  The rows of a 2048-edge tile
+// lie in one row block almost always, so the tile counts its column blocks in LDS and adds the non-zero counters to memory once (a
+// global atomic per edge would serialise on the hub pairs: millions of increments of one address).
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_hist16(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E, int32_t row_base,
+                                                              int gather_rows, int skip_self, uint32_t nA16, uint32_t ncol16, uint32_t *count16)
+{
+    __shared__ int s_map[VGL_TILE];
+    __shared__ int s_w[VGL_WAVES];
+    __shared__ uint32_t s_h[8192];
+    const int64_t e0 = (int64_t)blockIdx.x * VGL_TILE;
+    const int n = (int)min((int64_t)VGL_TILE, E - e0);
+    const int r_first = tile_row[blockIdx.x], r_last = tile_row[blockIdx.x + 1];
+    for (uint32_t i = threadIdx.x; i < ncol16; i += VGL_BLOCK) s_h[i] = 0;
+    vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);       // (starts with a barrier after its own stores: s_h is cleared for everybody)
+    const uint32_t row16_tile = (uint32_t)r_first >> VGL_FBLK_BITS;
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;
+        if (i < n) {
+            const uint32_t r = (uint32_t)(r_first + s_map[i]), col = (uint32_t)adj[e0 + i];
+            if (skip_self && (uint32_t)row_base + r == col) continue;
+            const uint32_t row16 = r >> VGL_FBLK_BITS, col16 = col >> VGL_FBLK_BITS;
+            if (row16 == row16_tile) atomicAdd(&s_h[col16], 1u);
+            else atomicAdd(&count16[gather_rows ? row16 * nA16 + col16 : col16 * nA16 + row16], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ncol16; i += VGL_BLOCK) {
+        const uint32_t h = s_h[i];
+        if (h) atomicAdd(&count16[gather_rows ? row16_tile * nA16 + i : i * nA16 + row16_tile], h);
+    }
+}
+
+// key = ab * nG + gb (sentinel nseg for dropped self loops), value = g_lo | a_lo << 16.  count16 (optional): pairs of 16384-id blocks with
+// at least fuse_min edges become fused tiles: key = nseg + 1 + gb16 * nA16 + ab16, value = the ids inside the 16384-id blocks.
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_keys(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E,
                                                             int32_t row_base, int gather_rows, int skip_self, uint32_t nG, uint32_t nseg,
-                                                            int a_bits, uint32_t *keys, uint32_t *packed)
+                                                            int a_bits, uint32_t *keys, uint32_t *packed, const uint32_t *count16, uint32_t fuse_min,
+                                                            uint32_t nA16)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int s_w[VGL_WAVES];
@@ -46,8 +82,14 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_keys(const int64_t *rowpt
             const uint32_t r = (uint32_t)(r_first + s_map[i]), col = (uint32_t)adj[e0 + i];
             const uint32_t g = gather_rows ? r : col, a = gather_rows ? col : r;
             const bool drop = skip_self && (uint32_t)row_base + r == col;
-            keys[e0 + i] = drop ? nseg : (a >> a_bits) * nG + (g >> VGL_BLK_BITS);
-            packed[e0 + i] = (g & (VGL_BLK - 1)) | ((a & ((1u << a_bits) - 1)) << 16);
+            uint32_t key = drop ? nseg : (a >> a_bits) * nG + (g >> VGL_BLK_BITS);
+            uint32_t pk = (g & (VGL_BLK - 1)) | ((a & ((1u << a_bits) - 1)) << 16);
+            if (count16 && !drop) {
+                const uint32_t f = (g >> VGL_FBLK_BITS) * nA16 + (a >> VGL_FBLK_BITS);
+                if (count16[f] >= fuse_min) { key = nseg + 1 + f; pk = (g & (VGL_FBLK - 1)) | ((a & (VGL_FBLK - 1)) << 16); }
+            }
+            keys[e0 + i] = key;
+            packed[e0 + i] = pk;
         }
     }
 }
@@ -109,6 +151,34 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill(uint32_t nchunks, ui
     }
 }
 
+// fused tiles: one wavefront per chunk; seg_chunk0[s] = first chunk of dense pair s (ascending, seg_chunk0[nsegs] = nchunks), seg_key[s] = its sort key
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill_fused(uint32_t nchunks, uint32_t nsegs, const uint32_t *seg_chunk0, const uint32_t *seg_key,
+                                                                  const uint32_t *seg_first, const uint32_t *seg_end, const uint32_t *packed_sorted,
+                                                                  const float *w_sorted, uint16_t *g_lo, uint16_t *a_lo, float *w_out)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint32_t j = blockIdx.x * VGL_WAVES + (threadIdx.x >> 6); j < nchunks; j += gridDim.x * VGL_WAVES) {
+        uint32_t lo = 0, hi = nsegs;                                // last s with seg_chunk0[s] <= j (every dense pair has at least one chunk)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg_chunk0[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint32_t k = seg_key[lo];
+        const uint32_t pos = (j - seg_chunk0[lo]) * VGL_CHUNK + lane, cnt = seg_end[k] - seg_first[k];
+        uint16_t gl = 0, al = (uint16_t)(VGL_FBLK + lane);         // pad entries: x[0] folded into a dummy accumulator behind the window
+        float w = 0.0f;
+        if (pos < cnt) {
+            const uint32_t pk = packed_sorted[seg_first[k] + pos];
+            gl = (uint16_t)(pk & 0xFFFFu);
+            al = (uint16_t)(pk >> 16);
+            if (w_sorted) w = w_sorted[seg_first[k] + pos];
+        }
+        g_lo[(size_t)j * VGL_CHUNK + lane] = gl;
+        a_lo[(size_t)j * VGL_CHUNK + lane] = al;
+        if (w_out) w_out[(size_t)j * VGL_CHUNK + lane] = w;
+    }
+}
+
 __global__ void vgl_k_blk_pick(int n, uint32_t stride, const uint32_t *in, uint32_t *out)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[(size_t)i * stride];
@@ -161,13 +231,14 @@ void make_units(const std::vector<uint32_t> &bounds, uint32_t cap, bool keep_emp
 void vgl_blocked_plan_destroy(vgl_blocked_plan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->g_lo, p->a_lo, p->w_mid, p->mid_to_a, p->vals, p->g_units, p->a_units, p->multi, p->slabs, p->g_dirty};
-    for (void *q : ptrs) if (q) hipFree(q);
+    void *ptrs[] = {p->g_lo, p->a_lo, p->w_mid, p->mid_to_a, p->vals, p->g_units, p->a_units, p->multi, p->slabs, p->g_dirty,
+                    p->f_g_lo, p->f_a_lo, p->f_w, p->f_segs, p->f_units};
+    for (void *q : ptrs) vgl_pool_free(p->stream, q);
     delete p;
 }
 
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
-                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits)
+                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges)
 {
     if (value_bits != 32 && value_bits != 1) VGL_FAIL("blocked_plan_build: values are 32 bits or 1 bit per edge");
     if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
@@ -185,23 +256,32 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     p->nA = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->a_count, 1 << a_bits));
     const uint32_t nG = (uint32_t)p->nG, nA = (uint32_t)p->nA, nseg = nG * nA;
     if ((int64_t)nG * nA >= (1LL << 31)) VGL_FAIL("blocked_plan_build: too many block pairs");
+    // fused tiles: pairs of 16384-id blocks; their keys follow the two-pass keys and the sentinel
+    const uint32_t nG16 = (uint32_t)std::max<int64_t>(1, vgl_ceil_div(p->g_count, VGL_FBLK)), nA16 = (uint32_t)std::max<int64_t>(1, vgl_ceil_div(p->a_count, VGL_FBLK));
+    const uint32_t ncol16 = gather_rows ? nA16 : nG16;
+    const bool fuse = fuse_min_edges > 0 && value_bits == 32 && a_bits == VGL_BLK_BITS && dir.edges > 0 && ncol16 <= 8192 &&
+                      (int64_t)nG16 * nA16 + nseg + 1 < (1LL << 31);
+    const uint32_t nseg16 = fuse ? nG16 * nA16 : 0, nkeys = nseg + 1 + nseg16;
 
     dev_bufs tmp;
+    tmp.st = st;
+    p->stream = st;
     stage_trace trace(st);
     std::unique_ptr<vgl_timed_launch> timed;
     uint32_t *keys = nullptr, *keys2 = nullptr, *packed = nullptr, *packed2 = nullptr, *seg_first = nullptr, *seg_end = nullptr;
     uint32_t *nch_a = nullptr, *nch_m = nullptr, *a_start = nullptr, *m_start = nullptr, *picked = nullptr;
     float *w2 = nullptr;
     void *sort_tmp = nullptr;
-    VGL_HIP_TRY(tmp.alloc(&seg_first, (size_t)nseg + 1));
-    VGL_HIP_TRY(tmp.alloc(&seg_end, (size_t)nseg + 1));
+    uint32_t *count16 = nullptr;
+    VGL_HIP_TRY(tmp.alloc(&seg_first, (size_t)nkeys + 1));
+    VGL_HIP_TRY(tmp.alloc(&seg_end, (size_t)nkeys + 1));
     VGL_HIP_TRY(tmp.alloc(&nch_a, (size_t)nseg + 1));
     VGL_HIP_TRY(tmp.alloc(&nch_m, (size_t)nseg + 1));
     VGL_HIP_TRY(tmp.alloc(&a_start, (size_t)nseg + 1));
     VGL_HIP_TRY(tmp.alloc(&m_start, (size_t)nseg + 1));
     VGL_HIP_TRY(tmp.alloc(&picked, (size_t)nG + nA + 2));
-    VGL_HIP_TRY(hipMemsetAsync(seg_first, 0, sizeof(uint32_t) * ((size_t)nseg + 1), st));
-    VGL_HIP_TRY(hipMemsetAsync(seg_end, 0, sizeof(uint32_t) * ((size_t)nseg + 1), st));
+    VGL_HIP_TRY(hipMemsetAsync(seg_first, 0, sizeof(uint32_t) * ((size_t)nkeys + 1), st));
+    VGL_HIP_TRY(hipMemsetAsync(seg_end, 0, sizeof(uint32_t) * ((size_t)nkeys + 1), st));
     if (E > 0) {
         VGL_HIP_TRY(tmp.alloc(&keys, (size_t)E));
         VGL_HIP_TRY(tmp.alloc(&keys2, (size_t)E));
@@ -210,17 +290,26 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         trace.mark("allocate keys");
         // (timing on: the stream time from here to the fill kernel is booked under "blk_plan_build" -- what the build costs the GPU,
         // without the allocator, which can stall for seconds right after tens of GB were freed)
+        if (fuse) {
+            VGL_HIP_TRY(tmp.alloc(&count16, (size_t)nseg16));
+            VGL_HIP_TRY(hipMemsetAsync(count16, 0, sizeof(uint32_t) * (size_t)nseg16, st));
+        }
         timed.reset(new vgl_timed_launch(c, "blk_plan_build"));
+        if (fuse) {
+            hipLaunchKernelGGL(vgl_k_blk_hist16, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E, row_base,
+                               gather_rows, skip_self, nA16, ncol16, count16);
+            VGL_HIP_TRY(hipGetLastError());
+            trace.mark("pair histogram (fused tiles)");
+        }
         hipLaunchKernelGGL(vgl_k_blk_keys, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E,
-                           row_base, gather_rows, skip_self, nG, nseg, a_bits, keys, packed);
+                           row_base, gather_rows, skip_self, nG, nseg, a_bits, keys, packed, (const uint32_t *)count16, (uint32_t)std::max(fuse_min_edges, 1), nA16);
         VGL_HIP_TRY(hipGetLastError());
         trace.mark("keys kernel");
         int bits = 1;
-        while ((1u << bits) <= nseg) bits++;                       // the sentinel nseg must sort last
+        while ((1ull << bits) <= (unsigned long long)nkeys) bits++;      // every key, the sentinel nseg and the fused range behind it, must be representable
         size_t need = 0;
         VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys2, packed, packed2, (size_t)E, 0, bits, st));
-        VGL_HIP_TRY(hipMalloc(&sort_tmp, std::max<size_t>(need, 16)));
-        tmp.ptrs.push_back(sort_tmp);
+        VGL_HIP_TRY(tmp.alloc((char **)&sort_tmp, std::max<size_t>(need, 16)));
         VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need, keys, keys2, packed, packed2, (size_t)E, 0, bits, st));
         trace.mark("sort (block pair, packed ids)");
         if (d_weights) {                                            // same keys, same stable sort: the weights land in the same order
@@ -249,8 +338,7 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         size_t need = 0;
         void *scan_tmp = nullptr;
         VGL_HIP_TRY(rocprim::exclusive_scan(nullptr, need, nch_a, a_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
-        VGL_HIP_TRY(hipMalloc(&scan_tmp, std::max<size_t>(need, 16)));
-        tmp.ptrs.push_back(scan_tmp);
+        VGL_HIP_TRY(tmp.alloc((char **)&scan_tmp, std::max<size_t>(need, 16)));
         VGL_HIP_TRY(rocprim::exclusive_scan(scan_tmp, need, nch_a, a_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
         VGL_HIP_TRY(rocprim::exclusive_scan(scan_tmp, need, nch_m, m_start, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), st));
     }
@@ -269,16 +357,16 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         std::vector<uint32_t> sent(2);
         VGL_TRY(vgl_hip_memcpy_d2h(c, &sent[0], seg_first + nseg, sizeof(uint32_t)));
         VGL_TRY(vgl_hip_memcpy_d2h(c, &sent[1], seg_end + nseg, sizeof(uint32_t)));
-        kept_end = sent[1] > sent[0] ? sent[0] : (uint32_t)E;
+        kept_end = (uint32_t)(E - (int64_t)(sent[1] > sent[0] ? sent[1] - sent[0] : 0));     // all but the dropped self loops (their run sits between the two key ranges)
         p->edges = kept_end;
     }
     const size_t slots = (size_t)p->nchunks * VGL_CHUNK;
-    VGL_HIP_TRY(hipMalloc((void **)&p->g_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->a_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->vals, value_bits == 1 ? sizeof(uint64_t) * std::max<size_t>(p->nchunks, 1) : sizeof(uint32_t) * std::max<size_t>(slots, 8)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->mid_to_a, sizeof(uint32_t) * std::max<size_t>(p->nchunks, 1)));
-    if (d_weights) VGL_HIP_TRY(hipMalloc((void **)&p->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->g_dirty, (size_t)nG));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->g_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->a_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->vals, value_bits == 1 ? sizeof(uint64_t) * std::max<size_t>(p->nchunks, 1) : sizeof(uint32_t) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->mid_to_a, sizeof(uint32_t) * std::max<size_t>(p->nchunks, 1)));
+    if (d_weights) VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->g_dirty, (size_t)nG));
     VGL_HIP_TRY(hipMemsetAsync(p->g_dirty, 1, (size_t)nG, st));
     trace.mark("allocate plan arrays");
     if (p->nchunks > 0) {
@@ -287,8 +375,71 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
                            (const uint32_t *)packed2, (const float *)w2, a_bits, p->g_lo, p->a_lo, p->w_mid, p->mid_to_a);
         VGL_HIP_TRY(hipGetLastError());
     }
-    timed.reset();
     trace.mark("fill kernel");
+    if (fuse) {
+        // dense pairs in key order (gather block major), cut into pieces of at most f_cap chunks (a hub x hub pair holds millions of edges:
+        // one workgroup must not be left alone with it), pieces grouped into units per gather block
+        std::vector<uint32_t> cnt((size_t)nseg16);
+        VGL_TRY(vgl_hip_memcpy_d2h(c, cnt.data(), count16, sizeof(uint32_t) * cnt.size()));
+        const uint32_t f_cap = (uint32_t)std::max(64, env_int("VGL_BLK_FUSED_UNIT", 4096));
+        std::vector<uint32_t> seg_chunk0, seg_key;
+        std::vector<vgl_blk_fseg> fsegs;
+        std::vector<vgl_blk_funit> funits;
+        uint32_t chunk = 0;
+        for (uint32_t gb = 0; gb < nG16; gb++) {
+            uint32_t in_unit = 0;
+            int32_t unit_seg0 = (int32_t)fsegs.size();
+            for (uint32_t ab = 0; ab < nA16; ab++) {
+                const uint32_t n_e = cnt[(size_t)gb * nA16 + ab];
+                if (n_e < (uint32_t)fuse_min_edges) continue;
+                const uint32_t n_ch = (n_e + VGL_CHUNK - 1) / VGL_CHUNK;
+                seg_chunk0.push_back(chunk); seg_key.push_back(nseg + 1 + gb * nA16 + ab);
+                p->f_edges += n_e;
+                for (uint32_t c0 = 0; c0 < n_ch; c0 += f_cap) {
+                    const uint32_t c1 = std::min(n_ch, c0 + f_cap);
+                    if (in_unit > 0 && in_unit + (c1 - c0) > f_cap) {
+                        funits.push_back(vgl_blk_funit{(int32_t)gb, unit_seg0, (int32_t)fsegs.size(), 0});
+                        unit_seg0 = (int32_t)fsegs.size(); in_unit = 0;
+                    }
+                    fsegs.push_back(vgl_blk_fseg{(int32_t)ab, chunk + c0, chunk + c1});
+                    in_unit += c1 - c0;
+                }
+                chunk += n_ch;
+            }
+            if ((int32_t)fsegs.size() > unit_seg0) funits.push_back(vgl_blk_funit{(int32_t)gb, unit_seg0, (int32_t)fsegs.size(), 0});
+        }
+        p->f_nchunks = chunk;
+        p->n_f_segs = (int)fsegs.size();
+        if (chunk > 0) {
+            auto unit_chunks = [&](const vgl_blk_funit &u) { uint32_t t = 0; for (int32_t i = u.seg0; i < u.seg1; i++) t += fsegs[(size_t)i].chunk1 - fsegs[(size_t)i].chunk0; return t; };
+            std::stable_sort(funits.begin(), funits.end(), [&](const vgl_blk_funit &x, const vgl_blk_funit &y) { return unit_chunks(x) > unit_chunks(y); });
+            p->n_f_units = (int)funits.size();
+            seg_chunk0.push_back(chunk);
+            uint32_t *d_chunk0 = nullptr, *d_key = nullptr;
+            VGL_HIP_TRY(tmp.alloc(&d_chunk0, seg_chunk0.size()));
+            VGL_HIP_TRY(tmp.alloc(&d_key, seg_key.size()));
+            VGL_TRY(vgl_hip_memcpy_h2d(c, d_chunk0, seg_chunk0.data(), sizeof(uint32_t) * seg_chunk0.size()));
+            VGL_TRY(vgl_hip_memcpy_h2d(c, d_key, seg_key.data(), sizeof(uint32_t) * seg_key.size()));
+            const size_t fslots = (size_t)chunk * VGL_CHUNK;
+            VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_g_lo, sizeof(uint16_t) * fslots));
+            VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_a_lo, sizeof(uint16_t) * fslots));
+            if (d_weights) VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_w, sizeof(float) * fslots));
+            VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_segs, sizeof(vgl_blk_fseg) * fsegs.size()));
+            VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_units, sizeof(vgl_blk_funit) * funits.size()));
+            VGL_TRY(vgl_hip_memcpy_h2d(c, p->f_segs, fsegs.data(), sizeof(vgl_blk_fseg) * fsegs.size()));
+            VGL_TRY(vgl_hip_memcpy_h2d(c, p->f_units, funits.data(), sizeof(vgl_blk_funit) * funits.size()));
+            hipLaunchKernelGGL(vgl_k_blk_fill_fused, dim3((unsigned)std::min<int64_t>(65536, vgl_ceil_div(chunk, VGL_WAVES))), dim3(VGL_BLOCK), 0, st, chunk,
+                               (uint32_t)seg_key.size(), (const uint32_t *)d_chunk0, (const uint32_t *)d_key, (const uint32_t *)seg_first, (const uint32_t *)seg_end,
+                               (const uint32_t *)packed2, (const float *)w2, p->f_g_lo, p->f_a_lo, p->f_w);
+            VGL_HIP_TRY(hipGetLastError());
+        }
+        trace.mark("fused tiles (tables + fill)");
+        if (trace.on)
+            fprintf(stderr, "[vgl blocked plan] fused tiles: %lld of %lld edges in %zu pairs (%d pieces, %d units, %u chunks); two-pass chunks %u\n", (long long)p->f_edges,
+                    (long long)p->edges, seg_key.size(), p->n_f_segs, p->n_f_units, p->f_nchunks, p->nchunks);
+    }
+    timed.reset();
+
     // work units.  Gather units: >= 4 per CU when the graph allows (each reloads its 128 KiB window, so not below ~256 K edges);
     // accumulate units larger (a block cut in several units costs a slab or a round of global atomics per unit)
     // (accumulate blocks up to 1.5x the average stay whole -- on a uniform graph every block is one unit and nothing goes through slabs --
@@ -302,13 +453,13 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     make_units(g_bounds, g_cap, false, false, gu, none, dummy);
     make_units(a_bounds, a_cap, true, true, au, multi, p->n_slabs);
     p->n_g_units = (int)gu.size(); p->n_a_units = (int)au.size(); p->n_multi = (int)multi.size();
-    VGL_HIP_TRY(hipMalloc((void **)&p->g_units, sizeof(vgl_blk_unit) * std::max<size_t>(gu.size(), 1)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->a_units, sizeof(vgl_blk_unit) * std::max<size_t>(au.size(), 1)));
-    VGL_HIP_TRY(hipMalloc((void **)&p->multi, sizeof(vgl_blk_multi) * std::max<size_t>(multi.size(), 1)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->g_units, sizeof(vgl_blk_unit) * std::max<size_t>(gu.size(), 1)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->a_units, sizeof(vgl_blk_unit) * std::max<size_t>(au.size(), 1)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->multi, sizeof(vgl_blk_multi) * std::max<size_t>(multi.size(), 1)));
     if (!gu.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->g_units, gu.data(), sizeof(vgl_blk_unit) * gu.size()));
     if (!au.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->a_units, au.data(), sizeof(vgl_blk_unit) * au.size()));
     if (!multi.empty()) VGL_TRY(vgl_hip_memcpy_h2d(c, p->multi, multi.data(), sizeof(vgl_blk_multi) * multi.size()));
-    VGL_HIP_TRY(hipMalloc(&p->slabs, sizeof(uint32_t) * VGL_BLK * (size_t)std::max(p->n_slabs, 1)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, &p->slabs, sizeof(uint32_t) * VGL_BLK * (size_t)std::max(p->n_slabs, 1)));
     VGL_HIP_TRY(hipStreamSynchronize(st));
     trace.mark("work units");
     tmp.free_all();

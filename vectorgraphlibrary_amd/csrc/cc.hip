@@ -169,9 +169,14 @@ int vgl_cc_hook_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *comp)
 {
     if (g->out.ntiles == 0) return 0;
     if (vgl_cc_use_blocked(g)) {
-        if (!g->blk_cc) VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, nullptr, VGL_BLK_BITS, &g->blk_cc));
+        if (!g->blk_cc) {
+            // dense pairs of 16384-id blocks as fused tiles (vgl_blocked.h): 4 bytes per edge streamed instead of 12
+            const char *fm = getenv("VGL_BLK_FUSE_MIN");
+            const int fuse_min = (fm && *fm) ? atoi(fm) : 16384;
+            VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, nullptr, VGL_BLK_BITS, &g->blk_cc, 32, fuse_min));
+        }
         const vgl_cc_blk_op op{comp, g->row_begin, c->d_counters};
-        return vgl_blocked_pass<vgl_cc_blk_op, false, false>(c, g->blk_cc, op, "cc_hook_gather", "cc_hook_accumulate");
+        return vgl_blocked_pass<vgl_cc_blk_op, false, false>(c, g->blk_cc, op, "cc_hook_gather", "cc_hook_accumulate", false, "cc_hook_fused");
     }
     vgl_timed_launch tl(c, "cc_hook");
     hipLaunchKernelGGL(vgl_k_cc_hook, dim3((unsigned)g->out.ntiles), dim3(VGL_BLOCK), 0, c->stream, g->out.rowptr, g->out.adj,

@@ -38,7 +38,22 @@ int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out)
     VGL_HIP_TRY(hipMalloc((void **)&c->d_shards, sizeof(int64_t) * VGL_NSHARD));
     VGL_HIP_TRY(hipMemsetAsync(c->d_shards, 0, sizeof(int64_t) * VGL_NSHARD, c->stream));
     memset(c->h_counters, 0, sizeof(int64_t) * (C_NSLOTS + 8));
+    {   // keep freed pool memory cached (see vgl_pool_alloc)
+        hipMemPool_t pool = nullptr;
+        uint64_t keep = UINT64_MAX;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
     *out = c;
+    return 0;
+}
+
+int vgl_hip_ctx_trim(vgl_hip_ctx *c)
+{
+    if (!c) VGL_FAIL("null context");
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    hipMemPool_t pool = nullptr;
+    VGL_HIP_TRY(hipDeviceGetDefaultMemPool(&pool, c->device));
+    VGL_HIP_TRY(hipMemPoolTrimTo(pool, 0));
     return 0;
 }
 

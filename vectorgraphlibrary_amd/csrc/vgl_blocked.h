@@ -50,7 +50,18 @@ struct vgl_blk_multi {                           // a block whose accumulation i
     int32_t block, first_slab, nslabs, pad;
 };
 
+// ---- fused tiles (dense segments): both windows in LDS, nothing travels through `vals` ----
+// A (gather block, accumulate block) pair that holds many edges -- the hub x hub, hub x anything and anything x hub pairs of a
+// degree-sorted RMAT graph -- is processed by ONE kernel: 64 KiB window of x + 64 KiB window of accumulators (blocks of VGL_FBLK = 16384
+// ids on both sides), per edge 2 + 2 (+ 4) bytes streamed instead of 12 (16) through the two-pass scheme.  The epilogue of a tile costs a
+// sweep over its 16384 accumulators, so only pairs with at least `fuse_min_edges` edges are laid out this way; the rest stays two-pass.
+constexpr int VGL_FBLK_BITS = 14;
+constexpr int VGL_FBLK = 1 << VGL_FBLK_BITS;
+struct vgl_blk_fseg { int32_t ab; uint32_t chunk0, chunk1; };      // one dense pair of the unit's gather block: chunks [chunk0, chunk1)
+struct vgl_blk_funit { int32_t gb, seg0, seg1, pad; };             // a workgroup's share: segments [seg0, seg1) of gather block gb
+
 struct vgl_blocked_plan {
+    hipStream_t stream = nullptr;                // the stream whose memory pool owns the arrays below
     int32_t g_count = 0, a_count = 0;            // index ranges of the gather / accumulate side
     int32_t nG = 0, nA = 0;
     int a_bits = VGL_BLK_BITS;                   // log2 of the accumulate-side block (15: 4-byte accumulators, 14: 8-byte)
@@ -66,6 +77,14 @@ struct vgl_blocked_plan {
     int n_multi = 0, n_slabs = 0;
     void *slabs = nullptr;                       // n_slabs * 128 KiB (one window of accumulators each)
     uint8_t *g_dirty = nullptr;                  // nG: gather blocks whose x changed since the last pass (filtered passes)
+    // fused tiles (empty unless the plan was built with fuse_min_edges > 0)
+    uint16_t *f_g_lo = nullptr, *f_a_lo = nullptr;
+    float *f_w = nullptr;
+    vgl_blk_fseg *f_segs = nullptr;
+    vgl_blk_funit *f_units = nullptr;
+    int n_f_segs = 0, n_f_units = 0;
+    uint32_t f_nchunks = 0;
+    int64_t f_edges = 0;                         // edges laid out as fused tiles (part of `edges`)
 };
 
 // Build the plan from one CSR direction.  gather_rows = 0: x is indexed by the adjacency ids (range `ncols`), y by the local rows;
@@ -73,8 +92,10 @@ struct vgl_blocked_plan {
 // out (PageRank, pr.hpp:111).  d_weights (optional): f32 per CSR position, carried to the mid order.  Synchronises; offline cost
 // (a 3-pass radix sort of the edges), like the reference's graph import.
 // value_bits = 1: what travels is one BIT per edge (the blocked top-down BFS level): `vals` then holds one 64-bit word per chunk.
+// fuse_min_edges > 0 (4-byte accumulators and 32-bit values only): block pairs of 16384 x 16384 ids with at least that many edges become
+// fused tiles.
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
-                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits = 32);
+                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits = 32, int fuse_min_edges = 0);
 void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
 
 #ifdef __HIPCC__
@@ -167,6 +188,55 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_accumulate(const vgl_b
     }
 }
 
+// fused tiles: x window of gather block gb stays in LDS for the whole unit; per dense pair (gb, ab) the accumulators of block ab are
+// folded in LDS and handed to memory by OP::partial (several units may hold pairs of the same accumulate block: one global atomic per
+// IMPROVED vertex, exactly what a multi-unit block of the two-pass scheme does).  Only min / max-type operators (partial() returning true).
+template <class OP, bool WEIGHTED>
+__global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_fused(const vgl_blk_funit *units, const vgl_blk_fseg *segs, const uint16_t *g_lo, const uint16_t *a_lo,
+                                                                const float *w, int32_t g_count, int32_t a_count, OP op)
+{
+    __shared__ uint32_t s_x[VGL_FBLK];
+    __shared__ uint32_t s_acc[VGL_FBLK + VGL_CHUNK];
+    const vgl_blk_funit u = units[blockIdx.x];
+    const int32_t gbase = u.gb << VGL_FBLK_BITS;
+    const int gn = min(VGL_FBLK, g_count - gbase);
+    for (int i = threadIdx.x; i < gn; i += VGL_BTHREADS) s_x[i] = op.load(gbase + i);
+    const uint32_t ident = op.identity();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, off = (lane & 7) * 8;
+    for (int32_t sg = u.seg0; sg < u.seg1; sg++) {
+        const vgl_blk_fseg seg = segs[sg];
+        for (int i = threadIdx.x; i < VGL_FBLK + VGL_CHUNK; i += VGL_BTHREADS) s_acc[i] = ident;
+        __syncthreads();                                            // (also orders the x window before its first use)
+        for (uint32_t m0 = seg.chunk0 + wave * VGL_BGROUP; m0 < seg.chunk1; m0 += VGL_BWAVES * VGL_BGROUP) {
+            const uint32_t m = m0 + sub;
+            if (m >= seg.chunk1) continue;
+            const size_t e = (size_t)m * VGL_CHUNK + off;
+            const uint4 gl = *reinterpret_cast<const uint4 *>(g_lo + e);
+            const uint4 al = *reinterpret_cast<const uint4 *>(a_lo + e);
+            float wv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (WEIGHTED) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(w + e), w1 = *reinterpret_cast<const float4 *>(w + e + 4);
+                wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+            }
+            const uint32_t g[4] = {gl.x, gl.y, gl.z, gl.w}, a[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                op.accumulate(&s_acc[a[k] & 0xFFFFu], op.edge(s_x[g[k] & 0xFFFFu], wv[2 * k]));
+                op.accumulate(&s_acc[a[k] >> 16], op.edge(s_x[g[k] >> 16], wv[2 * k + 1]));
+            }
+        }
+        __syncthreads();
+        const int32_t abase = seg.ab << VGL_FBLK_BITS;
+        const int an = min(VGL_FBLK, a_count - abase);
+        for (int i = threadIdx.x; i < an; i += VGL_BTHREADS) {
+            const uint32_t acc = s_acc[i];
+            if (acc != ident) op.partial(abase + i, acc);
+        }
+        __syncthreads();
+    }
+}
+
 // sum-type operators: add the slabs of a multi-unit block in unit order (OP::combine), then the epilogue
 template <class OP>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_finish_slabs(const vgl_blk_multi *multi, const typename OP::acc_t *slabs, int32_t a_count, OP op)
@@ -186,7 +256,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_finish_slabs(const vgl_bl
 // one blocked pass: gather kernel, accumulate kernel and (sum-type operators) the slab epilogue, enqueued on the context stream
 template <class OP, bool WEIGHTED, bool SLABS>
 static inline int vgl_blocked_pass(vgl_hip_ctx *c, const vgl_blocked_plan *p, const OP &op, const char *gather_name, const char *accum_name,
-                                   bool filtered = false)
+                                   bool filtered = false, const char *fused_name = nullptr)
 {
     if (p->n_g_units > 0) {
         vgl_timed_launch tl(c, gather_name);
@@ -199,6 +269,16 @@ static inline int vgl_blocked_pass(vgl_hip_ctx *c, const vgl_blocked_plan *p, co
         vgl_timed_launch tl(c, accum_name);
         hipLaunchKernelGGL((vgl_k_blk_accumulate<OP>), dim3((unsigned)p->n_a_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_unit *)p->a_units,
                            (const uint16_t *)p->a_lo, (const uint32_t *)p->vals, p->a_count, (typename OP::acc_t *)p->slabs, op);
+    }
+    if (p->n_f_units > 0) {
+        // after the two-pass part: the fused tiles load their x windows now, so they already see what the accumulate kernel just improved
+        // (any order of relaxations reaches the same fixed point; a later read only helps)
+        if constexpr (SLABS) VGL_FAIL("blocked pass: fused tiles are for min / max-type operators");
+        else {
+            vgl_timed_launch tl(c, fused_name ? fused_name : accum_name);
+            hipLaunchKernelGGL((vgl_k_blk_fused<OP, WEIGHTED>), dim3((unsigned)p->n_f_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_funit *)p->f_units,
+                               (const vgl_blk_fseg *)p->f_segs, (const uint16_t *)p->f_g_lo, (const uint16_t *)p->f_a_lo, (const float *)p->f_w, p->g_count, p->a_count, op);
+        }
     }
     if constexpr (SLABS) {
         if (p->n_multi > 0)

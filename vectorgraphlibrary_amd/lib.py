@@ -54,6 +54,7 @@ _SIGNATURES = {
     "vgl_hip_ctx_create": [_int, _p, _pp],
     "vgl_hip_ctx_destroy": [_p],
     "vgl_hip_ctx_sync": [_p],
+    "vgl_hip_ctx_trim": [_p],
     "vgl_hip_malloc": [_p, C.c_size_t, _pp],
     "vgl_hip_free": [_p, _p],
     "vgl_hip_memcpy_h2d": [_p, _p, _p, C.c_size_t],
