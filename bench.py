@@ -29,16 +29,30 @@ KERNEL_OF = {"bfs_bottom_up": "vgl_k_bu_probe", "bfs_top_down": "vgl_k_td_expand
              "sssp_relax": "vgl_k_sssp_relax<true>"}
 
 
+def kernel_source_sha():
+    """what the committed counter summaries are tied to: the sources of the BFS kernels"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("bfs.hip", "vgl_hip_internal.h", "vgl_gnf.h"):
+        h.update(open(os.path.join(ROOT, "vectorgraphlibrary_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(timing_name):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summary (profiles/pmc_summarize.py; FETCH_SIZE and
-    WRITE_SIZE from separate passes of this same command).  Raw (FETCH+WRITE)*1024; see the summary script for the gfx950
-    half-count caveat on coalesced streams."""
+    """(HBM bytes per launch, provenance) of a kernel from the committed rocprofv3 --pmc summary (profiles/pmc_summarize.py; FETCH_SIZE
+    and WRITE_SIZE from separate passes of this same command; raw (FETCH+WRITE)*1024, see the summary script for the gfx950 half-count
+    caveat on coalesced streams).  The counters cannot be collected inside a timed run, so the figure is STATIC: the summary records the
+    hash of the kernel sources it was measured on and is refused (traffic = null) when they have changed since."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
-    rec = json.load(open(files[-1])).get(KERNEL_OF.get(timing_name, ""))
-    return rec["hbm_bytes_raw"] if rec else None
+        return None, "no committed counter summary"
+    doc = json.load(open(files[-1]))
+    name = os.path.basename(files[-1])
+    if doc.get("_kernel_source_sha") != kernel_source_sha():
+        return None, f"stale: profiles/{name} was collected on other kernel sources"
+    rec = doc.get(KERNEL_OF.get(timing_name, ""))
+    return (rec["hbm_bytes_raw"] if rec else None), f"static: profiles/{name} (separate rocprofv3 --pmc passes of this command on these kernel sources)"
 
 
 def pick_sources(rowptr_dev, n, seed, degrees=None):
@@ -93,8 +107,10 @@ def leg_sssp(api, ctx, g, w, E, V, sources, args, extra, cpu):
     ctx.timing(False)
     runs = [("bellman_ford_push_all_active", dict(mode=api.SSSP_ALL_ACTIVE), ("sssp_relax",)),
             ("bellman_ford_push_active_tiles", dict(mode=api.SSSP_ACTIVE_TILES), ("sssp_relax",)),
-            ("bellman_ford_pull_blocked", dict(mode=api.SSSP_PULL, plan=pull_plan), ("sssp_pull_gather", "sssp_pull_accumulate")),
-            ("bellman_ford_direction_optimising", dict(mode=api.SSSP_DIRECTION_OPT, plan=pull_plan), ("sssp_relax", "sssp_pull_gather", "sssp_pull_accumulate"))]
+            ("bellman_ford_pull_blocked", dict(mode=api.SSSP_PULL, plan=pull_plan), ("sssp_pull_gather", "sssp_pull_accumulate", "sssp_pull_fused", "gnf")),
+            ("bellman_ford_direction_optimising", dict(mode=api.SSSP_DIRECTION_OPT, plan=pull_plan),
+             ("sssp_relax", "sssp_pull_gather", "sssp_pull_accumulate", "sssp_pull_fused", "gnf"))]
+    plan_info = pull_plan.info()
     srcs = sources[args.warmup:args.warmup + 3]
     for name, kw, kernels in runs:
         api.sssp(g, w, sources[0], raw=True, **kw)
@@ -121,11 +137,12 @@ def leg_sssp(api, ctx, g, w, E, V, sources, args, extra, cpu):
             ms = kern["sssp_relax"]["ms_per_launch"]
             rec["relax_pass"] = {"ms": ms, "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms * 1e-3) / 1e9)}
         if name == "bellman_ford_pull_blocked":
-            ms = kern["sssp_pull_gather"]["ms_per_launch"] + kern["sssp_pull_accumulate"]["ms_per_launch"]
-            # one all-edges relax pass = gather launch + accumulate launch; the pass really streams 16 B per edge (2 + 4 + 4 in the
-            # gather kernel, 4 + 2 in the accumulate kernel)
+            ms = sum((kern[k]["ms_per_launch"] or 0.0) for k in ("sssp_pull_gather", "sssp_pull_accumulate", "sssp_pull_fused"))
+            # one all-edges relax pass = gather + accumulate launches over the two-pass part (16 B per edge: 2 + 4 + 4 and 2 + 4) and the
+            # fused-tile launch over the dense block pairs (8 B per edge: 2 + 2 + 4, both windows in LDS)
             rec["relax_pass"] = {"ms": round(ms, 4), "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms * 1e-3) / 1e9),
-                                 "streamed_GBps": round(16 * E / (ms * 1e-3) / 1e9, 1)}
+                                 "streamed_GBps": round(plan_info["streamed_bytes_per_pass"] / (ms * 1e-3) / 1e9, 1),
+                                 "fused_tile_share_of_edges": round(plan_info["fused_edges"] / max(plan_info["edges"], 1), 4)}
         if kw.get("plan") is not None:
             # stream time of the layout build (keys, sorts, scans, fill) / wall time of the call (the allocator can stall after large frees)
             rec["plan_build_ms_once_per_weights_NOT_in_ms"] = round(t_pull_plan_gpu * 1e3, 1)
@@ -156,6 +173,13 @@ def leg_sssp(api, ctx, g, w, E, V, sources, args, extra, cpu):
     plan.close()
     extra["sssp"] = res
     extra["sssp_value_teps"] = res["bellman_ford_direction_optimising"]["teps"]
+    rp = res["bellman_ford_pull_blocked"]["relax_pass"]
+    # the all-edges relax pass of the direction-optimising run (12 E + 28 V algorithmic bytes), HIP-event time of its launches
+    extra["sssp_roofline"] = {"bound": "hbm", "kernel": "relax pass = vgl_k_blk_gather + vgl_k_blk_accumulate + vgl_k_blk_fused", "achieved": rp["algorithmic_GBps"],
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["frac_of_hbm_peak"], "bytes_per_launch": 12 * E + 28 * V,
+                              "ms_per_launch": rp["ms"], "streamed_GBps": rp["streamed_GBps"], "traffic": None,
+                              "plan_build_ms_once_per_weights": res["bellman_ford_direction_optimising"]["plan_build_ms_once_per_weights_NOT_in_ms"],
+                              "plan_build_call_wall_ms": res["bellman_ford_direction_optimising"]["plan_build_call_wall_ms"]}
     extra["sssp_value_note"] = ("direction-optimising Bellman-Ford (push <-> blocked pull); the blocked plan is built once per weights and is "
                                 "not in the time; the bucketed schedule (sssp.delta_stepping, plan likewise excluded) is faster still")
     if cpu is not None:
@@ -557,6 +581,14 @@ def main():
         if bad:
             sys.exit(f"bench.py: direction-optimising BFS levels differ from the top-down levels at {bad} vertices (source {check_source})")
         extra["verified"] = {"bfs_do_equals_top_down": True, "source": check_source}
+        # ... and EVERY timed traversal: its level count and the number of vertices it reached (host values of its stats record, kept
+        # during the timed region at no cost) equal those of the reference algorithm from the same source
+        for s_i, st_i in zip(sources[args.warmup:], stats):
+            td_i = api.bfs(g, s_i, api.BFS_TOP_DOWN, raw=True)[1]
+            if td_i["levels"] != st_i["levels"] or td_i["discovered"] != st_i["discovered"]:
+                sys.exit(f"bench.py: timed traversal from source {s_i}: {st_i['levels']} levels / {st_i['discovered']} reached, top-down "
+                         f"{td_i['levels']} / {td_i['discovered']}")
+        extra["verified"]["every_timed_traversal_levels_and_reached_equal_top_down"] = len(stats)
         bu_edges = sum(s["bu_edges"] for s in stats)
         bu_found = sum(s["bu_found"] for s in stats)
         bu_steps = sum(s["bu_steps"] for s in stats)
@@ -577,7 +609,7 @@ def main():
             per_launch_ms = dom_ms / dom_n
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom)[0], "traffic_source": pmc_traffic(dom)[1],
                         "bytes_per_launch": int(per_launch_bytes), "ms_per_launch": round(per_launch_ms, 5),
                         "launches": dom_n}
         total_alg = sum(s["algorithmic_bytes"] for s in stats)
@@ -775,7 +807,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "TEPS (edges/s) BFS on RMAT-%d" % scale, "value": round(args.steps * E / dt, 1), "unit": "edges/s",
+            "metric": "TEPS (edges/s) BFS + SSSP on RMAT-%d; value = direction-optimising BFS, sssp_value_teps = direction-optimising Bellman-Ford" % scale, "value": round(args.steps * E / dt, 1), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload, "vertices": V, "edges": E, "seed": seed, "parallelism": f"edge-cut x{world}" + (" (64-vertex blocks dealt round-robin)" if weak else ""),

@@ -305,6 +305,11 @@ class SsspPullPlan:
         _l.check(self.ctx.L.vgl_hip_sssp_pull_plan_create(self.ctx.h, graph.h, _ptr(weights), C.byref(h)))
         self.h = h
 
+    def info(self):
+        e, f, b, m = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        _l.check(self.ctx.L.vgl_hip_sssp_pull_plan_info(self.h, C.byref(e), C.byref(f), C.byref(b), C.byref(m)))
+        return {"edges": e.value, "fused_edges": f.value, "streamed_bytes_per_pass": b.value, "plan_bytes": m.value}
+
     def close(self):
         if self.h:
             self.ctx.L.vgl_hip_sssp_pull_plan_destroy(self.ctx.h, self.h)

@@ -905,8 +905,7 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
 // frontier of the current level from a frontier bitmap (owned words).  count: per-workgroup counts, their scan and F / M in
 // h_counters[C_FRONT] / [C_NEIGH] (one launch, the host waits for it); write: ids + edge offsets + tile_first (needs the M of
 // the count pass)
-static int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1,
-                          bool advance = false)
+int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known, bool advance)
 {
     const int64_t word0 = g->row_begin >> 6;
     const int64_t nwords = vgl_ceil_div(g->row_end, 64) - word0;

@@ -135,6 +135,7 @@ static inline unsigned vgl_grid2(int64_t n) { return (unsigned)std::max<int64_t>
 // label moves one hop per pass before the pointer jump spreads it -- the fixed point, hence every label, is the same.
 struct vgl_cc_blk_op {
     typedef uint32_t acc_t;
+    static constexpr bool MARK = false;
     int32_t *comp;
     int32_t g_base;
     int64_t *counters;

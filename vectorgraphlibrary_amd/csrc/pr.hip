@@ -239,6 +239,7 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
 // ordered kernel whenever a row is long enough for that to approach the 1e-6 bar of the north star.
 struct vgl_pr_blk_op {
     typedef unsigned long long acc_t;
+    static constexpr bool MARK = false;
     const float *contrib;
     const float *dangling;
     float k, d;

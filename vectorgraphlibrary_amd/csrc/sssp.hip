@@ -165,10 +165,10 @@ static int vgl_sssp_launch(vgl_hip_ctx *c, vgl_hip_graph *g, const float *w, flo
 template <class Path>
 struct vgl_path_blk_op {
     typedef uint32_t acc_t;
+    static constexpr bool MARK = true;
     float *dist;
-    int32_t *epoch;
-    int32_t iter, g_base;
-    int64_t *counters;
+    uint64_t *changed;           // bitmap of the vertices this step improved = the frontier of the next step
+    int32_t g_base;
     __device__ __forceinline__ uint32_t load(int32_t i) const { return __float_as_uint(dist[g_base + i]); }
     __device__ __forceinline__ uint32_t edge(uint32_t x, float w) const
     {
@@ -182,21 +182,36 @@ struct vgl_path_blk_op {
         else __hip_atomic_fetch_max(reinterpret_cast<int *>(p), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return Path::better(__uint_as_float(b), __uint_as_float(a)) ? b : a; }
-    __device__ __forceinline__ void finish(int32_t v, uint32_t acc) const
+    __device__ __forceinline__ bool finish_m(int32_t v, uint32_t acc) const          // the only unit of v's block: plain compare + store
     {
         const float cand = __uint_as_float(acc);
-        if (Path::better(cand, dist[v])) { dist[v] = cand; epoch[v] = iter; counters[C_CHANGED] = 1; }
-    }
-    __device__ __forceinline__ bool partial(int32_t v, uint32_t acc) const
-    {
-        const float cand = __uint_as_float(acc);
-        if (Path::better(cand, dist[v])) {
-            const int before = Path::update(dist + v, cand);
-            if (Path::improved(before, cand)) { epoch[v] = iter; counters[C_CHANGED] = 1; }
-        }
+        if (!Path::better(cand, dist[v])) return false;
+        dist[v] = cand;
         return true;
     }
+    __device__ __forceinline__ bool partial_m(int32_t v, uint32_t acc) const         // other workgroups may improve v too: one atomic per improvement
+    {
+        const float cand = __uint_as_float(acc);
+        if (!Path::better(cand, dist[v])) return false;
+        return Path::improved(Path::update(dist + v, cand), cand);
+    }
+    __device__ __forceinline__ void mark(int32_t v0, unsigned long long mask, bool shared) const
+    {
+        if (shared) atomicOr(reinterpret_cast<unsigned long long *>(changed + (v0 >> 6)), mask);
+        else changed[v0 >> 6] |= mask;               // (a whole-block unit is the only writer of its words in this launch; fused tiles run after it)
+    }
+    // (the non-marking interface of vgl_blocked.h, unused: MARK is set)
+    __device__ __forceinline__ void finish(int32_t v, uint32_t acc) const { (void)finish_m(v, acc); }
+    __device__ __forceinline__ bool partial(int32_t v, uint32_t acc) const { (void)partial_m(v, acc); return true; }
 };
+
+__global__ void vgl_k_sssp_seed_bits(int64_t words, int32_t source, uint64_t *front, uint64_t *next)
+{
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) {
+        front[w] = (w == (source >> 6)) ? (1ULL << (source & 63)) : 0ULL;
+        next[w] = 0;
+    }
+}
 
 // tile_first[t] = frontier position whose edge range contains edge t * VGL_TILE (defined in bfs.hip, shared by the sparse advances)
 __global__ void vgl_k_tile_first(int32_t F, const int64_t *offs, int32_t *tile_first);
@@ -207,7 +222,7 @@ __global__ void vgl_k_tile_first(int32_t F, const int64_t *offs, int32_t *tile_f
 template <class Path>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax_sparse(const int32_t *ids, const int64_t *offs, const int32_t *tile_first, int32_t F, int64_t M,
                                                                      const int64_t *rowptr, const int32_t *adj, const float *w, int32_t row_base,
-                                                                     float *dist, int32_t *epoch, int32_t iter)
+                                                                     float *dist, uint64_t *changed)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int64_t s_base[VGL_TILE];
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax_sparse(const int32
     for (int j = 0; j < VGL_EPT; j++)
         if (dsts[j] >= 0 && Path::live(cand[j]) && Path::better(cand[j], olds[j])) {
             const int before = Path::update(dist + dsts[j], cand[j]);
-            if (Path::improved(before, cand[j])) epoch[dsts[j]] = iter;
+            if (Path::improved(before, cand[j])) atomicOr(reinterpret_cast<unsigned long long *>(changed + (dsts[j] >> 6)), 1ULL << (dsts[j] & 63));
         }
 }
 
@@ -273,34 +288,39 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     if (mode != VGL_HIP_SSSP_PULL && mode != VGL_HIP_SSSP_DIRECTION_OPT) return fail("unknown mode");
     const char *env = getenv("VGL_SSSP_PULL_SHARE");
     const double share = (env && *env) ? atof(env) : 0.35;      // pull when the rows that changed own more than this share of the edges (0.2 - 0.5 measure within 3 % on RMAT-24)
-    hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, g->epoch);
+    hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, (int32_t *)nullptr);
     vgl_hip_sssp_stats st = {0, 0, 0, 0, 0};
     int64_t pull_edges = 0, push_edges = 0;
-    // Every step starts from the frontier of the step before -- the rows whose value changed in it (epoch == iter - 1; the source
-    // carries epoch 0), compacted with their edge counts by the GNF.  An empty frontier ends the run (the step before changed nothing:
-    // do { ... } while(changes), shortest_paths.hpp:112-154); its edge share picks the direction of a DIRECTION_OPT step.
+    // Every step starts from the frontier of the step before -- the rows whose value changed in it -- kept as a BITMAP that the step's
+    // kernels fill (one word per wavefront in the blocked epilogues, one atomicOr per improvement in the push): sizing it reads V / 8 bytes
+    // instead of the V * 4 of an epoch array (two 50 us scans per step of RMAT-24 before, 2.8 of 17.7 ms).  An empty frontier ends the run
+    // (do { ... } while(changes), shortest_paths.hpp:112-154); its edge share picks the direction of a DIRECTION_OPT step.
+    const int64_t words = vgl_ceil_div(g->V, 64);
+    uint64_t *front = g->bm_front, *next = g->bm_next;
+    hipLaunchKernelGGL(vgl_k_sssp_seed_bits, dim3(vgl_grid1(words)), dim3(VGL_BLOCK), 0, c->stream, words, source, front, next);
     for (int32_t iter = 1;; iter++) {
-        const vgl_pred_equal_i32 pred{g->epoch, iter - 1};                  // (whole-graph handle: row_begin == 0)
-        VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)nullptr, (uint8_t *)nullptr, (int32_t *)nullptr, true, true));
+        VGL_TRY(vgl_bfs_bm_gnf(c, g, front, true, false));
         const int64_t F = c->h_counters[C_FRONT], M = c->h_counters[C_NEIGH];
         if (F == 0) break;
         st.iterations = iter;
         const bool pull = mode == VGL_HIP_SSSP_PULL || (double)M > share * (double)g->out.edges;
         if (pull) {
-            const vgl_path_blk_op<Path> op{d_dist, g->epoch, iter, g->row_begin, c->d_counters};
+            const vgl_path_blk_op<Path> op{d_dist, next, g->row_begin};
             VGL_TRY((vgl_blocked_pass<vgl_path_blk_op<Path>, true, false>(c, plan->blk, op, "sssp_pull_gather", "sssp_pull_accumulate", false, "sssp_pull_fused")));
             pull_edges += plan->blk->edges;
             st.pull_steps++;
         } else if (M > 0) {
-            hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid1(F)), dim3(VGL_BLOCK), 0, c->stream, (int32_t)F, (const int64_t *)g->offs, g->tile_first);
+            VGL_TRY(vgl_bfs_bm_gnf(c, g, front, false, true, M));       // ids + edge offsets + tile table of the frontier
             vgl_timed_launch tl(c, "sssp_relax");
             hipLaunchKernelGGL((vgl_k_sssp_relax_sparse<Path>), dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, (const int32_t *)g->ids,
                                (const int64_t *)g->offs, (const int32_t *)g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, d_weights, g->row_begin, d_dist,
-                               g->epoch, iter);
+                               next);
             push_edges += M;
             st.push_steps++;
         } else st.push_steps++;                                 // the frontier has no outgoing edges: nothing to relax, the next frontier is empty
         VGL_HIP_TRY(hipGetLastError());
+        std::swap(front, next);
+        VGL_HIP_TRY(hipMemsetAsync(next, 0, sizeof(uint64_t) * (size_t)words, c->stream));
     }
     st.edges_relaxed = push_edges + pull_edges;
     st.algorithmic_bytes = 12 * st.edges_relaxed + 28 * (int64_t)g->V * st.iterations;
@@ -373,6 +393,18 @@ extern "C" {
 int vgl_hip_sssp_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan **out)
 {
     return vgl_pull_plan_create(c, g, d_weights, out);
+}
+int vgl_hip_sssp_pull_plan_info(vgl_hip_sssp_pull_plan *p, int64_t *edges, int64_t *fused_edges, int64_t *streamed_bytes_per_pass, int64_t *plan_bytes)
+{
+    if (!p || !p->blk) VGL_FAIL("sssp_pull_plan_info: null plan");
+    const vgl_blocked_plan *b = p->blk;
+    const int64_t two_pass_slots = (int64_t)b->nchunks * VGL_CHUNK, fused_slots = (int64_t)b->f_nchunks * VGL_CHUNK;
+    if (edges) *edges = b->edges;
+    if (fused_edges) *fused_edges = b->f_edges;
+    // what one pass streams, pad entries included: two-pass 2 + 4 + 4 (gather) + 2 + 4 (accumulate) per slot, fused 2 + 2 + 4 per slot
+    if (streamed_bytes_per_pass) *streamed_bytes_per_pass = 16 * two_pass_slots + 8 * fused_slots;
+    if (plan_bytes) *plan_bytes = 12 * two_pass_slots + 4 * (int64_t)b->nchunks + 8 * fused_slots;
+    return 0;
 }
 int vgl_hip_sssp_pull_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_pull_plan *p)
 {

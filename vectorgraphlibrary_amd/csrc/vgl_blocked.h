@@ -107,6 +107,8 @@ void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
 //   OP::identity()         -> value the accumulators start from
 //   OP::accumulate(p, v)   LDS atomic that folds the travelling uint32 v into *p
 //   OP::finish(i, acc)     epilogue of vertex i of the accumulate side when its block was handled by ONE unit
+//   OP::MARK               true: the operator keeps a bitmap of improved vertices -- finish_m / partial_m return "improved", mark(v0, mask, shared)
+//                          gets one word per wavefront step (shared: other workgroups may write the same word)
 //   OP::partial(i, acc)    a block cut into several units: fold this unit's result into memory (min-type operators: a global
 //                          atomic), or return false to have the unit write its accumulators to a slab (sum-type operators);
 //                          vgl_k_blk_finish_slabs then adds the slabs in unit order and calls finish
@@ -179,6 +181,18 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_accumulate(const vgl_b
         }
     }
     __syncthreads();
+    if constexpr (OP::MARK) {
+        // operators that keep a bitmap of the vertices they improved (the next frontier): one 64-bit word per wavefront step instead of a
+        // store (or an atomic) per vertex -- the lanes of a wavefront handle 64 consecutive vertices of the word-aligned block
+        const int nround = (n + 63) & ~63;
+        for (int i = threadIdx.x; i < nround; i += VGL_BTHREADS) {
+            bool ch = false;
+            if (i < n) ch = u.slab < 0 ? op.finish_m(base + i, s_acc[i]) : op.partial_m(base + i, s_acc[i]);
+            const unsigned long long m = __ballot(ch);
+            if (m && lane == 0) op.mark(base + i, m, u.slab >= 0);
+        }
+        return;
+    }
     if (u.slab < 0) {
         for (int i = threadIdx.x; i < n; i += VGL_BTHREADS) op.finish(base + i, s_acc[i]);
     } else {
@@ -229,9 +243,19 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_blk_fused(const vgl_blk_fu
         __syncthreads();
         const int32_t abase = seg.ab << VGL_FBLK_BITS;
         const int an = min(VGL_FBLK, a_count - abase);
-        for (int i = threadIdx.x; i < an; i += VGL_BTHREADS) {
-            const uint32_t acc = s_acc[i];
-            if (acc != ident) op.partial(abase + i, acc);
+        if constexpr (OP::MARK) {
+            const int anround = (an + 63) & ~63;
+            for (int i = threadIdx.x; i < anround; i += VGL_BTHREADS) {
+                bool ch = false;
+                if (i < an) { const uint32_t acc = s_acc[i]; if (acc != ident) ch = op.partial_m(abase + i, acc); }
+                const unsigned long long m = __ballot(ch);
+                if (m && lane == 0) op.mark(abase + i, m, true);
+            }
+        } else {
+            for (int i = threadIdx.x; i < an; i += VGL_BTHREADS) {
+                const uint32_t acc = s_acc[i];
+                if (acc != ident) op.partial(abase + i, acc);
+            }
         }
         __syncthreads();
     }

@@ -138,7 +138,9 @@ int64_t vgl_next_seq(vgl_hip_ctx *ctx);
 int vgl_wait_counters(vgl_hip_ctx *ctx, int64_t seq);
 int vgl_zero_counters(vgl_hip_ctx *ctx, int first, int count);
 int vgl_ensure_partials(vgl_hip_ctx *ctx, size_t n);
-int vgl_build_tile_rows(vgl_hip_ctx *ctx, struct vgl_dir_csr &d, int32_t nrows);   // d.tile_row / d.ntiles from d.rowptr / d.edges (owned by the caller)
+int vgl_build_tile_rows(vgl_hip_ctx *ctx, struct vgl_dir_csr &d, int32_t nrows);
+// frontier from a bitmap over the owned words (bfs.hip): count = sizes to h_counters[C_FRONT / C_NEIGH] (waits), write = ids + edge offsets + tile table
+int vgl_bfs_bm_gnf(vgl_hip_ctx *c, struct vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1, bool advance = false);   // d.tile_row / d.ntiles from d.rowptr / d.edges (owned by the caller)
 
 static inline int64_t vgl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
