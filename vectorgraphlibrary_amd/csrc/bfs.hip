@@ -563,11 +563,18 @@ typedef int vgl_int4_u __attribute__((ext_vector_type(4), aligned(4)));     // 1
 // 12-18; an empty deferred pass costs 9.5 us, vgl_k_bm_advance 4.2.  Also tried: chaining the bottom-up levels on the device (the last workgroup of a level evaluates the
 // switch rule, speculative launches of the next levels return at once when it says stop; one host wait per chain): 0.394 ms per
 // traversal with three levels per wait against 0.389 with one -- the polled hand-over costs less than the extra launches.
+// INLINE_HEAVY (round 3): the rows a workgroup defers are scanned by the same workgroup right after its probe loop, 16 lanes per row, and
+// the last workgroup folds the counters and hands them to the host -- no second launch (vgl_k_bu_heavy: ~15 us per level even when it has
+// nothing to scan, three levels per traversal).  The 64-row groups are dealt round-robin to the wavefronts of the grid, so the deferred
+// rows -- the hubs, i.e. the first ids of a degree-sorted graph -- are spread over all workgroups by construction; the balanced second
+// pass dates from the time of contiguous chunks.  VGL_BU_SPLIT=1 keeps the two-launch form.
+template <bool INLINE_HEAVY>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32_t row_base, int32_t chunk, const int64_t *in_rowptr,
                                                             const int32_t *in_adj, int64_t in_edges, const uint64_t *visited, const uint64_t *in_nz,
                                                             const uint64_t *front, uint64_t *next, int32_t *levels,
                                                             int32_t next_level, int32_t *heavy, int32_t *heavy_cnt, int64_t *partials,
-                                                            int32_t *heavy_off, uint32_t *ticket, const int4 *in_head, const uint64_t *in_long)
+                                                            int32_t *heavy_off, uint32_t *ticket, const int4 *in_head, const uint64_t *in_long,
+                                                            int64_t *counters, volatile int64_t *host, int64_t seq, const int32_t *nz_rank, int32_t nz_rows)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s_nheavy;
@@ -587,16 +594,22 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
     const int lane = vgl_lane();
     for (int64_t g0 = (int64_t)blockIdx.x * VGL_WAVES + vgl_wave(); g0 < groups; g0 += NW * 64) {
         const int64_t mine = g0 + (int64_t)lane * NW;                   // lane l holds the candidate word of group g0 + l * NW
-        uint64_t cw = 0;
+        uint64_t cw = 0, nzw = 0;
+        int32_t nzr = 0;
         if (mine < groups) {
-            cw = ~visited[word0 + mine] & in_nz[word0 + mine];
+            nzw = in_nz[word0 + mine];
+            cw = ~visited[word0 + mine] & nzw;
             if (cw == 0ULL) next[word0 + mine] = 0ULL;                  // nothing to find here
+            else nzr = nz_rank[mine];
         }
         unsigned long long todo = __ballot(cw != 0ULL);
         while (todo) {
             const int j = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const uint64_t cand_word = __shfl(cw, j);
+            // the row's head record: rows with incoming edges are numbered consecutively, so the candidates of a group -- every other
+            // row of an RMAT graph has none -- read consecutive 16-byte records
+            const int32_t rec = __shfl(nzr, j) + (int32_t)__popcll(__shfl(nzw, j) & ((1ULL << lane) - 1ULL));
             const int64_t grp = g0 + (int64_t)j * NW;
             const int32_t r = (int32_t)(grp << 6) + lane;
             const int32_t v = row_base + r;
@@ -606,7 +619,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                 // row offsets, no dependent adjacency load): most candidates find their parent among the first four, the rest look
                 // at the next four; a row that still misses and is longer than eight goes to the wavefront pass.  (Requesting the next
                 // group's records before waiting for this group's probes was tried: no change.)
-                const int4 h = in_head[r];
+                const int4 h = in_head[rec];
                 const int32_t u0[4] = {h.x, h.y, h.z, h.w};
                 uint32_t hit = 0;
                 int n = 0;
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                 }
                 bool longer = false;
                 if (hit == 0 && n == 4) {
-                    const int4 k = in_head[(int64_t)nrows + r];
+                    const int4 k = in_head[(int64_t)nz_rows + rec];
                     const int32_t u1[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
                     for (int q = 0; q < 4; q++)
@@ -643,6 +656,50 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                 if (defer) my_heavy[base + __popcll(dm & ((1ULL << lane) - 1ULL))] = r;
             }
         }
+    }
+    if (INLINE_HEAVY) {
+        __syncthreads();                                    // the workgroup's deferred list is complete (and its stores to `next` have landed)
+        const int nh = s_nheavy;
+        constexpr int G = VGL_BU_HEAVY_LANES, NG = 64 / G;  // lanes per deferred row, rows per wavefront
+        const int quarter = lane / G, ql = lane % G;
+        for (int h0 = vgl_wave() * NG; h0 < nh; h0 += VGL_WAVES * NG) {
+            const int h = h0 + quarter;
+            bool done = h >= nh, hit_any = false;
+            int32_t r = 0;
+            int64_t p = 0, e = 0;
+            if (!done) { r = my_heavy[h]; p = in_rowptr[r]; e = in_rowptr[r + 1]; }     // the whole row: its head records are a selection, not a prefix
+            while (!__all(done)) {
+                const int64_t q = p + ql;
+                bool hit = false;
+                if (!done && q < e) { const int32_t u = in_adj[q]; hit = (front[u >> 6] >> (u & 63)) & 1ULL; }
+                const unsigned long long hm = __ballot(hit);
+                const unsigned qm = (unsigned)(hm >> (quarter * G)) & (G >= 32 ? 0xFFFFFFFFu : ((1u << (G & 31)) - 1u));
+                if (!done) {
+                    if (qm) { hit_any = true; done = true; if (ql == 0) probes += __ffs(qm); }
+                    else { if (ql == 0) probes += min((int64_t)G, e - p); p += G; if (p >= e) done = true; }
+                }
+            }
+            if (hit_any && ql == 0) {
+                const int32_t v = row_base + r;
+                levels[v] = next_level;
+                atomicOr((unsigned long long *)&next[v >> 6], 1ULL << (v & 63));
+                found_cnt++;
+            }
+        }
+        found_cnt = vgl_block_reduce_add(found_cnt, s64);
+        probes = vgl_block_reduce_add(probes, s64);
+        uint32_t dep2 = 0;
+        if (threadIdx.x == 0) dep2 = vgl_put_agent(partials + blockIdx.x * 4 + 0, found_cnt) ^ vgl_put_agent(partials + blockIdx.x * 4 + 1, probes);
+        if (!vgl_last_block(ticket, dep2)) return;
+        int64_t f = 0, pr = 0;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += VGL_BLOCK) { f += vgl_load_agent(partials + b * 4 + 0); pr += vgl_load_agent(partials + b * 4 + 1); }
+        f = vgl_block_reduce_add(f, s64);
+        pr = vgl_block_reduce_add(pr, s64);
+        if (threadIdx.x == 0) {
+            if (host) vgl_publish2(counters, host, seq, C_BU_FOUND, f, C_BU_EDGES, pr);
+            else { counters[C_BU_FOUND] = f; counters[C_BU_EDGES] = pr; }
+        }
+        return;
     }
     found_cnt = vgl_block_reduce_add(found_cnt, s64);
     probes = vgl_block_reduce_add(probes, s64);
@@ -944,13 +1001,25 @@ static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, 
                              const uint64_t *front, uint64_t *next, int64_t *seq_out, int heavy_blocks = VGL_BU_BLOCKS)
 {
     const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
+    static const bool split = getenv("VGL_BU_SPLIT") && getenv("VGL_BU_SPLIT")[0] == '1';
+    const int64_t seq = vgl_next_seq(c);
+    if (!split) {
+        vgl_timed_launch tl(c, "bfs_bottom_up");
+        hipLaunchKernelGGL(vgl_k_bu_probe<true>, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
+                           g->in.rowptr, g->in.adj, g->in.edges, visited, g->bm_in_nz, front, next, levels, next_level,
+                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS, reinterpret_cast<const int4 *>(g->in_head), g->bm_in_long,
+                           c->d_counters, (volatile int64_t *)c->h_counters, seq, (const int32_t *)g->in_nz_rank, g->in_nz_rows);
+        VGL_HIP_TRY(hipGetLastError());
+        if (seq_out) *seq_out = seq;
+        return 0;
+    }
     {
         vgl_timed_launch tl(c, "bfs_bottom_up");
-        hipLaunchKernelGGL(vgl_k_bu_probe, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
+        hipLaunchKernelGGL(vgl_k_bu_probe<false>, dim3(VGL_BU_BLOCKS), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, chunk,
                            g->in.rowptr, g->in.adj, g->in.edges, visited, g->bm_in_nz, front, next, levels, next_level,
-                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS, reinterpret_cast<const int4 *>(g->in_head), g->bm_in_long);
+                           g->heavy, g->heavy_cnt, g->bu_partials, g->heavy_off, g->tickets + 1 * VGL_TICKET_WORDS, reinterpret_cast<const int4 *>(g->in_head), g->bm_in_long,
+                           c->d_counters, (volatile int64_t *)c->h_counters, seq, (const int32_t *)g->in_nz_rank, g->in_nz_rows);
     }
-    const int64_t seq = vgl_next_seq(c);
     {
         vgl_timed_launch tl(c, "bfs_bottom_up_heavy");
         hipLaunchKernelGGL(vgl_k_bu_heavy, dim3((unsigned)heavy_blocks), dim3(VGL_BLOCK), 0, c->stream, g->row_begin, chunk, g->in.rowptr,

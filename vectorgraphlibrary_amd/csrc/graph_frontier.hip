@@ -29,6 +29,24 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_nonempty_rows(int32_t nrows, 
     }
 }
 
+// rank[g] = set bits of the words before group g (exclusive prefix over the owned words); rank[ngroups] = total.  One workgroup.
+__global__ __launch_bounds__(1024) void vgl_k_nz_rank(int64_t ngroups, const uint64_t *bits, int32_t *rank)
+{
+    __shared__ int s_w[16];
+    const int64_t per = (ngroups + 1023) / 1024;
+    const int64_t lo = min(ngroups, (int64_t)threadIdx.x * per), hi = min(ngroups, lo + per);
+    int sum = 0;
+    for (int64_t g = lo; g < hi; g++) sum += __popcll(bits[g]);
+    const int inc = vgl_wave_incl_add(sum);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < (int)(threadIdx.x >> 6)) base += s_w[w]; total += s_w[w]; }
+    int run = base + inc - sum;
+    for (int64_t g = lo; g < hi; g++) { rank[g] = run; run += __popcll(bits[g]); }
+    if (threadIdx.x == 0) rank[ngroups] = total;
+}
+
 // The eight smallest distinct ids seen so far, ascending (INT32_MAX = free slot); `overflow` = a distinct id did not fit.
 struct vgl_small8 {
     int32_t a[8];
@@ -69,7 +87,7 @@ struct vgl_small8 {
 // wavefront per 64 rows: rows of more than 64 entries are scanned by the whole wavefront (per-lane selections merged by eight wave
 // minima), the others by their own lane.
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_row_heads(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj, int4 *head0,
-                                                             int4 *head1, uint64_t *long_bits)
+                                                             int4 *head1, uint64_t *long_bits, const int32_t *nz_rank)
 {
     const int lane = threadIdx.x & 63;
     const int32_t ngroups = (nrows + 63) >> 6;
@@ -77,6 +95,9 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_row_heads(int32_t nrows, int3
         const int32_t r = (grp << 6) + lane;
         int64_t b = 0, n = 0;
         if (r < nrows) { b = rowptr[r]; n = rowptr[r + 1] - b; }
+        // record of this row: the rows with incoming edges are numbered consecutively (rows without have no record)
+        const unsigned long long nzw = __ballot(n > 0);
+        const int32_t rec = nz_rank[grp] + (int32_t)__popcll(nzw & ((1ULL << lane) - 1ULL));
         bool has_more = false;
         unsigned long long big = __ballot(n > 64);
         while (big) {                                               // long rows: all lanes on one row
@@ -97,20 +118,20 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_row_heads(int32_t nrows, int3
             }
             const bool more = __any(s.overflow || s.a[0] != INT32_MAX);
             if (lane == j) {
-                head0[r] = make_int4(out[0], out[1], out[2], out[3]);
-                head1[r] = make_int4(out[4], out[5], out[6], out[7]);
+                head0[rec] = make_int4(out[0], out[1], out[2], out[3]);
+                head1[rec] = make_int4(out[4], out[5], out[6], out[7]);
                 has_more = more;
             }
         }
-        if (r < nrows && n <= 64) {
+        if (r < nrows && n > 0 && n <= 64) {
             vgl_small8 s;
             s.init();
             for (int64_t i = 0; i < n; i++) s.insert(adj[b + i]);
             int32_t out[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) out[k] = s.a[k] == INT32_MAX ? -1 : s.a[k];
-            head0[r] = make_int4(out[0], out[1], out[2], out[3]);
-            head1[r] = make_int4(out[4], out[5], out[6], out[7]);
+            head0[rec] = make_int4(out[0], out[1], out[2], out[3]);
+            head1[rec] = make_int4(out[4], out[5], out[6], out[7]);
             has_more = s.overflow;
         }
         const unsigned long long m = __ballot(has_more);
@@ -294,11 +315,16 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     if (g->in.rowptr) {
         int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, vgl_ceil_div(g->nrows, VGL_BLOCK)));
         hipLaunchKernelGGL(vgl_k_nonempty_rows, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, g->in.rowptr, g->bm_in_nz);
-        VGL_TRY(vgl_alloc(&g->in_head, (size_t)g->nrows * 8));
+        const int64_t ngroups = vgl_ceil_div(g->nrows, 64);
+        VGL_TRY(vgl_alloc(&g->in_nz_rank, (size_t)ngroups + 1));
+        hipLaunchKernelGGL(vgl_k_nz_rank, dim3(1), dim3(1024), 0, c->stream, ngroups, (const uint64_t *)(g->bm_in_nz + (row_begin >> 6)), g->in_nz_rank);
+        VGL_HIP_TRY(hipGetLastError());
+        VGL_TRY(vgl_hip_memcpy_d2h(c, &g->in_nz_rows, g->in_nz_rank + ngroups, sizeof(int32_t)));
+        VGL_TRY(vgl_alloc(&g->in_head, (size_t)std::max(g->in_nz_rows, 1) * 8));
         VGL_TRY(vgl_alloc(&g->bm_in_long, words));
         VGL_HIP_TRY(hipMemsetAsync(g->bm_in_long, 0, words * 8, c->stream));
         hipLaunchKernelGGL(vgl_k_row_heads, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, g->in.rowptr, g->in.adj,
-                           reinterpret_cast<int4 *>(g->in_head), reinterpret_cast<int4 *>(g->in_head) + g->nrows, g->bm_in_long);
+                           reinterpret_cast<int4 *>(g->in_head), reinterpret_cast<int4 *>(g->in_head) + g->in_nz_rows, g->bm_in_long, (const int32_t *)g->in_nz_rank);
         VGL_HIP_TRY(hipGetLastError());
     }
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -315,7 +341,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     if (g->blk_pr) { vgl_blocked_plan_destroy(g->blk_pr); g->blk_pr = nullptr; }
     if (g->blk_cc) { vgl_blocked_plan_destroy(g->blk_cc); g->blk_cc = nullptr; }
     if (g->blk_bfs) { vgl_blocked_plan_destroy(g->blk_bfs); g->blk_bfs = nullptr; }
-    void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
+    void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->in_nz_rank, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
                     g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->out.hub_rows, g->in.hub_rows, g->out.pull_blk_row,
                     g->in.pull_blk_row, g->out.hub_chunks, g->in.hub_chunks, g->out.hub_chunk_sums, g->in.hub_chunk_sums};

@@ -84,7 +84,12 @@ struct vgl_hip_graph {
     // scratch shared by the fused algorithms (allocated at creation, sized by V / nrows / edges)
     uint64_t *bm_visited = nullptr, *bm_front = nullptr, *bm_next = nullptr; // ceil(V/64)+1 words each
     uint64_t *bm_in_nz = nullptr;    // bit v = owned vertex v has incoming edges (bottom-up candidates)
-    int32_t *in_head = nullptr;      // two planes of 4 per owned row: in-neighbours 0-3 and 4-7 (-1 padded), 16-byte records (bottom-up probes)
+    int32_t *in_head = nullptr;      // two planes of 16-byte records (in-neighbours 0-3 and 4-7 of the eight smallest ids, -1 padded), ONE RECORD PER
+                                     // OWNED ROW THAT HAS INCOMING EDGES, in row order: record index = in_nz_rank[group] + rank of the row among the set
+                                     // bits of its in_nz word -- the rows without incoming edges (45 % of an RMAT graph) are never bottom-up
+                                     // candidates and used to take half of every 128-byte line of the planes
+    int32_t *in_nz_rank = nullptr;   // per 64-row group: number of owned rows with incoming edges before the group
+    int32_t in_nz_rows = 0;          // owned rows with incoming edges = records per plane
     uint64_t *bm_in_long = nullptr;  // bit v = owned vertex v has more than 8 incoming edges (deferred to the wavefront pass when it misses)
     int32_t *ids = nullptr;          // nrows
     int64_t *offs = nullptr;         // nrows+1
