@@ -219,14 +219,18 @@ def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
         del ps, pd
         rec, auto_ranks = {}, None
         for mode, mname in ((api.PR_AUTO, "auto"), (api.PR_EXACT_ORDER, "exact_order")):
-            torch.cuda.synchronize()                              # (graph build finished: t_first is the plan build + two iterations only)
+            torch.cuda.synchronize()                              # (graph build finished)
             ctx.timing(True)
+            t1 = time.perf_counter()
+            pg.prepare_page_rank(mode)                            # explicit graph preparation (vgl_hip_pr_prepare): blocked layout or hub schedule
+            torch.cuda.synchronize()
+            t_prepare = time.perf_counter() - t1
+            t_plan_gpu = ctx.timing_get("blk_plan_build")[1]
+            ctx.timing(False)
             t1 = time.perf_counter()
             api.page_rank(pg, 2, raw=True, mode=mode)
             torch.cuda.synchronize()
             t_first = time.perf_counter() - t1
-            t_plan_gpu = ctx.timing_get("blk_plan_build")[1]
-            ctx.timing(False)
             ctx.timing(True)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -245,7 +249,8 @@ def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
                    "kernels": {k: v for k, v in kern.items() if v["launches"]}}
             if blocked:
                 one["plan_build_ms_once_per_graph_NOT_in_ms"] = round(t_plan_gpu, 1)      # stream time of the layout build
-                one["first_call_wall_ms"] = round(t_first * 1e3, 1)                         # build + allocations + two iterations
+                one["prepare_call_wall_ms"] = round(t_prepare * 1e3, 1)                     # vgl_hip_pr_prepare: build + allocations
+            one["first_call_wall_ms"] = round(t_first * 1e3, 1)                             # the first two iterations after the preparation
             if mname == "auto":
                 rec.update(one)
                 auto_ranks = ranks
@@ -307,6 +312,57 @@ def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
         extra["cpu_baseline_cc"] = {"value": round(cE / dtc, 1), "unit": "edges/s", "cores": threads, "kind": "port", "passes": passes,
                                     "sample": "1 Shiloach-Vishkin run (oracle/vgl_oracle.c, OpenMP) on the same symmetrised RMAT-24 x16 graph"}
     cg.close()
+
+
+def leg_cc_big(api, vd, ctx, cc_scale, seed, renumber, chunk_edges, extra):
+    """BASELINE configs[4] at its stated scale on ONE GPU: Shiloach-Vishkin on the symmetrised RMAT-<cc_scale> x 16 (RMAT-27: 4.29 G stored
+    edges, more than one blocked plan's 2^32 -- the hook runs as blocked passes over row-range pieces), built by the streaming builder.
+    Checked without a CPU oracle (the graph is too large for one in the bench's time): the min-id union-find reaches the same labels, and
+    the labels are roots."""
+    import torch
+    cV, cE = 1 << cc_scale, (1 << cc_scale) * 16 * 2
+    t1 = time.perf_counter()
+    cg, _, _ = vd.build_generated_shard(ctx, cc_scale, 16, seed, 0, 1, kind="rmat", renumber=renumber, chunk_edges=chunk_edges, placement="ranges",
+                                        symmetric=True, with_incoming=False)
+    ctx.sync()
+    t_build = time.perf_counter() - t1
+    res = {"scale": cc_scale, "stored_edges": cE, "graph_build_s": round(t_build, 2)}
+    labels = {}
+    for name, sym in (("shiloach_vishkin", False), ("union_find_symmetric", True)):
+        ctx.timing(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        api.connected_components(cg, raw=True, symmetric=sym)       # first call: builds the blocked plan(s) of the hook
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t1
+        t_plan_gpu = ctx.timing_get("blk_plan_build")[1]
+        ctx.timing(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            comp, cst = api.connected_components(cg, raw=True, symmetric=sym)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t1) / 2
+        n, ms, path = cc_hook_pass(ctx)
+        ctx.timing(False)
+        labels[name] = comp
+        res[name] = {"teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "passes": cst["hook_passes"], "first_call_wall_ms": round(t_first * 1e3, 1)}
+        if n and not sym:
+            alg = 8 * cE + 12 * cV
+            res[name]["plan_build_ms_once_per_graph_NOT_in_ms"] = round(t_plan_gpu, 1)
+            res[name]["hook_pass"] = {"path": path, "ms": round(ms / n, 4), "algorithmic_GBps": round(alg / (ms / n * 1e-3) / 1e9, 1),
+                                      "frac_of_hbm_peak": frac(alg / (ms / n * 1e-3) / 1e9)}
+    same = torch.equal(labels["shiloach_vishkin"], labels["union_find_symmetric"])
+    lab = labels["shiloach_vishkin"].long()
+    roots = bool((lab[lab] == lab).all())
+    res["verified"] = {"shiloach_vishkin_equals_union_find": same, "labels_are_roots": roots, "components": int((lab == torch.arange(cV, device=ctx.device)).sum())}
+    extra[f"cc_rmat{cc_scale}x16_symmetrised_one_gpu"] = res
+    if not (same and roots):
+        sys.exit(f"bench.py: CC on RMAT-{cc_scale}: the two algorithms disagree or the labels are not roots")
+    cg.close()
+    del cg, labels, lab
+    torch.cuda.empty_cache()
+    ctx.L.vgl_hip_ctx_trim(ctx.h)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -457,7 +513,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = RMAT scale+log2(N) built shard-by-shard (default), strong = the scale-24 graph cut N ways")
     ap.add_argument("--pr-scale", type=int, default=25, help="N>1: scale of the uniform-random graph of the PageRank leg (BASELINE configs[3]: 25)")
-    ap.add_argument("--cc-scale", type=int, default=0, help="N>1: scale of the symmetrised RMAT graph of the CC leg (default: the BFS leg's scale, RMAT-27 at 8 GPUs)")
+    ap.add_argument("--cc-scale", type=int, default=-1,
+                    help="scale of the symmetrised RMAT graph of the CC leg.  N>1: default the BFS leg's scale (RMAT-27 at 8 GPUs).  N=1: the leg at "
+                         "RMAT-24 always runs; default -1 adds BASELINE configs[4]'s RMAT-27 on the one GPU (0 or 24: skip it)")
     ap.add_argument("--chunk-edges", type=int, default=1 << 27, help="generator chunk of the streaming shard build")
     ap.add_argument("--sssp-delta", type=float, default=10.0)    # 8 .. 12 measure the same (13.0 ms), 16: 13.9 ms, 4: 14.0 ms
     ap.add_argument("--renumber", default="total", choices=["none", "out", "in", "total"],
@@ -723,6 +781,8 @@ def main():
             g.out_adj = g.in_adj = g.perm = None
             torch.cuda.empty_cache()
             leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu)
+            if args.cc_scale != 0 and args.cc_scale != 24:          # configs[4] at its stated scale (27 by default) on this one GPU
+                leg_cc_big(api, vd, ctx, args.cc_scale if args.cc_scale > 0 else 27, seed, renumber, args.chunk_edges, extra)
         if not args.no_operator_api and not args.no_pr_cc and scale == 24:     # (the apps build their own graphs: the bench's are freed by now)
             leg_operator_api(scale, ef, extra)
         workload = f"BFS direction-optimising on RMAT scale-{scale} (edge factor {ef}), 1xMI355X"
@@ -803,7 +863,7 @@ def main():
             del shard, degrees, levels_buf
             torch.cuda.empty_cache()
             leg_pr_sharded(api, vd, vs, comm, ctx, dist, world, rank, args.pr_scale, ef, seed, args.chunk_edges, extra)
-            leg_cc_sharded(api, vd, vs, comm, ctx, dist, world, rank, args.cc_scale or scale, seed, args.chunk_edges, renumber, extra)
+            leg_cc_sharded(api, vd, vs, comm, ctx, dist, world, rank, args.cc_scale if args.cc_scale > 0 else scale, seed, args.chunk_edges, renumber, extra)
 
     if rank == 0:
         out = {

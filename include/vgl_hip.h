@@ -248,6 +248,14 @@ int vgl_hip_pr_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_indeg_no
 #define VGL_HIP_PR_AUTO 2
 int vgl_hip_pr_run_mode(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_indeg_noloops, int iterations, int mode,
                         float *d_ranks, vgl_hip_pr_stats *stats);
+/* Graph preparation for PageRank / Shiloach-Vishkin (the counterpart of the reference's offline import): builds NOW what the first
+ * vgl_hip_pr_run / vgl_hip_cc_run would otherwise build inside its first call -- the blocked layout (a radix sort of the edges, tens of ms
+ * for 10^9 edges plus the allocations) or the hub schedule of the ordered pull.  *resolved_mode (optional): what AUTO resolved to.  The
+ * default entry point vgl_hip_pr_run uses AUTO: bit-identical to seq_page_rank below 2^25 stored edges or when a row is longer than 256
+ * entries, exact per-vertex sums (<= 1e-6 of the chain on such graphs, NOT bit-identical) otherwise; pass VGL_HIP_PR_EXACT_ORDER to
+ * vgl_hip_pr_run_mode for the reference's evaluation order at any size. */
+int vgl_hip_pr_prepare(vgl_hip_ctx *ctx, vgl_hip_graph *g, int mode, int *resolved_mode);
+int vgl_hip_cc_prepare(vgl_hip_ctx *ctx, vgl_hip_graph *g);
 
 typedef struct {
     int32_t hook_passes;

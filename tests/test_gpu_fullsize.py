@@ -161,3 +161,44 @@ def test_config5_cc_rmat24_symmetrised(ctx, oracle):
         assert (comp.cpu().numpy() == ref).all(), f"CC (symmetric={sym}) labels differ from the oracle"
     g.close()
     torch.cuda.empty_cache()
+
+
+def test_config5_cc_rmat27_on_one_gpu(ctx):
+    """configs[4] at its stated scale on ONE MI355X: Shiloach-Vishkin (hook as blocked passes over row-range pieces: 4.29 G stored edges are
+    more than one plan's 2^32) and the min-id union-find on the symmetrised RMAT-27 x 16, checked through properties no CPU oracle is
+    needed for: the two algorithms agree on every label; every stored edge joins equal labels; labels are roots no larger than their
+    vertices; the giant component holds most of the vertices that have edges."""
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import distributed as vd
+    import torch
+    scale, ef = 27, 16
+    V = 1 << scale
+    g, _, _ = vd.build_generated_shard(ctx, scale, ef, SEED, 0, 1, kind="rmat", renumber="total", placement="ranges", symmetric=True, with_incoming=False)
+    assert g.E == 2 * ef * V and g.E >= (1 << 32)
+    os.environ["VGL_CC_BLOCKED"] = "1"
+    try:
+        sv, st = api.connected_components(g, raw=True)
+    finally:
+        os.environ.pop("VGL_CC_BLOCKED")
+    assert st["hook_passes"] >= 2
+    uf, _ = api.connected_components(g, raw=True, symmetric=True)
+    assert torch.equal(sv, uf), "Shiloach-Vishkin and union-find labels differ"
+    lab = sv.long()
+    assert bool((lab[lab] == lab).all()) and bool((lab <= torch.arange(V, device=ctx.device)).all())
+    deg = g.out_rowptr[1:] - g.out_rowptr[:-1]
+    step = 1 << 22                                               # rows per slice of the edge check
+    for r0 in range(0, V, step):
+        r1 = min(V, r0 + step)
+        e0, e1 = int(g.out_rowptr[r0]), int(g.out_rowptr[r1])
+        if e1 == e0:
+            continue
+        rows = torch.repeat_interleave(torch.arange(r0, r1, device=ctx.device), deg[r0:r1])
+        assert bool((sv[rows] == sv[g.out_adj[e0:e1].long()]).all()), f"an edge of rows {r0}..{r1} joins two labels"
+        del rows
+    sizes = torch.bincount(lab, minlength=1)
+    with_edges = int((deg > 0).sum())
+    assert int(sizes.max()) > 0.9 * with_edges and int((deg == 0).sum()) == int(((sizes == 1) & (deg == 0)).sum())
+    g.close()
+    del g, sv, uf, lab, sizes
+    torch.cuda.empty_cache()
+    ctx.L.vgl_hip_ctx_trim(ctx.h)

@@ -1045,16 +1045,20 @@ def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, orac
     rowptr, adj, w = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy(), w_d.cpu().numpy()
     # layouts: default (two-pass at these sizes), blocks cut into 64-chunk units, and dense block pairs as FUSED TILES -- forced down to
     # pairs of 64 edges, with 64-chunk pieces so that a pair is spread over several workgroups (what RMAT-24's hub pairs go through)
-    for unit, fuse in (("", ""), ("64", ""), ("", "64"), ("64", "64")):
+    # ... and the layout in row-range PIECES (what a direction with 2^32 edges or more gets), forced at a twentieth of the edges
+    for unit, fuse, piece in (("", "", ""), ("64", "", ""), ("", "64", ""), ("64", "64", ""), ("", "", str(max(4096, src.numel() // 20))), ("", "64", str(max(4096, src.numel() // 7)))):
         if unit:
             os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = os.environ["VGL_BLK_FUSED_UNIT"] = unit
         if fuse:
             os.environ["VGL_BLK_FUSE_MIN"] = fuse
+        if piece:
+            os.environ["VGL_BLK_PIECE_EDGES"] = piece
         try:
             plan = api.SsspPullPlan(g, w_d)
         finally:
-            for name in ("VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BLK_FUSED_UNIT", "VGL_BLK_FUSE_MIN"):
+            for name in ("VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BLK_FUSED_UNIT", "VGL_BLK_FUSE_MIN", "VGL_BLK_PIECE_EDGES"):
                 os.environ.pop(name, None)
+        assert plan.info()["edges"] == src.numel()
         for k in range(2):
             s = O.pick_source(rowptr, seed, k)
             ref, _ = O.sssp_bellman_ford(rowptr, adj, w, s)
@@ -1066,8 +1070,8 @@ def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, orac
                     wd, wst = api.sswp(g, w_d, s, api.SSSP_DIRECTION_OPT, raw=True, plan=plan)
                 finally:
                     del os.environ["VGL_SSSP_PULL_SHARE"]
-                assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all(), (unit, fuse, k, share)
-                assert (wd.cpu().numpy().view(np.int32) == refw.view(np.int32)).all(), (unit, fuse, k, share)
+                assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all(), (unit, fuse, piece, k, share)
+                assert (wd.cpu().numpy().view(np.int32) == refw.view(np.int32)).all(), (unit, fuse, piece, k, share)
                 assert st["push_steps"] + st["pull_steps"] == st["iterations"]
                 if share == "2":
                     assert st["pull_steps"] == 0
@@ -1091,12 +1095,14 @@ def test_cc_blocked_hook(kind, scale, ef, symmetric, ctx, oracle):
     ref, _ = O.cc_sv(rowptr, adj)
     # layouts: default (dense pairs of 16384-id blocks become fused tiles from 16384 edges: most pairs of these graphs), everything two-pass,
     # and both with 64-chunk units / pieces
-    for unit, fuse in (("", ""), ("64", ""), ("", "0"), ("64", "0"), ("64", "64")):
+    for unit, fuse, piece in (("", "", ""), ("64", "", ""), ("", "0", ""), ("64", "0", ""), ("64", "64", ""), ("", "", "50000"), ("64", "0", "30000")):
         os.environ["VGL_CC_BLOCKED"] = "1"
         if unit:
             os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = os.environ["VGL_BLK_FUSED_UNIT"] = unit
         if fuse:
             os.environ["VGL_BLK_FUSE_MIN"] = fuse
+        if piece:
+            os.environ["VGL_BLK_PIECE_EDGES"] = piece             # row-range pieces, as for a direction with 2^32 edges or more
         try:
             g2 = api.Graph(ctx, V, g.out_rowptr, g.out_adj, g.in_rowptr, g.in_adj)
             comp, st = api.connected_components(g2)
@@ -1116,7 +1122,7 @@ def test_cc_blocked_hook(kind, scale, ef, symmetric, ctx, oracle):
                 s.close()
             g2.close()
         finally:
-            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BLK_FUSED_UNIT", "VGL_BLK_FUSE_MIN"):
+            for k in ("VGL_CC_BLOCKED", "VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BLK_FUSED_UNIT", "VGL_BLK_FUSE_MIN", "VGL_BLK_PIECE_EDGES"):
                 os.environ.pop(k, None)
     g.close()
 

@@ -196,6 +196,15 @@ class Graph:
     def out_edge_range(self, row_begin, row_end):
         return int(self.out_rowptr[row_begin]), int(self.out_rowptr[row_end])
 
+    def prepare_page_rank(self, mode=PR_AUTO):
+        """build now what the first page_rank() call would build (blocked layout or hub schedule); returns the resolved mode"""
+        m = C.c_int()
+        _l.check(self.ctx.L.vgl_hip_pr_prepare(self.ctx.h, self.h, int(mode), C.byref(m)))
+        return m.value
+
+    def prepare_cc(self):
+        _l.check(self.ctx.L.vgl_hip_cc_prepare(self.ctx.h, self.h))
+
     def prepare_blocked_bfs(self):
         """one-time layout for the blocked top-down BFS levels (vgl_hip_bfs_prepare_blocked); bfs() results do not change"""
         _l.check(self.ctx.L.vgl_hip_bfs_prepare_blocked(self.ctx.h, self.h))

@@ -33,7 +33,7 @@ struct dev_bufs {                                   // frees whatever the build 
 // lie in one row block almost always, so the tile counts its column blocks in LDS and adds the non-zero counters to memory once (a
 // global atomic per edge would serialise on the hub pairs: millions of increments of one address).
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_hist16(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E, int32_t row_base,
-                                                              int gather_rows, int skip_self, uint32_t nA16, uint32_t ncol16, uint32_t *count16)
+                                                              int gather_rows, int skip_self, uint32_t nA16, uint32_t ncol16, uint32_t *count16, uint32_t row_off)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int s_w[VGL_WAVES];
@@ -43,12 +43,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_hist16(const int64_t *row
     const int r_first = tile_row[blockIdx.x], r_last = tile_row[blockIdx.x + 1];
     for (uint32_t i = threadIdx.x; i < ncol16; i += VGL_BLOCK) s_h[i] = 0;
     vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);       // (starts with a barrier after its own stores: s_h is cleared for everybody)
-    const uint32_t row16_tile = (uint32_t)r_first >> VGL_FBLK_BITS;
+    const uint32_t row16_tile = ((uint32_t)r_first + row_off) >> VGL_FBLK_BITS;
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) {
         const int i = threadIdx.x + j * VGL_BLOCK;
         if (i < n) {
-            const uint32_t r = (uint32_t)(r_first + s_map[i]), col = (uint32_t)adj[e0 + i];
+            const uint32_t r = (uint32_t)(r_first + s_map[i]) + row_off, col = (uint32_t)adj[e0 + i];
             if (skip_self && (uint32_t)row_base + r == col) continue;
             const uint32_t row16 = r >> VGL_FBLK_BITS, col16 = col >> VGL_FBLK_BITS;
             if (row16 == row16_tile) atomicAdd(&s_h[col16], 1u);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_hist16(const int64_t *row
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_keys(const int64_t *rowptr, const int32_t *adj, const int32_t *tile_row, int64_t E,
                                                             int32_t row_base, int gather_rows, int skip_self, uint32_t nG, uint32_t nseg,
                                                             int a_bits, uint32_t *keys, uint32_t *packed, const uint32_t *count16, uint32_t fuse_min,
-                                                            uint32_t nA16)
+                                                            uint32_t nA16, uint32_t row_off)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int s_w[VGL_WAVES];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_keys(const int64_t *rowpt
     for (int j = 0; j < VGL_EPT; j++) {
         const int i = threadIdx.x + j * VGL_BLOCK;
         if (i < n) {
-            const uint32_t r = (uint32_t)(r_first + s_map[i]), col = (uint32_t)adj[e0 + i];
+            const uint32_t r = (uint32_t)(r_first + s_map[i]) + row_off, col = (uint32_t)adj[e0 + i];        // (row_off: a piece's rows keep their global numbers)
             const uint32_t g = gather_rows ? r : col, a = gather_rows ? col : r;
             const bool drop = skip_self && (uint32_t)row_base + r == col;
             uint32_t key = drop ? nseg : (a >> a_bits) * nG + (g >> VGL_BLK_BITS);
@@ -231,14 +231,20 @@ void make_units(const std::vector<uint32_t> &bounds, uint32_t cap, bool keep_emp
 void vgl_blocked_plan_destroy(vgl_blocked_plan *p)
 {
     if (!p) return;
+    if (p->next) { vgl_blocked_plan_destroy(p->next); p->next = nullptr; }
+    if (p->piece_rowptr) hipFree(p->piece_rowptr);
+    if (p->piece_tile_row) hipFree(p->piece_tile_row);
     void *ptrs[] = {p->g_lo, p->a_lo, p->w_mid, p->mid_to_a, p->vals, p->g_units, p->a_units, p->multi, p->slabs, p->g_dirty,
                     p->f_g_lo, p->f_a_lo, p->f_w, p->f_segs, p->f_units};
     for (void *q : ptrs) vgl_pool_free(p->stream, q);
     delete p;
 }
 
-int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
-                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges)
+// one plan over the rows of `dir` (all rows of the direction, or a row-range piece of it: row_off = number of rows before the piece,
+// nrows_total = rows of the whole direction)
+static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                                      int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges,
+                                      int32_t row_off, int32_t nrows_total)
 {
     if (value_bits != 32 && value_bits != 1) VGL_FAIL("blocked_plan_build: values are 32 bits or 1 bit per edge");
     if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
@@ -249,8 +255,9 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     const int64_t E = dir.edges;
     vgl_blocked_plan *p = new vgl_blocked_plan();
     struct guard { vgl_blocked_plan *p; ~guard() { if (p) vgl_blocked_plan_destroy(p); } } own{p};
-    p->g_count = gather_rows ? nrows : ncols;
-    p->a_count = gather_rows ? ncols : nrows;
+    (void)nrows;
+    p->g_count = gather_rows ? nrows_total : ncols;
+    p->a_count = gather_rows ? ncols : nrows_total;
     p->nG = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->g_count, VGL_BLK));
     p->a_bits = a_bits;
     p->nA = (int32_t)std::max<int64_t>(1, vgl_ceil_div(p->a_count, 1 << a_bits));
@@ -297,12 +304,12 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         timed.reset(new vgl_timed_launch(c, "blk_plan_build"));
         if (fuse) {
             hipLaunchKernelGGL(vgl_k_blk_hist16, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E, row_base,
-                               gather_rows, skip_self, nA16, ncol16, count16);
+                               gather_rows, skip_self, nA16, ncol16, count16, (uint32_t)row_off);
             VGL_HIP_TRY(hipGetLastError());
             trace.mark("pair histogram (fused tiles)");
         }
         hipLaunchKernelGGL(vgl_k_blk_keys, dim3((unsigned)dir.ntiles), dim3(VGL_BLOCK), 0, st, dir.rowptr, dir.adj, (const int32_t *)dir.tile_row, E,
-                           row_base, gather_rows, skip_self, nG, nseg, a_bits, keys, packed, (const uint32_t *)count16, (uint32_t)std::max(fuse_min_edges, 1), nA16);
+                           row_base, gather_rows, skip_self, nG, nseg, a_bits, keys, packed, (const uint32_t *)count16, (uint32_t)std::max(fuse_min_edges, 1), nA16, (uint32_t)row_off);
         VGL_HIP_TRY(hipGetLastError());
         trace.mark("keys kernel");
         int bits = 1;
@@ -466,5 +473,54 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     trace.mark("free temporaries");
     own.p = nullptr;
     *out = p;
+    return 0;
+}
+
+__global__ void vgl_k_blk_rebase_rows(int32_t n, const int64_t *rowptr, int64_t base, int64_t *out)
+{
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) out[i] = rowptr[i] - base;
+}
+
+int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                           int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges)
+{
+    if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
+    // chunk positions are 32-bit: a direction is laid out whole below 2^32 - 2048 edges (VGL_BLK_PIECE_EDGES lowers the bound: tests)
+    int64_t limit = (1LL << 32) - VGL_TILE;
+    if (const char *e = getenv("VGL_BLK_PIECE_EDGES")) limit = std::max<int64_t>(4096, atoll(e));
+    if (dir.edges < limit) return vgl_blocked_plan_build_one(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, 0, nrows);
+    if (value_bits != 32 || a_bits != VGL_BLK_BITS) VGL_FAIL("blocked_plan_build: only 4-byte min / max-type layouts can be cut into row-range pieces (2^32 edges or more)");
+    // row ranges of at most `piece` edges each (a single row above the bound cannot be cut)
+    const int64_t piece = std::min<int64_t>(limit, 1LL << 31);
+    const int parts = (int)std::min<int64_t>(4096, vgl_ceil_div(dir.edges, piece) + 1);
+    std::vector<int32_t> bounds((size_t)parts + 1);
+    VGL_TRY(vgl_hip_partition_rows(c, nrows, dir.rowptr, parts, bounds.data()));
+    std::vector<int64_t> starts((size_t)parts + 1);
+    for (int k = 0; k <= parts; k++) VGL_TRY(vgl_hip_memcpy_d2h(c, &starts[(size_t)k], dir.rowptr + bounds[(size_t)k], sizeof(int64_t)));
+    vgl_blocked_plan *head = nullptr, *tail = nullptr;
+    struct guard { vgl_blocked_plan **h; ~guard() { if (*h) vgl_blocked_plan_destroy(*h); } } own{&head};
+    for (int k = 0; k < parts; k++) {
+        const int32_t lo = bounds[(size_t)k], hi = bounds[(size_t)k + 1];
+        const int64_t e0 = starts[(size_t)k], e1 = starts[(size_t)k + 1];
+        if (hi <= lo || e1 <= e0) continue;
+        if (e1 - e0 >= (1LL << 32) - VGL_TILE) VGL_FAIL("blocked_plan_build: a row range of one piece holds 2^32 edges or more");
+        vgl_dir_csr view;
+        int64_t *rp = nullptr;
+        VGL_HIP_TRY(hipMalloc((void **)&rp, sizeof(int64_t) * ((size_t)(hi - lo) + 1)));
+        hipLaunchKernelGGL(vgl_k_blk_rebase_rows, dim3((unsigned)std::min<int64_t>(4096, vgl_ceil_div((int64_t)(hi - lo) + 1, 256))), dim3(256), 0, c->stream, hi - lo,
+                           dir.rowptr + lo, e0, rp);
+        view.rowptr = rp; view.adj = dir.adj + e0; view.edges = e1 - e0;
+        int rc = vgl_build_tile_rows(c, view, hi - lo);
+        vgl_blocked_plan *q = nullptr;
+        if (!rc) rc = vgl_blocked_plan_build_one(c, view, hi - lo, row_base, ncols, gather_rows, skip_self, d_weights ? d_weights + e0 : nullptr, a_bits, &q, value_bits,
+                                                 fuse_min_edges, lo, nrows);
+        if (rc) { hipFree(rp); if (view.tile_row) hipFree(view.tile_row); return rc; }
+        q->piece_rowptr = rp; q->piece_tile_row = view.tile_row;
+        if (tail) tail->next = q; else head = q;
+        tail = q;
+    }
+    if (!head) return vgl_blocked_plan_build_one(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, 0, nrows);
+    *out = head;
+    head = nullptr;
     return 0;
 }

@@ -386,6 +386,19 @@ int vgl_hip_pr_iteration_owned(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *
     return vgl_pr_iteration(c, g, d_indeg, d_rdeg, d_ranks, d_contrib_scratch, d_ranks, VGL_HIP_PR_AUTO);
 }
 
+int vgl_hip_pr_prepare(vgl_hip_ctx *c, vgl_hip_graph *g, int mode, int *resolved_mode)
+{
+    if (!c || !g) VGL_FAIL("pr_prepare: null argument");
+    if (mode < VGL_HIP_PR_EXACT_ORDER || mode > VGL_HIP_PR_AUTO) VGL_FAIL("pr_prepare: unknown mode");
+    VGL_TRY(vgl_pr_mode_auto(c, g, &mode));
+    if (mode == VGL_HIP_PR_BLOCKED) {
+        if (!g->blk_pr) VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 0, 1, nullptr, VGL_BLK_BITS - 1, &g->blk_pr));
+    } else VGL_TRY(vgl_pull_find_hubs(c, g, g->out));
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (resolved_mode) *resolved_mode = mode;
+    return 0;
+}
+
 int vgl_hip_pr_run(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *d_indeg_noloops, int iterations, float *d_ranks,
                    vgl_hip_pr_stats *stats)
 {

@@ -307,7 +307,7 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
         if (pull) {
             const vgl_path_blk_op<Path> op{d_dist, next, g->row_begin};
             VGL_TRY((vgl_blocked_pass<vgl_path_blk_op<Path>, true, false>(c, plan->blk, op, "sssp_pull_gather", "sssp_pull_accumulate", false, "sssp_pull_fused")));
-            pull_edges += plan->blk->edges;
+            pull_edges += vgl_blocked_plan_edges(plan->blk);
             st.pull_steps++;
         } else if (M > 0) {
             VGL_TRY(vgl_bfs_bm_gnf(c, g, front, false, true, M));       // ids + edge offsets + tile table of the frontier
@@ -397,13 +397,16 @@ int vgl_hip_sssp_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float 
 int vgl_hip_sssp_pull_plan_info(vgl_hip_sssp_pull_plan *p, int64_t *edges, int64_t *fused_edges, int64_t *streamed_bytes_per_pass, int64_t *plan_bytes)
 {
     if (!p || !p->blk) VGL_FAIL("sssp_pull_plan_info: null plan");
-    const vgl_blocked_plan *b = p->blk;
-    const int64_t two_pass_slots = (int64_t)b->nchunks * VGL_CHUNK, fused_slots = (int64_t)b->f_nchunks * VGL_CHUNK;
-    if (edges) *edges = b->edges;
-    if (fused_edges) *fused_edges = b->f_edges;
+    int64_t two_pass_slots = 0, fused_slots = 0, e_all = 0, f_all = 0, nch = 0;
+    for (const vgl_blocked_plan *b = p->blk; b; b = b->next) {          // (a direction with 2^32 edges or more is laid out in pieces)
+        two_pass_slots += (int64_t)b->nchunks * VGL_CHUNK; fused_slots += (int64_t)b->f_nchunks * VGL_CHUNK;
+        e_all += b->edges; f_all += b->f_edges; nch += b->nchunks;
+    }
+    if (edges) *edges = e_all;
+    if (fused_edges) *fused_edges = f_all;
     // what one pass streams, pad entries included: two-pass 2 + 4 + 4 (gather) + 2 + 4 (accumulate) per slot, fused 2 + 2 + 4 per slot
     if (streamed_bytes_per_pass) *streamed_bytes_per_pass = 16 * two_pass_slots + 8 * fused_slots;
-    if (plan_bytes) *plan_bytes = 12 * two_pass_slots + 4 * (int64_t)b->nchunks + 8 * fused_slots;
+    if (plan_bytes) *plan_bytes = 12 * two_pass_slots + 4 * nch + 8 * fused_slots;
     return 0;
 }
 int vgl_hip_sssp_pull_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_pull_plan *p)

@@ -85,6 +85,11 @@ struct vgl_blocked_plan {
     int n_f_segs = 0, n_f_units = 0;
     uint32_t f_nchunks = 0;
     int64_t f_edges = 0;                         // edges laid out as fused tiles (part of `edges`)
+    // a direction with 2^32 edges or more is laid out in row-range PIECES of at most 2^31 edges, each a plan of its own over the same
+    // index spaces (its rows keep their global numbers); a pass runs the pieces one after the other (min / max-type operators only)
+    vgl_blocked_plan *next = nullptr;
+    int64_t *piece_rowptr = nullptr;             // the piece's rebased row offsets and tile table (owned; null for a whole-direction plan)
+    int32_t *piece_tile_row = nullptr;
 };
 
 // Build the plan from one CSR direction.  gather_rows = 0: x is indexed by the adjacency ids (range `ncols`), y by the local rows;
@@ -97,6 +102,7 @@ struct vgl_blocked_plan {
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
                            int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits = 32, int fuse_min_edges = 0);
 void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
+static inline int64_t vgl_blocked_plan_edges(const vgl_blocked_plan *p) { int64_t e = 0; for (; p; p = p->next) e += p->edges; return e; }
 
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -279,8 +285,8 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_finish_slabs(const vgl_bl
 
 // one blocked pass: gather kernel, accumulate kernel and (sum-type operators) the slab epilogue, enqueued on the context stream
 template <class OP, bool WEIGHTED, bool SLABS>
-static inline int vgl_blocked_pass(vgl_hip_ctx *c, const vgl_blocked_plan *p, const OP &op, const char *gather_name, const char *accum_name,
-                                   bool filtered = false, const char *fused_name = nullptr)
+static inline int vgl_blocked_pass_one(vgl_hip_ctx *c, const vgl_blocked_plan *p, const OP &op, const char *gather_name, const char *accum_name,
+                                       bool filtered, const char *fused_name)
 {
     if (p->n_g_units > 0) {
         vgl_timed_launch tl(c, gather_name);
@@ -310,6 +316,14 @@ static inline int vgl_blocked_pass(vgl_hip_ctx *c, const vgl_blocked_plan *p, co
                                (const typename OP::acc_t *)p->slabs, p->a_count, op);
     }
     VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <class OP, bool WEIGHTED, bool SLABS>
+static inline int vgl_blocked_pass(vgl_hip_ctx *c, const vgl_blocked_plan *p, const OP &op, const char *gather_name, const char *accum_name,
+                                   bool filtered = false, const char *fused_name = nullptr)
+{
+    if (SLABS && p->next) VGL_FAIL("blocked pass: a plan in several pieces needs a min / max-type operator");
+    for (const vgl_blocked_plan *q = p; q; q = q->next) VGL_TRY((vgl_blocked_pass_one<OP, WEIGHTED, SLABS>(c, q, op, gather_name, accum_name, filtered, fused_name)));
     return 0;
 }
 #endif  // __HIPCC__

@@ -104,6 +104,8 @@ _SIGNATURES = {
     "vgl_hip_sssp_run_plan": [_p, _p, _p, _i32, _p, C.POINTER(SsspStats)],
     "vgl_hip_pr_run": [_p, _p, _p, _int, _p, C.POINTER(PrStats)],
     "vgl_hip_pr_run_mode": [_p, _p, _p, _int, _int, _p, C.POINTER(PrStats)],
+    "vgl_hip_pr_prepare": [_p, _p, _int, C.POINTER(_int)],
+    "vgl_hip_cc_prepare": [_p, _p],
     "vgl_hip_hits_run": [_p, _p, _int, _p, _p],
     "vgl_hip_scc_run": [_p, _p, _p, C.POINTER(SccStats)],
     "vgl_hip_cc_run": [_p, _p, _p, C.POINTER(CcStats)],
