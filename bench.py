@@ -298,7 +298,8 @@ def leg_pr_cc(api, ctx, ef, seed, renumber, extra, cpu):
         res[name] = {"teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "passes": cst["hook_passes"]}
         if n and not sym:
             alg = 8 * cE + 12 * (1 << 24)
-            res[name]["hook_pass"] = {"path": path, "ms": round(ms / n, 4), "algorithmic_GBps": round(alg / (ms / n * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (ms / n * 1e-3) / 1e9)}
+            pass_ms = ms / (3 * cst["hook_passes"])                 # all launches of a hook pass (gather + accumulate + fused tiles), 3 timed runs
+            res[name]["hook_pass"] = {"path": path, "ms": round(pass_ms, 4), "algorithmic_GBps": round(alg / (pass_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (pass_ms * 1e-3) / 1e9)}
     extra["cc_rmat24x16_symmetrised"] = res
     if cpu is not None:
         O, threads = cpu
@@ -350,8 +351,9 @@ def leg_cc_big(api, vd, ctx, cc_scale, seed, renumber, chunk_edges, extra):
         if n and not sym:
             alg = 8 * cE + 12 * cV
             res[name]["plan_build_ms_once_per_graph_NOT_in_ms"] = round(t_plan_gpu, 1)
-            res[name]["hook_pass"] = {"path": path, "ms": round(ms / n, 4), "algorithmic_GBps": round(alg / (ms / n * 1e-3) / 1e9, 1),
-                                      "frac_of_hbm_peak": frac(alg / (ms / n * 1e-3) / 1e9)}
+            pass_ms = ms / (2 * cst["hook_passes"])                 # every piece's launches of a hook pass, 2 timed runs
+            res[name]["hook_pass"] = {"path": path + " in row-range pieces", "ms": round(pass_ms, 4), "algorithmic_GBps": round(alg / (pass_ms * 1e-3) / 1e9, 1),
+                                      "frac_of_hbm_peak": frac(alg / (pass_ms * 1e-3) / 1e9)}
     same = torch.equal(labels["shiloach_vishkin"], labels["union_find_symmetric"])
     lab = labels["shiloach_vishkin"].long()
     roots = bool((lab[lab] == lab).all())
@@ -487,8 +489,8 @@ def leg_cc_sharded(api, vd, vs, comm, ctx, dist, world, rank, cc_scale, seed, ch
     extra["cc_rmat_symmetrised_sharded"] = {
         "scale": cc_scale, "stored_edges": cE, "teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "hook_passes": passes, "shard_edges": int(shard.E),
         "graph_build_s": round(t_build, 2), "exchange": st, "labels_idempotent": ok,
-        "rank0_hook_pass": {"path": path, "ms": round(ms / max(n, 1), 4), "algorithmic_GBps": round(alg / (ms / max(n, 1) * 1e-3) / 1e9, 1) if ms > 0 else None,
-                            "frac_of_hbm_peak": frac(alg / (ms / max(n, 1) * 1e-3) / 1e9) if ms > 0 else None}}
+        "rank0_hook_pass": {"path": path, "ms": round(ms / max(passes, 1), 4), "algorithmic_GBps": round(alg / (ms / max(passes, 1) * 1e-3) / 1e9, 1) if ms > 0 else None,
+                            "frac_of_hbm_peak": frac(alg / (ms / max(passes, 1) * 1e-3) / 1e9) if ms > 0 else None}}
     if not ok:
         sys.exit("bench.py: sharded CC labels are not idempotent")
     shard.close()

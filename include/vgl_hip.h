@@ -132,13 +132,27 @@ int vgl_hip_gnf_equal_i32(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_v
 int vgl_hip_graph_tile_rows(vgl_hip_graph *g, int direction, const int32_t **d_tile_row, int64_t *ntiles);
 int vgl_hip_frontier_advance_plan(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f, int direction,
                                   const int64_t **d_offs, const int32_t **d_tile_first, int64_t *edges);
-/* generate_new_frontier with a USER predicate (the C++ operator class): the count pass -- predicate, flags, per-tile counts, totals --
- * runs in the caller's translation unit (vgl_k_gnf_count of csrc/vgl_gnf.h instantiated with the user's lambda; it may write the
- * terminator of the edge-offset array returned by vgl_hip_frontier_plan_offsets), vgl_hip_gnf_complete does the rest: size / neighbours /
- * sparsity choice (generate_new_frontier.hpp:67-91,113-164) and, for a SPARSE result, the ascending-id compaction -- with the exclusive
- * out-edge offsets of the ids when want_plan != 0, which vgl_hip_frontier_advance_plan(direction 0) then reuses. */
-int64_t *vgl_hip_frontier_plan_offsets(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f);
-int vgl_hip_gnf_complete(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f, double dense_threshold, int want_plan);
+/* generate_new_frontier with a USER predicate (the C++ operator class).  The count pass -- predicate, flags, per-tile counts, totals --
+ * runs in the caller's translation unit: vgl_k_gnf_count of csrc/vgl_gnf.h instantiated with the user's lambda, launched on the context's
+ * stream with the buffers vgl_hip_gnf_begin hands out (plain pointers: the caller never sees the library's internal structures).
+ * vgl_hip_gnf_complete waits for that launch (sequence number `seq` from begin, published by the kernel's last workgroup) and does the
+ * rest: size / neighbours / sparsity choice (generate_new_frontier.hpp:67-91,113-164) and, for a SPARSE result, the ascending-id
+ * compaction -- with the exclusive out-edge offsets of the ids when want_plan != 0, which vgl_hip_frontier_advance_plan(direction 0) reuses. */
+typedef struct {
+    int32_t nrows, row_begin;          /* owned rows of the graph handle (generate_new_frontier needs a whole-graph handle) */
+    int64_t nvtiles;                   /* 2048-vertex tiles = workgroups of the count launch (256 threads each) */
+    const int64_t *out_rowptr;         /* degrees counted into the neighbour total */
+    int32_t *vt_cnt, *vt_cnt_off;      /* per-tile counts and their exclusive offsets */
+    int64_t *vt_deg, *vt_deg_off;
+    uint32_t *ticket;                  /* arrival counters of the launch (the last workgroup scans the tiles) */
+    int64_t *counters;                 /* device counter slots */
+    volatile int64_t *host_counters;   /* their pinned mirror */
+    int32_t *flags;                    /* the frontier's flags (written by the count pass) */
+    int64_t *plan_offs;                /* want_plan: edge-offset array whose terminator the count pass writes, else NULL */
+    int64_t seq;                       /* sequence number the launch must publish */
+} vgl_hip_gnf_buffers;
+int vgl_hip_gnf_begin(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f, int want_plan, vgl_hip_gnf_buffers *out);
+int vgl_hip_gnf_complete(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier *f, double dense_threshold, int want_plan, int64_t seq);
 /* sums n doubles on the device in a fixed order (the operator class folds its per-workgroup reduce partials with it) */
 int vgl_hip_reduce_sum_f64_buffer(vgl_hip_ctx *ctx, int64_t n, const double *d_values, double *result);
 

@@ -433,20 +433,33 @@ static int vgl_frontier_reserve(vgl_hip_graph *g, vgl_hip_frontier *f)
 
 extern "C" {
 
-int64_t *vgl_hip_frontier_plan_offsets(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f)
+int vgl_hip_gnf_begin(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, int want_plan, vgl_hip_gnf_buffers *out)
 {
-    if (!c || !g || !f || vgl_frontier_reserve(g, f)) return nullptr;
-    return f->offs;
+    if (!c || !g || !f || !out) VGL_FAIL("gnf_begin: null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("generate_new_frontier: graph handle must own all rows");
+    if (want_plan) VGL_TRY(vgl_frontier_reserve(g, f));
+    out->nrows = g->nrows; out->row_begin = g->row_begin; out->nvtiles = g->nvtiles; out->out_rowptr = g->out.rowptr;
+    out->vt_cnt = g->vt_cnt; out->vt_cnt_off = g->vt_cnt_off; out->vt_deg = g->vt_deg; out->vt_deg_off = g->vt_deg_off;
+    out->ticket = g->nvtiles <= 16384 ? g->tickets + 0 * VGL_TICKET_WORDS : nullptr;      // beyond 2^25 vertices vgl_hip_gnf_complete runs the scan pass
+    out->counters = c->d_counters; out->host_counters = (volatile int64_t *)c->h_counters;
+    out->flags = f->flags; out->plan_offs = want_plan ? f->offs : nullptr;
+    out->seq = vgl_next_seq(c);
+    return 0;
 }
 
 // second half of a frontier generation whose count pass ran in the caller's translation unit (the C++ operator class evaluates the
 // user's predicate in vgl_k_gnf_count itself: flags, per-tile counts, totals in the context's pinned counters): size / neighbours /
 // sparsity, and for a SPARSE result the ascending-id compaction -- with the exclusive out-edge offsets of the ids when want_plan, so
 // that the advance that follows needs no offset pass of its own.
-int vgl_hip_gnf_complete(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, double dense_threshold, int want_plan)
+int vgl_hip_gnf_complete(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, double dense_threshold, int want_plan, int64_t seq)
 {
     if (!c || !g || !f) VGL_FAIL("gnf_complete: null argument");
     if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("generate_new_frontier: graph handle must own all rows");
+    VGL_HIP_TRY(hipGetLastError());
+    if (g->nvtiles > 16384)                                  // the count launch left per-tile counts only (see vgl_gnf_run)
+        hipLaunchKernelGGL(vgl_k_gnf_scan, dim3(1), dim3(VGL_SCAN_THREADS), 0, c->stream, g->nvtiles, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, c->d_counters,
+                           want_plan ? f->offs : (int64_t *)nullptr, (volatile int64_t *)c->h_counters, seq);
+    VGL_TRY(vgl_wait_counters(c, seq));
     f->size = (int32_t)c->h_counters[C_FRONT];
     f->neighbours = c->h_counters[C_NEIGH];
     f->plan_dir = -1;

@@ -1293,13 +1293,15 @@ public:
         // ONE pass evaluates the condition, writes the flags and counts (the last workgroup scans the per-tile counts and hands size and
         // neighbour count to the host); the compaction then reads the flags and leaves the ids' out-edge offsets behind for scatter
         vgl_hip_ctx *c = VGL_RUNTIME::ctx();
-        vgl_hip_frontier *fh = f.get_handle();
         const bool plan = current_traversal_direction == SCATTER;
-        int64_t *offs = plan ? vgl_hip_frontier_plan_offsets(c, g.get_handle(), fh) : nullptr;
-        if (plan && !offs) throw vgl_hip_last_error();
+        vgl_hip_gnf_buffers b;
+        VGL_HIP_CALL(vgl_hip_gnf_begin(c, g.get_handle(), f.get_handle(), plan ? 1 : 0, &b));
         const vgl_pred_user<C> pred{filter_cond, v.rowptr};
-        if (vgl_gnf_run(c, g.get_handle(), pred, fh->ids, offs, nullptr, nullptr, fh->flags, false, true)) throw vgl_hip_last_error();
-        VGL_HIP_CALL(vgl_hip_gnf_complete(c, g.get_handle(), fh, dense_threshold, plan ? 1 : 0));
+        hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), pred, b.nrows, b.row_begin,
+                           b.out_rowptr, b.vt_cnt, b.vt_deg, (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters,
+                           b.plan_offs, b.host_counters, b.seq);
+        VGL_HIP_RT(hipGetLastError());
+        VGL_HIP_CALL(vgl_hip_gnf_complete(c, g.get_handle(), f.get_handle(), dense_threshold, plan ? 1 : 0, b.seq));
         performance_stats.update_gnf_stats(watch.seconds(), (size_t)V);
     }
 

@@ -85,7 +85,8 @@ _SIGNATURES = {
     "vgl_hip_graph_tile_rows": [_p, _int, _pp, C.POINTER(_i64)],
     "vgl_hip_frontier_advance_plan": [_p, _p, _p, _int, _pp, _pp, C.POINTER(_i64)],
     "vgl_hip_reduce_sum_f64_buffer": [_p, _i64, _p, C.POINTER(_dbl)],
-    "vgl_hip_gnf_complete": [_p, _p, _p, _dbl, _int],
+    "vgl_hip_gnf_begin": [_p, _p, _p, _int, _p],
+    "vgl_hip_gnf_complete": [_p, _p, _p, _dbl, _int, _i64],
     "vgl_hip_reduce_sum_i32": [_p, _p, _p, C.POINTER(_i64)],
     "vgl_hip_reduce_sum_f32": [_p, _p, _p, C.POINTER(_dbl)],
     "vgl_hip_count_not_equal_u32": [_p, _i32, _p, _p, C.POINTER(_i64)],
@@ -166,7 +167,6 @@ _SPECIAL = {
     "vgl_hip_ctx_stream": (_p, [_p]),
     "vgl_hip_frontier_ids": (_p, [_p]),
     "vgl_hip_frontier_flags": (_p, [_p]),
-    "vgl_hip_frontier_plan_offsets": (_p, [_p, _p, _p]),
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_SPECIAL))
 
