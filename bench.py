@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-KERNEL_OF = {"bfs_bottom_up": "vgl_k_bu_probe", "bfs_top_down": "vgl_k_td_expand", "gnf": "vgl_k_gnf_count<vgl_pred_equal_i32>",
+KERNEL_OF = {"bfs_bottom_up": "vgl_k_bu_probe<true>", "bfs_top_down": "vgl_k_td_expand", "gnf": "vgl_k_gnf_count<vgl_pred_equal_i32>",
              "sssp_relax": "vgl_k_sssp_relax<true>"}
 
 

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-3 profile collection, run on the GPU box from the repository root:  gpurun -- bash profiles/collect_r03.sh
+# Writes under gpurun_out/r3prof/; the summaries are then copied into profiles/ (see profiles/README.md).
+set -u
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/r3prof
+mkdir -p $OUT
+export TMPDIR=/tmp
+BFS="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-sssp --no-pr-cc --no-operator-api"
+# 1. per-kernel times of the default bench command (CPU baseline and the operator-API apps off: they only add host / child-process time)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-operator-api > $OUT/trace_bench_line.json 2> $OUT/trace.err
+echo "trace done" > $OUT/progress.txt
+# 2. HBM traffic of the BFS kernels (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in passes of their own, no tracing in the same run)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_bfs_$i -- $BFS > $OUT/pmc_bfs_$i.log 2>&1
+    echo "pmc bfs $i done ($set)" >> $OUT/progress.txt
+done
+# 3. the Bellman-Ford pull pass on RMAT-24: two-pass layout only (round 2: VGL_BLK_FUSE_MIN=0) against dense block pairs as fused tiles
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    VGL_BLK_FUSE_MIN=0 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_pull_twopass_$i -- python3 profiles/microbench/sssp_do_trace.py 1 pull > $OUT/pmc_pull_twopass_$i.log 2>&1
+    rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_pull_fused_$i -- python3 profiles/microbench/sssp_do_trace.py 1 pull > $OUT/pmc_pull_fused_$i.log 2>&1
+    echo "pmc pull $i done ($set)" >> $OUT/progress.txt
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_do -- python3 profiles/microbench/sssp_do_trace.py 3 do > $OUT/trace_do.log 2>&1
+echo "do trace done" >> $OUT/progress.txt
+python3 profiles/pmc_reduce.py $OUT > $OUT/summary.log 2>&1
+find $OUT -name "*_kernel_trace.csv" -size +2M -delete
+find $OUT -name "*counter_collection.csv" -size +0 -delete
+echo "all done" >> $OUT/progress.txt

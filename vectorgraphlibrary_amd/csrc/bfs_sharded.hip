@@ -215,6 +215,7 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
             int64_t found = 0, probed = 0;
             VGL_TRY(vgl_hip_bfs_step_bottom_up(c, g, d_levels, level, visited, front, front_new, stats ? &found : nullptr, stats ? &probed : nullptr));
             st.bu_steps++; st.bu_edges += probed; st.bu_found += found; st.edges_examined += probed;
+            vgl_timed_launch tl(c, "bfs_shard_resolve");
             hipLaunchKernelGGL(vgl_k_shard_resolve<false>, dim3(nb_own), dim3(VGL_BLOCK), 0, c->stream, w0, nw, 1, (const uint64_t *)front_new, (int64_t)0, w0,
                                visited, front_new, d_levels, level + 1, g->out.rowptr, g->row_begin, g->row_end, partials, ticket, my_counts);
         } else {
@@ -225,8 +226,11 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
                 VGL_TRY(vgl_hip_bitmap_to_ids(c, words, cand, sparse_cap, my_list));
                 VGL_TRY(vgl_comm_allgather(m, my_list, all_lists, sizeof(int32_t) * (size_t)(1 + sparse_cap)));
                 VGL_HIP_TRY(hipMemsetAsync(front_new, 0, sizeof(uint64_t) * (size_t)words, c->stream));
+                {
+                vgl_timed_launch tl(c, "bfs_shard_resolve");
                 hipLaunchKernelGGL(vgl_k_shard_apply_ids, dim3(64), dim3(VGL_BLOCK), 0, c->stream, P, sparse_cap, (const int32_t *)all_lists, V, g->row_begin,
                                    g->row_end, visited, front_new, d_levels, level + 1, g->out.rowptr, partials, ticket, my_counts);
+                }
                 VGL_TRY(vgl_comm_allgather(m, my_counts, all_counts, sizeof(int64_t) * 4));
                 VGL_TRY(vgl_comm_read_small(m, all_counts, 4 * P, h_counts));
                 if (h_counts[2] == 0) { exchanged_sparse = true; m->stats.sparse_levels++; }      // (every rank computed the same overflow flag)
@@ -238,6 +242,7 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
                     if (equal) { VGL_TRY(vgl_comm_alltoall(m, cand, recv, (words / P) * 8)); in = recv; stride = words / P; off = 0; }
                     else { VGL_TRY(vgl_comm_allgather(m, cand, recv, words * 8)); in = recv; stride = words; off = w0; }
                 }
+                vgl_timed_launch tl(c, "bfs_shard_resolve");
                 hipLaunchKernelGGL(vgl_k_shard_resolve<true>, dim3(nb_own), dim3(VGL_BLOCK), 0, c->stream, w0, nw, P, in, stride, off, visited, front_new,
                                    d_levels, level + 1, g->out.rowptr, g->row_begin, g->row_end, partials, ticket, my_counts);
             }

@@ -30,7 +30,8 @@ struct vgl_hosted_header {
     std::atomic<uint32_t> generation;
     uint32_t world;
     uint64_t slot_bytes;
-    char pad[256 - 24];
+    std::atomic<uint32_t> turn;          // VGL_HOSTED_SERIALIZE=1: ranks that have finished the phase after the last barrier
+    char pad[256 - 28];
 };
 static_assert(sizeof(vgl_hosted_header) == 256, "hosted header is one 256-byte block");
 constexpr uint32_t VGL_HOSTED_MAGIC = 0x56474C48u;      // "VGLH"
@@ -38,24 +39,35 @@ constexpr double VGL_HOSTED_TIMEOUT_S = 180.0;
 
 static inline char *vgl_hosted_slot(vgl_hip_comm *m, int p) { return reinterpret_cast<char *>(m->shm) + sizeof(vgl_hosted_header) + (size_t)p * m->slot_bytes; }
 
+// VGL_HOSTED_SERIALIZE=1 (rehearsals of more ranks than GPUs): between two barriers the ranks work ONE AT A TIME, in rank order, so that the
+// kernel times a rank measures with HIP events are those of its own work, not of P processes or threads sharing the card.
 static int vgl_hosted_barrier(vgl_hip_comm *m)
 {
     vgl_hosted_header *h = m->shm;
+    static const bool serialize = getenv("VGL_HOSTED_SERIALIZE") && getenv("VGL_HOSTED_SERIALIZE")[0] == '1';
+    const auto t0 = std::chrono::steady_clock::now();
+    auto timed_out = [&](long spin) {
+        if ((spin & 0xFFFF) != 0xFFFF) return false;
+        usleep(50);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > VGL_HOSTED_TIMEOUT_S;
+    };
     const uint32_t gen = h->generation.load(std::memory_order_acquire);
+    if (serialize) h->turn.fetch_add(1, std::memory_order_acq_rel);         // my phase is over: the next rank may start its own
     if (h->arrived.fetch_add(1, std::memory_order_acq_rel) == (uint32_t)m->world - 1) {
         h->arrived.store(0, std::memory_order_relaxed);
+        h->turn.store(0, std::memory_order_relaxed);
         h->generation.fetch_add(1, std::memory_order_release);
-        return 0;
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    for (long spin = 0; h->generation.load(std::memory_order_acquire) == gen; spin++) {
-        if ((spin & 0xFFFF) == 0xFFFF) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > VGL_HOSTED_TIMEOUT_S)
-                VGL_FAIL("hosted transport: a rank did not reach the barrier (timeout)");
-            usleep(50);
+    } else {
+        for (long spin = 0; h->generation.load(std::memory_order_acquire) == gen; spin++) {
+            if (timed_out(spin)) VGL_FAIL("hosted transport: a rank did not reach the barrier (timeout)");
+            __builtin_ia32_pause();
         }
-        __builtin_ia32_pause();
     }
+    if (serialize)
+        for (long spin = 0; h->turn.load(std::memory_order_acquire) != (uint32_t)m->rank; spin++) {
+            if (timed_out(spin)) VGL_FAIL("hosted transport: the rank before this one did not finish its phase (timeout)");
+            __builtin_ia32_pause();
+        }
     return 0;
 }
 
@@ -417,7 +429,7 @@ int vgl_hip_comm_create_hosted(vgl_hip_ctx *c, int rank, int world, const char *
     m->ctx = c; m->rank = rank; m->world = world; m->transport = VGL_HIP_COMM_HOSTED;
     m->shm = reinterpret_cast<vgl_hosted_header *>(p); m->shm_bytes = total; m->slot_bytes = slot_bytes; m->shm_name = name;
     if (rank == 0) {
-        m->shm->arrived.store(0); m->shm->generation.store(0);
+        m->shm->arrived.store(0); m->shm->generation.store(0); m->shm->turn.store(0);
         m->shm->world = (uint32_t)world; m->shm->slot_bytes = slot_bytes;
         m->shm->magic.store(VGL_HOSTED_MAGIC, std::memory_order_release);
     } else {
