@@ -35,7 +35,8 @@ struct vgl_hosted_header {
 };
 static_assert(sizeof(vgl_hosted_header) == 256, "hosted header is one 256-byte block");
 constexpr uint32_t VGL_HOSTED_MAGIC = 0x56474C48u;      // "VGLH"
-constexpr double VGL_HOSTED_TIMEOUT_S = 180.0;
+static double vgl_hosted_timeout() { static const double t = getenv("VGL_HOSTED_TIMEOUT") ? atof(getenv("VGL_HOSTED_TIMEOUT")) : 180.0; return t; }
+#define VGL_HOSTED_TIMEOUT_S (vgl_hosted_timeout())
 
 static inline char *vgl_hosted_slot(vgl_hip_comm *m, int p) { return reinterpret_cast<char *>(m->shm) + sizeof(vgl_hosted_header) + (size_t)p * m->slot_bytes; }
 
@@ -451,7 +452,11 @@ int vgl_hip_comm_destroy(vgl_hip_comm *m)
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     if (m->nccl) ncclCommDestroy(m->nccl);
-    if (m->shm) munmap(m->shm, m->shm_bytes);
+    if (m->shm) {
+        // serialised rehearsal: leaving counts as the end of this rank's last phase (the next rank is waiting for its turn)
+        if (getenv("VGL_HOSTED_SERIALIZE") && getenv("VGL_HOSTED_SERIALIZE")[0] == '1') m->shm->turn.fetch_add(1, std::memory_order_acq_rel);
+        munmap(m->shm, m->shm_bytes);
+    }
     for (int i = 0; i < VGL_COMM_SCRATCH_SLOTS; i++) if (m->scratch[i]) hipFree(m->scratch[i]);
     if (m->d_small) hipFree(m->d_small);
     if (m->h_small) hipHostFree(m->h_small);
