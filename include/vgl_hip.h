@@ -198,7 +198,7 @@ typedef struct {
                                             incoming edges; here a blocked gather / LDS-minimum pass, no scattered stores, no per-edge L2 line */
 #define VGL_HIP_SSSP_DIRECTION_OPT 4     /* push over the compacted frontier of the rows that changed (atomic minima) while they own few edges,
                                             pull while they own many; the switch is on the share of edges whose source changed in the last
-                                            super-step (VGL_SSSP_PULL_SHARE, 0.35) */
+                                            super-step (VGL_SSSP_PULL_SHARE, 0.2) */
 int vgl_hip_sssp_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, int32_t source, int mode,
                      float *d_dist, vgl_hip_sssp_stats *stats);
 /* SSWP::vgl_dijkstra, algorithms/sswp/widest_paths.hpp:5-76 (single-source widest paths): widths[source] = FLT_MAX, others 0;

@@ -214,16 +214,17 @@ void make_units(const std::vector<uint32_t> &bounds, uint32_t cap, bool keep_emp
     for (size_t b = 0; b + 1 < bounds.size(); b++) {
         const uint32_t c0 = bounds[b], c1 = bounds[b + 1], n = c1 - c0;
         if (n == 0 && !keep_empty) continue;
-        const uint32_t parts = std::max<uint32_t>(1, (n + cap - 1) / cap);
-        const uint32_t step = (n + parts - 1) / parts;
+        const uint32_t want = std::max<uint32_t>(1, (n + cap - 1) / cap);
+        const uint32_t step = std::max<uint32_t>(1, (n + want - 1) / want);
+        const uint32_t parts = std::max<uint32_t>(1, (n + step - 1) / step);        // no empty parts: (parts - 1) * step < n
         if (parts > 1 && want_slabs) multi.push_back(vgl_blk_multi{(int32_t)b, n_slabs, (int32_t)parts, 0});
         for (uint32_t p = 0; p < parts; p++) {
-            const uint32_t lo = c0 + p * step, hi = std::min(c1, lo + step);
+            const uint32_t lo = c0 + std::min(n, p * step), hi = c0 + std::min(n, (p + 1) * step);
             units.push_back(vgl_blk_unit{(int32_t)b, parts > 1 ? (want_slabs ? n_slabs++ : 0) : -1, lo, hi});
         }
     }
     // long units first: the tail of the launch is then made of short ones
-    std::stable_sort(units.begin(), units.end(), [](const vgl_blk_unit &x, const vgl_blk_unit &y) { return x.chunk1 - x.chunk0 > y.chunk1 - y.chunk0; });
+    std::stable_sort(units.begin(), units.end(), [](const vgl_blk_unit &x, const vgl_blk_unit &y) { return (int64_t)x.chunk1 - (int64_t)x.chunk0 > (int64_t)y.chunk1 - (int64_t)y.chunk0; });
 }
 
 }  // namespace

@@ -287,7 +287,8 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     if (source < 0 || source >= g->V) return fail("source vertex out of range");
     if (mode != VGL_HIP_SSSP_PULL && mode != VGL_HIP_SSSP_DIRECTION_OPT) return fail("unknown mode");
     const char *env = getenv("VGL_SSSP_PULL_SHARE");
-    const double share = (env && *env) ? atof(env) : 0.35;      // pull when the rows that changed own more than this share of the edges (0.2 - 0.5 measure within 3 % on RMAT-24)
+    const double share = (env && *env) ? atof(env) : 0.2;       // pull when the rows that changed own more than this share of the edges (with the fused-tile
+                                                                // pass, RMAT-24, mean of 5 sources: 0.1 15.5 ms, 0.15 15.4, 0.2 15.35, 0.25 15.6, 0.35 15.9, 0.5 17.6)
     hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, (int32_t *)nullptr);
     vgl_hip_sssp_stats st = {0, 0, 0, 0, 0};
     int64_t pull_edges = 0, push_edges = 0;

@@ -39,6 +39,10 @@ constexpr int VGL_CHUNK = 64;                    // entries per chunk
 constexpr int VGL_BTHREADS = 1024;               // workgroup of the two kernels (16 wavefronts, one workgroup per CU: 128 KiB LDS)
 constexpr int VGL_BWAVES = VGL_BTHREADS / 64;
 constexpr int VGL_BGROUP = 8;                    // chunks per wavefront step (16 bytes of uint16 indices per lane)
+// the windows below are sized for gfx950's 160 KiB of LDS per CU; other targets (gfx942: 64 KiB) cannot hold them
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "vgl_blocked.h: the blocked advance keeps 128 KiB windows in LDS and is written for gfx950 (MI355X) only; build with --offload-arch=gfx950"
+#endif
 // a_lo of pad entry i of a chunk = (accumulate block size) + i: 64 dummy accumulators behind the window, no branch per entry
 
 struct vgl_blk_unit {                            // one workgroup's share: chunks [chunk0, chunk1) of block `block`
