@@ -632,6 +632,18 @@ def test_pagerank_indegree_paths_and_hub_schedule(ctx, oracle):
     assert (a.cpu().numpy().view(np.int32) == want.view(np.int32)).all()
     assert (b.cpu().numpy().view(np.int32) == want.view(np.int32)).all()
     both.close(); out_only.close()
+    # the longest rows as GIANT hubs (a whole workgroup per row: three wavefronts gather, one adds; vgl_pull.h) -- forced from 1000 entries
+    # here (default 32768), odd row lengths included -- and with the scheme off: the same bits, the chain's order is the adjacency order
+    import os
+    for name, value in (("VGL_PULL_GIANT_DEGREE", "1000"), ("VGL_PULL_GIANT_DEGREE", "513"), ("VGL_PULL_NO_GIANTS", "1")):
+        os.environ[name] = value
+        try:
+            g2 = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True)
+            c2, _ = api.page_rank(g2, 4)
+        finally:
+            os.environ.pop(name)
+        assert (c2.cpu().numpy().view(np.int32) == want.view(np.int32)).all(), (name, value)
+        g2.close()
 
 
 @pytest.mark.gpu

@@ -14,6 +14,7 @@
 #include "vgl_blocked.h"
 #include "vgl_comm.h"
 #include <queue>
+#include <cstdio>
 #include <cstdlib>
 
 static inline unsigned vgl_grid3(int64_t n, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
@@ -148,7 +149,8 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
     VGL_HIP_TRY(hipGetLastError());
     VGL_TRY(vgl_hip_memcpy_d2h(c, &dir.nhubs, d_count, sizeof(int32_t)));
     const size_t n = (size_t)dir.nhubs;
-    dir.hub_blocks = n ? (int)std::min<int64_t>(VGL_PULL_HUB_BLOCKS, vgl_ceil_div((int64_t)n, VGL_WAVES)) : 0;
+    const int hub_blocks_cap = getenv("VGL_PULL_HUB_BLOCKS") ? std::max(1, atoi(getenv("VGL_PULL_HUB_BLOCKS"))) : VGL_PULL_HUB_BLOCKS;
+    dir.hub_blocks = n ? (int)std::min<int64_t>(hub_blocks_cap, vgl_ceil_div((int64_t)n, VGL_WAVES)) : 0;
     const int W = dir.hub_blocks * VGL_WAVES;
     // device layout: [n hub rows grouped by wavefront][W+1 offsets]
     VGL_HIP_TRY(hipMalloc((void **)&dir.hub_rows, sizeof(int32_t) * (n + (size_t)W + 1)));
@@ -158,13 +160,46 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
         VGL_TRY(vgl_hip_memcpy_d2h(c, deg.data(), d_deg, sizeof(int32_t) * n));
         for (size_t i = 0; i < n; i++) order[i] = (int32_t)i;
         std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return deg[x] != deg[y] ? deg[x] > deg[y] : rows[x] < rows[y]; });
+        // giants (vgl_pull.h): the longest rows go to whole workgroups, longest-processing-time over at most VGL_PULL_GIANT_BLOCKS of them
+        size_t ng = 0;
+        const int giant_degree = getenv("VGL_PULL_GIANT_DEGREE") ? atoi(getenv("VGL_PULL_GIANT_DEGREE")) : VGL_PULL_GIANT_DEGREE;
+        while (ng < n && deg[order[ng]] >= giant_degree) ng++;
+        if (getenv("VGL_PULL_NO_GIANTS")) ng = 0;
+        if (getenv("VGL_PULL_TRACE")) {
+            int64_t ge = 0, he = 0;
+            for (size_t i = 0; i < n; i++) (i < ng ? ge : he) += deg[order[i]];
+            fprintf(stderr, "[vgl pull] %zu hubs (%lld entries), %zu giants (%lld entries, largest %d)\n", n, (long long)(ge + he), ng, (long long)ge, n ? deg[order[0]] : 0);
+        }
+        dir.ngiants = (int)ng;
+        dir.giant_blocks = (int)std::min<size_t>(ng, VGL_PULL_GIANT_BLOCKS);
+        if (ng > 0) {
+            typedef std::pair<int64_t, int> gslot;
+            std::priority_queue<gslot, std::vector<gslot>, std::greater<gslot>> gheap;
+            for (int b = 0; b < dir.giant_blocks; b++) gheap.push(gslot(0, b));
+            std::vector<std::vector<int32_t>> glists((size_t)dir.giant_blocks);
+            for (size_t i = 0; i < ng; i++) {
+                gslot sl = gheap.top();
+                gheap.pop();
+                glists[(size_t)sl.second].push_back(rows[order[i]]);
+                gheap.push(gslot(sl.first + deg[order[i]], sl.second));
+            }
+            std::vector<int32_t> gp(ng + (size_t)dir.giant_blocks + 1);
+            size_t gpos = 0;
+            for (int b = 0; b < dir.giant_blocks; b++) {
+                gp[ng + (size_t)b] = (int32_t)gpos;
+                for (int32_t r : glists[(size_t)b]) gp[gpos++] = r;
+            }
+            gp[ng + (size_t)dir.giant_blocks] = (int32_t)gpos;
+            VGL_HIP_TRY(hipMalloc((void **)&dir.giant_rows, sizeof(int32_t) * gp.size()));
+            VGL_TRY(vgl_hip_memcpy_h2d(c, dir.giant_rows, gp.data(), sizeof(int32_t) * gp.size()));
+        }
         // longest-processing-time list scheduling: the next-largest hub goes to the least loaded wavefront, so the critical path is
         // max(largest hub, total / W) edges; a fixed per-hub cost stands for the un-overlapped first batch
         typedef std::pair<int64_t, int> slot;
         std::priority_queue<slot, std::vector<slot>, std::greater<slot>> heap;
         for (int wv = 0; wv < W; wv++) heap.push(slot(0, wv));
         std::vector<std::vector<int32_t>> lists((size_t)W);
-        for (size_t i = 0; i < n; i++) {
+        for (size_t i = ng; i < n; i++) {                                  // (the giants have their own workgroups)
             slot s = heap.top();
             heap.pop();
             lists[(size_t)s.second].push_back(rows[order[i]]);
@@ -350,9 +385,12 @@ int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *indeg, con
     {
         vgl_timed_launch tl(c, "pr_pull");
         const vgl_pr_epilogue epi{dangling, k, d, ranks_out};
-        hipLaunchKernelGGL((vgl_k_pull_sum<float, true, false, vgl_pr_epilogue>), dim3(nblk + hub_blocks), dim3(VGL_BLOCK), 0, c->stream, g->nrows,
+        const int giant_blocks = g->out.giant_blocks;
+        hipLaunchKernelGGL((vgl_k_pull_sum<float, true, false, vgl_pr_epilogue>), dim3(nblk + hub_blocks + giant_blocks), dim3(VGL_BLOCK), 0, c->stream, g->nrows,
                            g->row_begin, g->out.rowptr, g->out.adj, (const float *)contrib, epi, hub_blocks, (const int32_t *)g->out.hub_rows,
-                           (const int32_t *)(g->out.hub_rows + g->out.nhubs), (double *)nullptr, (const int32_t *)g->out.pull_blk_row);
+                           (const int32_t *)(g->out.hub_rows + g->out.nhubs), (double *)nullptr, (const int32_t *)g->out.pull_blk_row,
+                           (const int32_t *)nullptr, 0, (float *)nullptr, giant_blocks, (const int32_t *)g->out.giant_rows,
+                           (const int32_t *)(g->out.giant_rows + g->out.ngiants));
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;

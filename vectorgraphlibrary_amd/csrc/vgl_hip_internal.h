@@ -68,6 +68,8 @@ struct vgl_dir_csr {                 // one direction of the graph (borrowed) + 
     int32_t *hub_rows = nullptr;     // pull sums (PageRank, HITS): rows with >= 512 edges grouped per wavefront + offsets (lazy)
     int32_t nhubs = 0;
     int hub_blocks = 0;              // workgroups of the pull kernel that run the hub schedule
+    int32_t *giant_rows = nullptr;   // rows of at least VGL_PULL_GIANT_DEGREE entries, grouped per workgroup + offsets (the workgroup scheme of vgl_pull.h)
+    int ngiants = 0, giant_blocks = 0;
     int32_t *hub_chunks = nullptr;   // unordered hub sums (HITS): per chunk (row, first entry - row start in units of VGL_PULL_CHUNK); then, per hub in
                                      // row order, (row, first chunk, chunks) triples -- see vgl_pull_find_hubs
     int n_hub_chunks = 0, n_hub_list = 0;

@@ -33,7 +33,7 @@ __device__ __forceinline__ double vgl_add_rn(double a, double b) { return __dadd
 // Epi: struct with  __device__ void operator()(int32_t v, T sum) const  (writes the result of vertex v)
 template <class T, bool SKIP_SELF, bool SUMSQ, class Epi>
 __device__ __forceinline__ void vgl_pull_hub_waves(T *s_vals, const int32_t *hub_rows, const int32_t *hub_off, int32_t row_base,
-                                                   const int64_t *rowptr, const int32_t *adj, const T *x, Epi epi, double &sumsq)
+                                                   const int64_t *rowptr, const int32_t *adj, const T *x, Epi epi, double &sumsq, int hub_block = -1)
 {
     __builtin_amdgcn_s_setprio(3);
     const int lane = vgl_lane();
@@ -43,7 +43,7 @@ __device__ __forceinline__ void vgl_pull_hub_waves(T *s_vals, const int32_t *hub
     // No lane-dependent control flow anywhere below: the LDS hand-over relies on the wavefront staying converged (a ticket fetched
     // under `if (lane == 0)` let the compiler unswitch the loop on the lane id and the lanes ran apart).  Each wavefront owns a
     // precomputed list of hubs.
-    const int32_t w = __builtin_amdgcn_readfirstlane((int32_t)blockIdx.x * VGL_WAVES + vgl_wave());    // scalar: loops are uniform
+    const int32_t w = __builtin_amdgcn_readfirstlane((hub_block >= 0 ? hub_block : (int32_t)blockIdx.x) * VGL_WAVES + vgl_wave());    // scalar: loops are uniform
     const int32_t h_end = hub_off[w + 1];
     for (int32_t h = hub_off[w]; h < h_end; h++) {
         const int32_t r = hub_rows[h];
@@ -94,6 +94,85 @@ __device__ __forceinline__ void vgl_pull_hub_waves(T *s_vals, const int32_t *hub
         }
         epi(self, acc);                                                  // all lanes: same value, same address
         if (SUMSQ && lane == 0) sumsq += (double)acc * (double)acc;
+    }
+}
+
+// GIANT hubs (ORDERED kernels, round 3).  A hub's adjacency-order chain is one dependent add per entry; the per-wavefront scheme above
+// runs it at ~10 cycles per entry because the same wavefront also issues and waits for its gathers (one 512-value batch per ~2 us of memory
+// latency).  For the few hubs whose chain alone exceeds what a wavefront's whole list costs -- RMAT-24: the largest row has 7.4e5 entries,
+// ~3 of the 4.3 ms of a PageRank iteration -- the WORKGROUP shares the job: wavefronts 0-2 gather (three batches in flight each:
+// adjacency of batch i + 2, values of batch i + 1, LDS store of batch i), wavefront 3 only adds, reading 16-byte LDS words; rounds of three
+// batches are handed over through two sets of three LDS slots with one workgroup barrier per round.  Same order of additions, same bits.
+constexpr int VGL_PULL_GIANT_DEGREE = 32768;      // rows at least this long take the workgroup scheme (RMAT-24 x 32: 554 rows, 11 % of the hub entries;
+                                                  // PageRank iteration 4.19 ms without, 3.66 with the two longest rows only, 3.50 from 32768 down:
+                                                  // below that the launch sits on its 537 M gathers of a 64 MiB table, ~3.3 ms -- profiles/README.md, gather floor)
+constexpr int VGL_PULL_GIANT_BLOCKS = 64;
+template <class T, bool SKIP_SELF, bool SUMSQ, class Epi>
+__device__ __forceinline__ void vgl_pull_giant_hubs(T *s_a, T *s_b, const int32_t *giant_rows, const int32_t *giant_off, int gb, int32_t row_base,
+                                                    const int64_t *rowptr, const int32_t *adj, const T *x, Epi epi, double &sumsq)
+{
+    constexpr int B = VGL_PULL_HUB_BATCH, U = B / 64, NP = 3;          // NP producer wavefronts, wavefront NP is the consumer
+    const int lane = vgl_lane(), wave = vgl_wave();
+    auto slot = [&](int i) -> T * { return i < 4 ? s_a + i * B : s_b + (i - 4) * B; };     // 6 slots: two sets of three
+    if (wave == NP) __builtin_amdgcn_s_setprio(3);
+    const int32_t h_end = giant_off[gb + 1];
+    for (int32_t h = giant_off[gb]; h < h_end; h++) {
+        const int32_t r = giant_rows[h];
+        const int64_t b = rowptr[r];
+        const uint32_t n = (uint32_t)(rowptr[r + 1] - b);
+        const int32_t *adj_h = adj + b;
+        const int32_t self = row_base + r;
+        const uint32_t nbatches = (n + B - 1) / B, rounds = (nbatches + NP - 1) / NP;
+        T acc = (T)0;
+        T val[U];
+        int32_t dst[U];
+        auto load_adj = [&](uint32_t batch) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t q = batch * B + u * 64 + lane;
+                int32_t t = (batch < nbatches && q < n) ? adj_h[q] : -1;
+                if (SKIP_SELF && t == self) t = -1;
+                dst[u] = t;
+            }
+        };
+        auto gather = [&]() {
+#pragma unroll
+            for (int u = 0; u < U; u++) val[u] = dst[u] >= 0 ? x[(uint32_t)dst[u]] : (T)0;      // (+0 is an exact no-op of the chain)
+        };
+        // producer `wave` owns batches wave, wave + NP, ...: its k-th batch belongs to round k and goes to slot (k & 1) * NP + wave
+        if (wave < NP) { load_adj((uint32_t)wave); gather(); load_adj((uint32_t)wave + NP); }
+        for (uint32_t k = 0; k <= rounds; k++) {
+            if (wave < NP) {
+                if (k < rounds) {
+                    T *cur = slot((int)(k & 1) * NP + wave);
+#pragma unroll
+                    for (int u = 0; u < U; u++) cur[u * 64 + lane] = val[u];
+                    gather();                                           // batch wave + (k + 1) NP (entries past the row: zeros)
+                    load_adj((uint32_t)wave + (k + 2) * NP);
+                }
+            } else if (k > 0) {                                         // consumer: the three batches of round k - 1, in order
+                const uint32_t first = (k - 1) * NP;
+                for (int p = 0; p < NP; p++) {
+                    if (first + p >= nbatches) break;
+                    const T *cur = slot((int)((k - 1) & 1) * NP + p);
+                    const uint32_t left = n - (first + p) * B;
+                    const int n4 = (int)min((uint32_t)(B / 4), (left + 3) / 4);
+#pragma unroll 8
+                    for (int i = 0; i < n4; i++) {
+                        const T v0 = cur[4 * i], v1 = cur[4 * i + 1], v2 = cur[4 * i + 2], v3 = cur[4 * i + 3];
+                        acc = vgl_add_rn(acc, v0);
+                        acc = vgl_add_rn(acc, v1);
+                        acc = vgl_add_rn(acc, v2);
+                        acc = vgl_add_rn(acc, v3);
+                    }
+                }
+            }
+            __syncthreads();                                            // round k is parked, round k - 1 is folded: the sets swap
+        }
+        if (wave == NP) {
+            epi(self, acc);
+            if (SUMSQ && lane == 0) sumsq += (double)acc * (double)acc;
+        }
     }
 }
 
@@ -158,7 +237,8 @@ template <class T, bool SKIP_SELF, bool SUMSQ, class Epi, bool ORDERED = true>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32_t row_base, const int64_t *rowptr, const int32_t *adj,
                                                             const T *x, Epi epi, int hub_blocks, const int32_t *hub_rows,
                                                             const int32_t *hub_off, double *sumsq_partials, const int32_t *blk_row,
-                                                            const int32_t *hub_chunks = nullptr, int n_hub_chunks = 0, T *hub_chunk_sums = nullptr)
+                                                            const int32_t *hub_chunks = nullptr, int n_hub_chunks = 0, T *hub_chunk_sums = nullptr,
+                                                            int giant_blocks = 0, const int32_t *giant_rows = nullptr, const int32_t *giant_off = nullptr)
 {
     __shared__ T s_val[VGL_TILE];                       // ordinary rows: staged values; hub wavefronts: 4 x 512 values
     __shared__ int32_t s_dst[VGL_TILE];
@@ -167,15 +247,19 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_pull_sum(int32_t nrows, int32
     double sumsq = 0.0;
     // ORDERED: the hub workgroups are dispatched first (one per CU runs the hub schedule: the longest chain starts at once).
     // Unordered: the chunk workgroups come LAST -- they are short, and behind the row blocks they fill the tail of the launch.
-    const int first_hub = ORDERED ? 0 : (int)gridDim.x - hub_blocks;
-    if ((int)blockIdx.x >= first_hub && (int)blockIdx.x < first_hub + hub_blocks) {
-        if (ORDERED) vgl_pull_hub_waves<T, SKIP_SELF, SUMSQ>(s_val, hub_rows, hub_off, row_base, rowptr, adj, x, epi, sumsq);
+    // ORDERED: the giant-hub workgroups come first of all (giant_blocks of them; their chains are the launch's critical path)
+    const int first_hub = ORDERED ? giant_blocks : (int)gridDim.x - hub_blocks;
+    if (ORDERED && (int)blockIdx.x < giant_blocks) {
+        if constexpr (ORDERED)
+            vgl_pull_giant_hubs<T, SKIP_SELF, SUMSQ>(s_val, reinterpret_cast<T *>(s_dst), giant_rows, giant_off, (int)blockIdx.x, row_base, rowptr, adj, x, epi, sumsq);
+    } else if ((int)blockIdx.x >= first_hub && (int)blockIdx.x < first_hub + hub_blocks) {
+        if (ORDERED) vgl_pull_hub_waves<T, SKIP_SELF, SUMSQ>(s_val, hub_rows, hub_off, row_base, rowptr, adj, x, epi, sumsq, (int)blockIdx.x - first_hub);
         else {
             const int cw = ((int)blockIdx.x - first_hub) * VGL_WAVES + vgl_wave();
             vgl_pull_hub_chunks<T, SKIP_SELF>(hub_chunks, n_hub_chunks, row_base, rowptr, adj, x, hub_chunk_sums, cw);
         }
     } else {
-        const int32_t blk = ORDERED ? (int32_t)blockIdx.x - hub_blocks : (int32_t)blockIdx.x;
+        const int32_t blk = ORDERED ? (int32_t)blockIdx.x - hub_blocks - giant_blocks : (int32_t)blockIdx.x;
         const int32_t r_lo = blk_row[blk];
         const int32_t r_hi = blk_row[blk + 1];                          // <= r_lo + VGL_BLOCK
         const int32_t r = r_lo + threadIdx.x;
