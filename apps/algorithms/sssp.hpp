@@ -103,10 +103,13 @@ struct ShortestPaths {
     // (adjacency, weights) is built once per EdgesArray, its build time is printed, not charged to the traversals
     static double hip_fused_pull(VGL_Graph &graph, EdgesArray<float> &weights, VerticesArray<float> &distances, int source_vertex, bool direction_optimising)
     {
+        // the plan holds a reordered copy of the weights: rebuilt when the graph handle, the array or its contents (EdgesArray::version,
+        // bumped by set_all_random / set_all_constant) changed
         static vgl_hip_sssp_pull_plan *plan = nullptr;
         static const void *plan_graph = nullptr, *plan_weights = nullptr;
+        static unsigned long long plan_version = 0;
         vgl_hip_ctx *c = VGL_RUNTIME::ctx();
-        if (!plan || plan_graph != (const void *)graph.get_handle() || plan_weights != (const void *)weights.get_ptr()) {
+        if (!plan || plan_graph != (const void *)graph.get_handle() || plan_weights != (const void *)weights.get_ptr() || plan_version != weights.version()) {
             if (plan) vgl_hip_sssp_pull_plan_destroy(c, plan);
             plan = nullptr;
             Timer tp;
@@ -114,7 +117,7 @@ struct ShortestPaths {
             VGL_HIP_CALL(vgl_hip_sssp_pull_plan_create(c, graph.get_handle(), weights.get_ptr(), &plan));
             tp.end();
             tp.print_time_stats("SSSP pull plan (blocked adjacency + weights, once per weights)");
-            plan_graph = graph.get_handle(); plan_weights = weights.get_ptr();
+            plan_graph = graph.get_handle(); plan_weights = weights.get_ptr(); plan_version = weights.version();
         }
         Timer tm;
         tm.start();
@@ -134,8 +137,10 @@ struct ShortestPaths {
         static vgl_hip_sssp_plan *plan = nullptr;
         static const void *plan_graph = nullptr, *plan_weights = nullptr;
         static float plan_delta = 0.0f;
+        static unsigned long long plan_version = 0;
         vgl_hip_ctx *c = VGL_RUNTIME::ctx();
-        if (!plan || plan_graph != (const void *)graph.get_handle() || plan_weights != (const void *)weights.get_ptr() || plan_delta != delta) {
+        if (!plan || plan_graph != (const void *)graph.get_handle() || plan_weights != (const void *)weights.get_ptr() || plan_delta != delta ||
+            plan_version != weights.version()) {
             if (plan) vgl_hip_sssp_plan_destroy(c, plan);
             plan = nullptr;
             Timer tp;
@@ -143,7 +148,7 @@ struct ShortestPaths {
             VGL_HIP_CALL(vgl_hip_sssp_plan_create(c, graph.get_handle(), weights.get_ptr(), delta, &plan));
             tp.end();
             tp.print_time_stats("SSSP plan (light / heavy split, once per weights)");
-            plan_graph = graph.get_handle(); plan_weights = weights.get_ptr(); plan_delta = delta;
+            plan_graph = graph.get_handle(); plan_weights = weights.get_ptr(); plan_delta = delta; plan_version = weights.version();
         }
         Timer tm;
         tm.start();

@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from oracle import oracle as O
 from vectorgraphlibrary_amd import api
+from vectorgraphlibrary_amd import sharded as vs
 ctx = api.Context(0)
 def relerr(a,b): return float(np.max(np.abs(a-b)/np.maximum(np.abs(b),1e-300)))
 t0=time.time(); bad=0
@@ -17,6 +18,16 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     w_in = (rng.random(E) * 100).astype(np.float32); w = w_in[perm] if E else np.zeros(0, np.float32)
     dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device) if len(a) else torch.zeros(0, dtype=dt, device=ctx.device)
     ren = [None, "total", "out"][seed % 3]
+    # round 3: layout switches of the blocked advance (fused tiles down to tiny block pairs, pieces of a third of the edges, tiny fused
+    # pieces), the blocked Shiloach-Vishkin hook, giant-hub workgroups of the ordered PageRank -- all read when a plan / schedule is built
+    env = {}
+    if seed % 3 == 1: env["VGL_BLK_FUSE_MIN"] = "64"
+    if seed % 3 == 2: env["VGL_BLK_FUSE_MIN"] = "3000"
+    if seed % 5 == 0: env["VGL_BLK_PIECE_EDGES"] = str(max(4096, E // 3))
+    if seed % 2 == 0: env["VGL_CC_BLOCKED"] = "1"
+    if seed % 4 == 3: env["VGL_PULL_GIANT_DEGREE"] = "600"
+    if seed % 7 == 0: env["VGL_BLK_FUSED_UNIT"] = "64"
+    os.environ.update(env)
     g = api.Graph.from_coo(ctx, V, dev(src, torch.int32), dev(dst, torch.int32), want_perm=True, renumber=ren)
     w_d = ctx.gather_u32(g.perm, dev(w_in, torch.float32)) if E else torch.zeros(1, dtype=torch.float32, device=ctx.device)
     source = int(rng.integers(0, V))
@@ -38,6 +49,12 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             d,_ = api.sssp(g, w_d, source, mode, delta=float(rng.choice([0.5, 7.0, 16.0, 40.0])))
             assert (d.cpu().numpy().view(np.int32) == ref_dist.view(np.int32)).all(), f"sssp {mode}"
         assert (api.sswp(g, w_d, source)[0].cpu().numpy().view(np.int32) == O.sswp_bellman_ford(rowptr, adj, w, source)[0].view(np.int32)).all(), "sswp"
+        wd_pull = api.sswp(g, w_d, source, api.SSSP_DIRECTION_OPT)[0]
+        assert (wd_pull.cpu().numpy().view(np.int32) == O.sswp_bellman_ford(rowptr, adj, w, source)[0].view(np.int32)).all(), "sswp do"
+        # the C++ super-step loops in a world of one (same code path as the sharded runs, no exchange)
+        for mode in (api.BFS_TOP_DOWN, api.BFS_DIRECTION_OPT):
+            assert (g.to_original(vs.bfs_run_sharded(g, None, g.vertex_id(source), mode, global_edges=E)[0]).cpu().numpy() == ref_levels).all(), f"sharded-loop bfs {mode}"
+        assert (g.to_original(vs.sssp_run_sharded(g, None, w_d, g.vertex_id(source))[0]).cpu().numpy().view(np.int32) == ref_dist.view(np.int32)).all(), "sharded-loop sssp"
         pr = api.page_rank(g, 3)[0].cpu().numpy(); prr = O.pagerank(rowptr, adj, 3, 1)
         if ren is None: assert (pr.view(np.int32) == prr.view(np.int32)).all(), "pr bits"
         else: assert relerr(pr.astype(np.float64), prr.astype(np.float64)) < 1e-5, "pr"
@@ -52,5 +69,6 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     except AssertionError as ex:
         bad += 1; print("FAIL seed", seed, "V", V, "E", E, "ren", ren, ex, flush=True)
     g.close()
+    for k in env: os.environ.pop(k, None)
     if seed % 20 == 0: print("seed", seed, "elapsed", round(time.time()-t0,1), flush=True)
 print("done, failures:", bad)

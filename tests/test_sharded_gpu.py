@@ -179,3 +179,69 @@ def test_operator_api_apps_with_exchange_vertices_array(ctx, world):
             assert out.count("error count: 0") == 2 and "AVG_PERF" in out, out[-2000:]
         for out in _run_app_ranks("pr_hip", ["-s", "12", "-e", "16", "-it", "1", "-check", "-format", fmt], world):
             assert "error count: 0" in out and "AVG_PERF" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("world,sparse_cap", [(8, "4096"), (8, "0"), (5, "16")])
+def test_sharded_bfs_eight_rank_threads_one_gpu(ctx, world, sparse_cap):
+    """the sharded BFS / SSSP / CC loops with EIGHT (and five: unequal, non-power-of-two ranges) ranks as threads of this process, each with its
+    own context and stream, over the hosted transport: all-to-all + all-gather with eight parts, id lists from eight ranks, eight pair lists;
+    levels / distances / labels bit-identical to the single-GPU results on every rank."""
+    import threading
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import sharded as vs
+    scale, ef, seed = 15, 16, 21
+    V, E = 1 << scale, (1 << scale) * ef
+    src, dst = ctx.gen_rmat(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True, renumber="total")
+    w = ctx.gather_u32(g.perm, ctx.gen_weights(E, seed))
+    deg = g.out_rowptr[1:] - g.out_rowptr[:-1]
+    sources = [int(torch.argmax(deg)), int(torch.nonzero(deg == 1)[0])]
+    ref_levels = [api.bfs(g, s, api.BFS_TOP_DOWN, raw=True)[0] for s in sources]
+    ref_dist = api.sssp(g, w, sources[0], api.SSSP_ALL_ACTIVE, raw=True)[0]
+    ref_comp = api.connected_components(g, raw=True)[0]
+    bounds = [p * (V // world) for p in range(world + 1)] if world == 8 else ctx.partition_rows(g.out_rowptr, world)
+    assert all(b % 64 == 0 for b in bounds[:-1])
+    pieces = []
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        sh = g.shard(lo, hi)
+        e_lo, e_hi = g.out_edge_range(lo, hi)
+        pieces.append((sh.out_rowptr, sh.out_adj, sh.in_rowptr, sh.in_adj, lo, hi, w[e_lo:e_hi].clone()))
+        sh.close()
+    ctx.sync()
+    name = "/vgl_thr_%s" % uuid.uuid4().hex[:12]
+    errors = []
+    os.environ["VGL_SHARD_SPARSE_CAP"] = sparse_cap
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=0)):
+                c = api.Context(0)
+                orp, oadj, irp, iadj, lo, hi, ws = pieces[r]
+                sh = api.Graph(c, V, orp, oadj, irp, iadj, lo, hi)
+                comm = vs.Comm.hosted(c, r, world, name, slot_bytes=1 << 16)
+                for s, ref in zip(sources, ref_levels):
+                    for mode in (api.BFS_DIRECTION_OPT, api.BFS_TOP_DOWN):
+                        lv, _ = vs.bfs_run_sharded(sh, comm, s, mode, global_edges=E, gather_levels=True)
+                        assert torch.equal(lv, ref), (r, s, mode)
+                d, _ = vs.sssp_run_sharded(sh, comm, ws, sources[0])
+                assert torch.equal(d.view(torch.int32), ref_dist.view(torch.int32)), r
+                comp, _ = vs.cc_run_sharded(sh, comm)
+                assert torch.equal(comp, ref_comp), r
+                comm.barrier()
+                comm.close()
+                sh.close()
+                c.close()
+        except Exception as e:                         # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        os.environ.pop("VGL_SHARD_SPARSE_CAP", None)
+    assert not errors, errors
+    g.close()

@@ -796,10 +796,12 @@ public:
 template <typename _T>
 class EdgesArray {                     // layout [outgoing E ; incoming E] (csr_edges_array.hpp:67-73)
     _T *edges_data = nullptr; long long edges_count = 0; bool is_copy = false; VGL_Graph *graph_ptr = nullptr;
+    unsigned long long version_ = 0;       // bumped by every host-side writer: caches built from the values (SSSP plans) key on it
 public:
+    unsigned long long version() const { return version_; }
     EdgesArray(VGL_Graph &g) : edges_count(g.get_edges_count()), graph_ptr(&g)
     { MemoryAPI::allocate_device_array(&edges_data, (size_t)(2 * edges_count)); }
-    __host__ __device__ EdgesArray(const EdgesArray &o) : edges_data(o.edges_data), edges_count(o.edges_count), is_copy(true), graph_ptr(o.graph_ptr) {}
+    __host__ __device__ EdgesArray(const EdgesArray &o) : edges_data(o.edges_data), edges_count(o.edges_count), is_copy(true), graph_ptr(o.graph_ptr), version_(o.version_) {}
     __host__ __device__ ~EdgesArray()
     {
 #ifndef __HIP_DEVICE_COMPILE__
@@ -822,12 +824,14 @@ public:
         VGL_HIP_CALL(vgl_hip_gather_u32(c, edges_count, graph_ptr->get_incoming_edges_reorder_indexes(), edges_data, edges_data + edges_count));
         VGL_RUNTIME::sync();
         MemoryAPI::free_device_array(w_in);
+        version_++;
     }
     void set_all_constant(_T v)            // both halves (csr_edges_array.hpp)
     {
         hipLaunchKernelGGL(vgl_k_fill_values<_T>, dim3(1024), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), 2 * edges_count, v, edges_data);
         VGL_HIP_RT(hipGetLastError());
         VGL_RUNTIME::sync();
+        version_++;
     }
     void finalize_advance() {}             // NEC-only merge of per-core copies (tc.hpp:77-78): nothing to do here
     template <class Merge> void finalize_advance(Merge &&) {}
