@@ -488,9 +488,10 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
     if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
     // chunk positions are 32-bit: a direction is laid out whole below 2^32 - 2048 edges (VGL_BLK_PIECE_EDGES lowers the bound: tests)
     int64_t limit = (1LL << 32) - VGL_TILE;
-    if (const char *e = getenv("VGL_BLK_PIECE_EDGES")) limit = std::max<int64_t>(4096, atoll(e));
+    const bool cuttable = value_bits == 32 && a_bits == VGL_BLK_BITS;            // (the variable only lowers the bound of layouts that can be cut)
+    if (const char *e = getenv("VGL_BLK_PIECE_EDGES")) if (cuttable) limit = std::max<int64_t>(4096, atoll(e));
     if (dir.edges < limit) return vgl_blocked_plan_build_one(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, 0, nrows);
-    if (value_bits != 32 || a_bits != VGL_BLK_BITS) VGL_FAIL("blocked_plan_build: only 4-byte min / max-type layouts can be cut into row-range pieces (2^32 edges or more)");
+    if (!cuttable) VGL_FAIL("blocked_plan_build: only 4-byte min / max-type layouts can be cut into row-range pieces (2^32 edges or more)");
     // row ranges of at most `piece` edges each (a single row above the bound cannot be cut)
     const int64_t piece = std::min<int64_t>(limit, 1LL << 31);
     const int parts = (int)std::min<int64_t>(4096, vgl_ceil_div(dir.edges, piece) + 1);

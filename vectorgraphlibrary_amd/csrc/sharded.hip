@@ -39,7 +39,7 @@ template <bool WIDEST>
 static int vgl_path_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g, const float *d_w, int32_t source, float *d_val,
                                 vgl_hip_sssp_stats *stats, const char *who)
 {
-    if (!c || !g || !d_w || !d_val) return vgl_set_error(__FILE__, __LINE__, (std::string(who) + ": null argument").c_str());
+    if (!c || !g || !d_val || (!d_w && g->out.edges > 0)) return vgl_set_error(__FILE__, __LINE__, (std::string(who) + ": null argument").c_str());     // (a shard may own no edges)
     if (source < 0 || source >= g->V) return vgl_set_error(__FILE__, __LINE__, (std::string(who) + ": source vertex out of range").c_str());
     vgl_solo_comm solo;
     VGL_TRY(solo.init(c, given));
