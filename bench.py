@@ -552,18 +552,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = env_world is not None                      # under torch.distributed.run (also with one rank: the driver's N = 1 .. 8 form)
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = api.Context(local_rank if world > 1 else 0)
+    ctx = api.Context(local_rank if launched else 0)
     # the library's own RCCL communicator: torch.distributed only carries rank 0's 128-byte id to the other ranks (and the barriers /
     # max-over-ranks of the timing contract); every data-path collective is issued by libvgl_hip.so on the context's stream
     comm = None
-    if world > 1:
-        comm = vs.Comm.from_torch_group(ctx)
-    elif args.force_sharded and os.environ.get("VGL_SHARD_FORCE_COLLECTIVES") == "1":
-        comm = vs.Comm.rccl(ctx, 0, 1, vs.Comm.unique_id())
+    if world > 1 or (args.force_sharded and os.environ.get("VGL_SHARD_FORCE_COLLECTIVES") == "1"):
+        comm = vs.Comm.from_torch_group(ctx) if launched else vs.Comm.rccl(ctx, 0, 1, vs.Comm.unique_id())
 
     scale, ef, seed = args.scale, args.edge_factor, args.seed
     renumber = None if args.renumber == "none" else args.renumber
@@ -884,7 +883,7 @@ def main():
         print(json.dumps(out))
     if comm is not None:
         comm.close()
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

@@ -71,3 +71,21 @@ def test_bench_single_gpu_line_contract(ctx):
     assert v["bfs_do_equals_top_down"] and v["bfs_equals_cpu_oracle"] and v["sssp_equals_cpu_oracle"]
     td = line["bfs_top_down_reference_algorithm"]
     assert td["ms"] > 0 and td["blocked_levels"]["ms"] > 0
+
+
+def test_bench_sharded_legs_through_the_library_rccl_communicator(ctx):
+    """bench.py's N > 1 form as the driver launches it (torch.distributed.run, 127.0.0.1) with ONE rank and VGL_SHARD_FORCE_COLLECTIVES=1: the
+    library's RCCL communicator is created from the id rank 0 broadcasts through the torch group, and every collective of the BFS, PageRank
+    and Shiloach-Vishkin legs is issued by libvgl_hip.so (vgl_hip_*_run_sharded) on the context's stream"""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", VGL_SHARD_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29741",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--scale", "15", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sssp",
+           "--pr-scale", "16", "--cc-scale", "15", "--chunk-edges", str(1 << 18)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads([x for x in out.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert line["value"] > 0 and line["verified_sharded_levels_consistent_over_owned_edges"] is True
+    assert line["bfs"]["exchange_last_traversal"]["collectives"] > 0                       # the RCCL path really ran
+    assert line["pagerank_uniform16_sharded"]["collectives"] > 0 and abs(line["pagerank_uniform16_sharded"]["ranks_sum"] - 1.0) < 1e-3
+    assert line["cc_rmat_symmetrised_sharded"]["labels_idempotent"] and line["cc_rmat_symmetrised_sharded"]["exchange"]["collectives"] > 0
