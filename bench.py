@@ -404,6 +404,17 @@ def leg_operator_api(scale, ef, extra):
         if row.get("operator_api_mteps") and row.get("fused_mteps"):
             row["operator_api_over_fused"] = round(row["operator_api_mteps"] / row["fused_mteps"], 3)
         out[name] = row
+    # ... and the reference's OWN algorithms/bfs/bfs.hpp, unchanged, on the operator class (oracle/_ref/dropin_hip: built where /root/reference
+    # exists from oracle/dropin_driver.cpp; the prebuilt binary travels)
+    exe = os.path.join(root, "oracle", "_ref", "dropin_hip")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe, "bfs", "rmat", str(scale), str(ef), "1", "-8", "vcsr", os.devnull], capture_output=True, text=True, timeout=600)
+            m = re.search(r"DROPIN bfs ([0-9.eE+-]+) MTEPS", r.stdout)
+            out["reference_bfs_hpp_unchanged"] = {"command": f"dropin_hip bfs rmat {scale} {ef} 1 -8 vcsr", "mteps": float(m.group(1)) if (m and r.returncode == 0) else None,
+                                                  "note": "BFS::vgl_top_down of /root/reference/algorithms/bfs/bfs.hpp compiled unchanged against hip/vgl_hip.hpp, 8 sources"}
+        except subprocess.TimeoutExpired:
+            out["reference_bfs_hpp_unchanged"] = {"mteps": None}
     extra["operator_api"] = out
 
 

@@ -48,7 +48,13 @@ int main(int argc, char **argv)
         graph.import(ec);
         if (algo == "bfs") {
             VerticesArray<int> levels(graph, SCATTER);
-            const double perf = BFS::vgl_top_down(graph, levels, graph.reorder(arg, ORIGINAL, SCATTER));       // the reference's function
+            // arg >= 0: that ORIGINAL vertex; arg < 0: -arg rounds from deterministic random non-isolated sources (bench.py's operator_api leg)
+            double perf = 0;
+            const int rounds = arg < 0 ? -arg : 1;
+            for (int i = 0; i < rounds; i++) {
+                const int source = arg < 0 ? graph.select_random_nz_vertex(ORIGINAL, i) : arg;
+                perf += BFS::vgl_top_down(graph, levels, graph.reorder(source, ORIGINAL, SCATTER)) / rounds;       // the reference's function
+            }
             levels.reorder(ORIGINAL);
             dump(argv[8], levels.to_host());
             std::cout << "DROPIN bfs " << perf << " MTEPS" << std::endl;
