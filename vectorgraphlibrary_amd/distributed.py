@@ -1,12 +1,20 @@
-"""Edge-cut multi-GPU super-step drivers: one process per GPU, vertex arrays replicated, every rank owns the
-out-edges (and in-edges) of a contiguous vertex range with ~E/P edges (VectorCSRGraph::get_mpi_thresholds,
-vect_csr/get_api.hpp:66-94), one exchange per super-step (common/mpi_exchange.hpp:110-150,222-271 in the reference,
-an RCCL collective over xGMI here; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
+"""Streaming shard builder + the earlier Python protocol model of the edge-cut multi-GPU path.
 
-The per-shard compute is delegated to an `ops` object.  `HipShardOps` (the product) calls libvgl_hip.so;
-tests/ inject a numpy double to exercise the exchange protocol with gloo on CPU (no GPU code runs there).
+PRODUCT PATH (round 3): the communicator, every collective and the super-step loops live in libvgl_hip.so -- include/vgl_hip.h
+"multi-GPU behind the boundary", csrc/{comm,exchange,sharded,bfs_sharded}.hip -- and are reached through vectorgraphlibrary_amd/sharded.py
+(ctypes) or GraphAbstractionsHIP::exchange_vertices_array (C++); bench.py --gpus N runs those.
 
-Exchange payloads:
+What stays here:
+  * build_generated_shard: a rank's edge-cut shard of a synthetic graph too large to materialise on one GPU, built by streaming the
+    counter-based generator (no build-time communication); used by bench.py and the tests for every sharded run.
+  * the super-step drivers written against torch.distributed (bfs_sharded, ChangedExchange, sssp / sswp / cc / page_rank_sharded) with
+    a pluggable `ops` object: the PROTOCOL MODEL the C++ loops were written from.  tests/test_distributed_cpu.py exercises it with gloo,
+    world size 2, and a numpy double for the kernels (no GPU code runs there); tests/test_distributed_gpu.py runs it once through a
+    one-rank RCCL group.  One process per GPU, vertex arrays replicated, every rank owns the out-edges (and in-edges) of a contiguous
+    vertex range with ~E/P edges (VectorCSRGraph::get_mpi_thresholds, vect_csr/get_api.hpp:66-94), one exchange per super-step
+    (common/mpi_exchange.hpp:110-150,222-271 in the reference).
+
+Exchange payloads of the model:
   BFS  : bitmap of the vertices discovered in this super-step (V/8 bytes per rank, all-gather + OR) instead of the
          reference's whole-array exchange
   SSSP : the (index, value) pairs of the distances each rank's step lowered, all-gathered and merged with min
