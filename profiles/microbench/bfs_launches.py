@@ -20,5 +20,12 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 spans = [(a, b) for a, b in zip(inits[:-1], inits[1:]) if any("bu_probe" in r[2] for r in rows[a:b])]
 for a, b in spans[-n:]:
     t0 = rows[a][0]
-    print("traversal: " + "  ".join(f"{next((v for k, v in short.items() if k in name), name.replace('void ', '').replace('vgl_k_', '')[:14])} {(e - s) / 1e3:.1f}"
-                                     for s, e, name in rows[a:b]) + f"   | span {(rows[b - 1][1] - t0) / 1e3:.1f} us")
+    parts, prev_end, busy = [], None, 0
+    for s, e, name in rows[a:b]:
+        label = next((v for k, v in short.items() if k in name), name.replace('void ', '').replace('vgl_k_', '')[:14])
+        gap = "" if prev_end is None else f"(+{(s - prev_end) / 1e3:.1f})"          # idle time of the stream before this launch
+        parts.append(f"{label} {(e - s) / 1e3:.1f}{gap}")
+        busy += e - s
+        prev_end = e
+    span = rows[b - 1][1] - t0
+    print("traversal: " + "  ".join(parts) + f"   | span {span / 1e3:.1f} us, kernels {busy / 1e3:.1f} us, idle {(span - busy) / 1e3:.1f} us")
