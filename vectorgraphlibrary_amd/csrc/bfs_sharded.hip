@@ -11,6 +11,7 @@
 //              all-gather of the owned slices (V/8 bytes in total)
 //   top-down   owned frontier rows expand into a candidate bitmap (any vertex); all-to-all of the candidate slices, the owner ORs
 //              what it received, masks with its visited words, writes levels; all-gather of the owned slices (2 V/8 bytes per rank)
+//              only while a bottom-up level may follow (before the bottom-up phase of a direction-optimising run): V/8 otherwise
 //   tiny top-down levels (frontier <= 4096): the candidates travel as id lists (16 KiB per rank) instead of bitmaps; the owner resolves
 //              its ids exactly, the others only mark them in their frontier copy -- a superset by already-visited vertices, which no
 //              probe can tell from the exact set (an unvisited vertex has no in-neighbour visited before the current level).
@@ -198,6 +199,11 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
     const int64_t factor = std::max<int64_t>(1, (E / V) / 2);                   // change_state.hpp:104
     int64_t F = 1, M = 0, prevF = 0, visited_total = 0;
     bool bottom_up = false;
+    // Who reads the words of the frontier a rank does not own: only a bottom-up level (its probes test arbitrary in-neighbours); a
+    // top-down level expands owned rows.  So a top-down level hands its next frontier round only while a bottom-up level can still
+    // follow it without notice -- in a direction-optimising run before the bottom-up phase; once that phase is over (and in a pure
+    // top-down run) the V/8-byte all-gather is left out, and a level that turns bottom-up after all fetches the slices first.
+    bool been_bottom_up = false, replicated = true;
     const unsigned nb_own = (unsigned)std::max<int64_t>(1, std::min<int64_t>(VGL_SHARD_NB, vgl_ceil_div(nw, VGL_BLOCK)));
     int64_t h_counts[4 * 64];
     for (int32_t level = 1;; level++) {
@@ -210,6 +216,11 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
         }
         prevF = F;
         bool exchanged_sparse = false;
+        if (bottom_up && !replicated) {
+            if (active) VGL_TRY(vgl_comm_allgatherv_inplace(m, front, word_bb.data()));
+            replicated = true;
+        }
+        been_bottom_up = been_bottom_up || bottom_up;
         if (bottom_up) {
             // owned unvisited rows look for a parent in the replicated frontier; the owned words of front_new = what they found
             int64_t found = 0, probed = 0;
@@ -248,10 +259,13 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
             }
         }
         VGL_HIP_TRY(hipGetLastError());
-        if (!exchanged_sparse) {
+        if (exchanged_sparse) replicated = true;                                // (a superset by vertices of earlier levels, see the header)
+        else {
             // the owned slices of the next frontier and the two counters of every rank, one fused RCCL launch
+            const bool hand_round = direction_opt && (bottom_up || !been_bottom_up);
+            replicated = hand_round || !active;
             vgl_comm_group_begin(m);
-            if (active) VGL_TRY(vgl_comm_allgatherv_inplace(m, front_new, word_bb.data()));
+            if (active && hand_round) VGL_TRY(vgl_comm_allgatherv_inplace(m, front_new, word_bb.data()));
             VGL_TRY(vgl_comm_allgather(m, my_counts, all_counts, sizeof(int64_t) * 4));
             VGL_TRY(vgl_comm_group_end(m));
             VGL_TRY(vgl_comm_read_small(m, all_counts, 4 * P, h_counts));
