@@ -808,19 +808,37 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_advance(int64_t words, uin
 }
 
 // ---- sparse exchange of tiny levels (multi-GPU): ids instead of V-bit bitmaps ----
-// out[0] = number of set bits (may exceed cap), out[1 .. 1+cap) = their ids in no particular order (the first `cap` to arrive)
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bitmap_to_ids(int64_t words, const uint64_t *bits, int32_t cap, int32_t *out)
+// out[0] = number of set bits (may exceed cap), out[1 .. 1+cap) = the ids of the first `cap` positions handed out (id = 64 * (word_base + word) + bit).
+// A workgroup owns a contiguous run of words: it counts its bits, reserves its range of the list with ONE atomic and writes in word
+// order (one atomic per non-empty word on a single counter, the first version, serialises at ~12 ns each: fine for a few thousand ids,
+// half a millisecond for the 10^5 of a late bottom-up level).
+constexpr int VGL_B2I_BLOCKS = 2048;
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bitmap_to_ids(int64_t words, const uint64_t *bits, int64_t word_base, int32_t cap, int32_t *out)
 {
-    const int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x;
-    if (wi >= words) return;
-    uint64_t w = bits[wi];
-    if (!w) return;
-    int pos = atomicAdd(out, (int)__popcll(w));              // one atomic per non-empty word: meant for bitmaps with few bits
-    while (w) {
-        const int b = __ffsll((long long)w) - 1;
-        w &= w - 1;
-        if (pos < cap) out[1 + pos] = (int32_t)((wi << 6) + b);
-        pos++;
+    __shared__ int s32[VGL_WAVES];
+    __shared__ int s_base;
+    const int64_t per = (((words + gridDim.x - 1) / gridDim.x + VGL_BLOCK - 1) / VGL_BLOCK) * VGL_BLOCK;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(words, lo + per);
+    int n = 0;
+    for (int64_t wi = lo + threadIdx.x; wi < hi; wi += VGL_BLOCK) n += (int)__popcll(bits[wi]);
+    int total = 0;
+    vgl_block_excl_add(n, s32, &total);
+    if (total == 0) return;                                     // (the same in every thread of the workgroup)
+    if (threadIdx.x == 0) s_base = atomicAdd(out, total);
+    __syncthreads();
+    int run = s_base;
+    for (int64_t w0 = lo; w0 < hi && run < cap; w0 += VGL_BLOCK) {      // (run is uniform over the workgroup)
+        const int64_t wi = w0 + threadIdx.x;
+        uint64_t w = wi < hi ? bits[wi] : 0ULL;
+        int step = 0;
+        int pos = run + vgl_block_excl_add((int)__popcll(w), s32, &step);
+        while (w) {
+            const int b = __ffsll((long long)w) - 1;
+            w &= w - 1;
+            if (pos < cap) out[1 + pos] = (int32_t)(((word_base + wi) << 6) + b);
+            pos++;
+        }
+        run += step;
     }
 }
 // `parts` lists of that layout (stride 1 + cap): a vertex reported by several ranks is taken once (claimed on the visited bitmap)
@@ -1046,6 +1064,18 @@ static int vgl_bfs_blocked_level(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *leve
         hipLaunchKernelGGL(vgl_k_bfs_blk_accumulate, dim3((unsigned)p->n_a_units), dim3(VGL_BTHREADS), 0, c->stream, (const vgl_blk_unit *)p->a_units,
                            (const uint16_t *)p->a_lo, reinterpret_cast<const uint64_t *>(p->vals), p->a_count, (const uint64_t *)g->bm_visited,
                            g->bm_next, levels, next_level);
+    }
+    VGL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int vgl_bitmap_to_ids(vgl_hip_ctx *c, int64_t words, const uint64_t *d_bits, int64_t word_base, int32_t cap, int32_t *d_out)
+{
+    VGL_HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(int32_t), c->stream));
+    if (words > 0) {
+        vgl_timed_launch tl(c, "bfs_shard_resolve");             // (only the sharded traversal uses it: counted with its owner-side passes)
+        hipLaunchKernelGGL(vgl_k_bitmap_to_ids, dim3((unsigned)std::min<int64_t>(VGL_B2I_BLOCKS, vgl_ceil_div(words, VGL_BLOCK))), dim3(VGL_BLOCK), 0, c->stream,
+                           words, d_bits, word_base, cap, d_out);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;
@@ -1346,11 +1376,7 @@ int vgl_hip_bitmap_to_ids(vgl_hip_ctx *c, int64_t words, const uint64_t *d_bits,
 {
     if (!c || !d_bits || !d_out) VGL_FAIL("bitmap_to_ids: null argument");
     if (words < 0 || cap < 1) VGL_FAIL("bitmap_to_ids: bad size");
-    VGL_HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(int32_t), c->stream));
-    if (words > 0)
-        hipLaunchKernelGGL(vgl_k_bitmap_to_ids, dim3((unsigned)vgl_ceil_div(words, VGL_BLOCK)), dim3(VGL_BLOCK), 0, c->stream, words, d_bits, cap, d_out);
-    VGL_HIP_TRY(hipGetLastError());
-    return 0;
+    return vgl_bitmap_to_ids(c, words, d_bits, 0, cap, d_out);
 }
 
 int vgl_hip_bfs_apply_ids(vgl_hip_ctx *c, int32_t V, int parts, int32_t cap, const int32_t *d_lists, int32_t *d_levels, int32_t level,

@@ -12,7 +12,9 @@
 //   top-down   owned frontier rows expand into a candidate bitmap (any vertex); all-to-all of the candidate slices, the owner ORs
 //              what it received, masks with its visited words, writes levels; all-gather of the owned slices (2 V/8 bytes per rank)
 //              only while a bottom-up level may follow (before the bottom-up phase of a direction-optimising run): V/8 otherwise
-//   tiny top-down levels (frontier <= 4096): the candidates travel as id lists (16 KiB per rank) instead of bitmaps; the owner resolves
+//   bottom-up levels with little left to find: the found vertices travel as id lists, every rank marks them in its copy
+//   small top-down levels (out-degree sum of the frontier <= half the lists' capacity; capacity per rank max(4096, V / 128 P) ids):
+//              the candidates travel as id lists instead of bitmaps; the owner resolves
 //              its ids exactly, the others only mark them in their frontier copy -- a superset by already-visited vertices, which no
 //              probe can tell from the exact set (an unvisited vertex has no in-neighbour visited before the current level).
 #include "vgl_comm.h"
@@ -80,22 +82,22 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_shard_apply_ids(int parts, in
     bool overflow = false;
     for (int p = 0; p < parts; p++) overflow |= lists[(int64_t)p * (1 + cap)] > cap;      // the same answer in every workgroup
     int64_t cnt = 0, deg = 0;
-    const int64_t total = overflow ? 0 : (int64_t)parts * cap;
-    for (int64_t t = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * VGL_BLOCK) {
-        const int p = (int)(t / cap), i = (int)(t % cap);
+    for (int p = 0; p < (overflow ? 0 : parts); p++) {
         const int32_t *list = lists + (int64_t)p * (1 + cap);
-        if (i >= list[0]) continue;
-        const int32_t v = list[1 + i];
-        if (v < 0 || v >= V) continue;
-        const unsigned long long bit = 1ULL << (v & 63);
-        if (v >= row_begin && v < row_end) {
-            const unsigned long long old = atomicOr((unsigned long long *)&visited[v >> 6], bit);
-            if (old & bit) continue;
-            levels[v] = level;
-            cnt++;
-            deg += rowptr[v - row_begin + 1] - rowptr[v - row_begin];
+        const int32_t n = list[0];
+        for (int32_t i = (int32_t)(blockIdx.x * VGL_BLOCK + threadIdx.x); i < n; i += (int32_t)(gridDim.x * VGL_BLOCK)) {
+            const int32_t v = list[1 + i];
+            if (v < 0 || v >= V) continue;
+            const unsigned long long bit = 1ULL << (v & 63);
+            if (v >= row_begin && v < row_end) {
+                const unsigned long long old = atomicOr((unsigned long long *)&visited[v >> 6], bit);
+                if (old & bit) continue;
+                levels[v] = level;
+                cnt++;
+                deg += rowptr[v - row_begin + 1] - rowptr[v - row_begin];
+            }
+            atomicOr((unsigned long long *)&front_new[v >> 6], bit);
         }
-        atomicOr((unsigned long long *)&front_new[v >> 6], bit);
     }
     cnt = vgl_block_reduce_add(cnt, s64);
     deg = vgl_block_reduce_add(deg, s64);
@@ -107,6 +109,32 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_shard_apply_ids(int parts, in
     a = vgl_block_reduce_add(a, s64);
     b = vgl_block_reduce_add(b, s64);
     if (threadIdx.x == 0) { counts_out[0] = a; counts_out[1] = b; counts_out[2] = overflow ? 1 : 0; counts_out[3] = 0; }
+}
+
+// Bottom-up levels that find little: the owners have resolved their rows already (probe + vgl_k_shard_resolve<false>); the found
+// vertices travel as id lists and every rank marks the OTHER ranks' ids in its copy of the next frontier (its own words are in place).
+// counts_all[4 p] = rank p's number of found vertices, [4 p + 2] = 1 when any list overflowed (then nothing is marked and the
+// caller falls back to the bitmap exchange; the same answer on every rank).
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_shard_mark_ids(int parts, int self, int32_t cap, const int32_t *lists, int32_t V, uint64_t *front_new,
+                                                                  int64_t *counts_all)
+{
+    bool overflow = false;
+    for (int p = 0; p < parts; p++) overflow |= lists[(int64_t)p * (1 + cap)] > cap;
+    if (blockIdx.x == 0)
+        for (int p = threadIdx.x; p < parts; p += VGL_BLOCK) {
+            counts_all[4 * p] = lists[(int64_t)p * (1 + cap)];
+            counts_all[4 * p + 1] = 0; counts_all[4 * p + 2] = overflow ? 1 : 0; counts_all[4 * p + 3] = 0;
+        }
+    if (overflow) return;
+    for (int p = 0; p < parts; p++) {
+        if (p == self) continue;
+        const int32_t *list = lists + (int64_t)p * (1 + cap);
+        const int32_t n = list[0];
+        for (int32_t i = (int32_t)(blockIdx.x * VGL_BLOCK + threadIdx.x); i < n; i += (int32_t)(gridDim.x * VGL_BLOCK)) {
+            const int32_t v = list[1 + i];
+            if (v >= 0 && v < V) atomicOr((unsigned long long *)&front_new[v >> 6], 1ULL << (v & 63));
+        }
+    }
 }
 
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_shard_bfs_init(int64_t words, int32_t source, uint64_t *visited, uint64_t *front, uint64_t *front_new,
@@ -170,9 +198,11 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
         for (int p = 0; p < P; p++) equal = equal && (word_bb[(size_t)p + 1] - word_bb[(size_t)p]) == (int64_t)(words / P) * 8;
         equal = equal && words % P == 0;
     }
-    int32_t sparse_cap = 4096;
+    // capacity of a rank's id list: lists pay while all of them together stay well below the V/8 bytes of a bitmap exchange
+    int32_t sparse_cap = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(4096, (int64_t)V / (128 * (int64_t)P)));
     if (const char *e = getenv("VGL_SHARD_SPARSE_CAP")) sparse_cap = std::max(0, atoi(e));
     if (!active) sparse_cap = 0;
+    const int64_t nz_total = active ? bounds[(size_t)P + 1] : 0;         // rows with incoming edges, all ranks: what a bottom-up level can find at most
 
     // one block of scratch, carved: visited | front A | front B | candidates | tickets | partials | counts (mine, all) | id lists
     const size_t bm = sizeof(uint64_t) * (size_t)(words + 1);
@@ -226,20 +256,38 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
             int64_t found = 0, probed = 0;
             VGL_TRY(vgl_hip_bfs_step_bottom_up(c, g, d_levels, level, visited, front, front_new, stats ? &found : nullptr, stats ? &probed : nullptr));
             st.bu_steps++; st.bu_edges += probed; st.bu_found += found; st.edges_examined += probed;
-            vgl_timed_launch tl(c, "bfs_shard_resolve");
-            hipLaunchKernelGGL(vgl_k_shard_resolve<false>, dim3(nb_own), dim3(VGL_BLOCK), 0, c->stream, w0, nw, 1, (const uint64_t *)front_new, (int64_t)0, w0,
-                               visited, front_new, d_levels, level + 1, g->out.rowptr, g->row_begin, g->row_end, partials, ticket, my_counts);
+            {
+                vgl_timed_launch tl(c, "bfs_shard_resolve");
+                hipLaunchKernelGGL(vgl_k_shard_resolve<false>, dim3(nb_own), dim3(VGL_BLOCK), 0, c->stream, w0, nw, 1, (const uint64_t *)front_new, (int64_t)0, w0,
+                                   visited, front_new, d_levels, level + 1, g->out.rowptr, g->row_begin, g->row_end, partials, ticket, my_counts);
+            }
+            // late bottom-up levels find little (RMAT-27: 4e7, 6e5, 2e3 vertices on the three levels): when at most 4 lists' worth of
+            // rows with incoming edges is still unvisited the found vertices travel as ids; an overflow falls back to the bitmaps
+            if (sparse_cap > 0 && nz_total > 0 && nz_total - visited_total <= 4 * (int64_t)sparse_cap * P) {
+                VGL_TRY(vgl_bitmap_to_ids(c, nw, front_new + w0, w0, sparse_cap, my_list));
+                VGL_TRY(vgl_comm_allgather(m, my_list, all_lists, sizeof(int32_t) * (size_t)(1 + sparse_cap)));
+                {
+                    vgl_timed_launch tl(c, "bfs_shard_resolve");
+                    hipLaunchKernelGGL(vgl_k_shard_mark_ids, dim3(128), dim3(VGL_BLOCK), 0, c->stream, P, rank, sparse_cap, (const int32_t *)all_lists, V, front_new,
+                                       all_counts);
+                }
+                VGL_HIP_TRY(hipGetLastError());
+                VGL_TRY(vgl_comm_read_small(m, all_counts, 4 * P, h_counts));
+                if (h_counts[2] == 0) { exchanged_sparse = true; m->stats.sparse_levels++; }
+            }
         } else {
             int64_t Fl = 0, Ml = 0;
             VGL_TRY(vgl_hip_bfs_step_top_down_bits(c, g, d_levels, level, visited, front, cand, &Fl, &Ml));
             st.td_steps++; st.td_frontier += Fl; st.td_edges += Ml; st.edges_examined += Ml;
-            if (sparse_cap > 0 && F <= sparse_cap) {
+            // id lists when the level cannot produce many candidates: M (the out-degree sum of the frontier, known after a top-down
+            // level) bounds them; after a bottom-up level and for the source only the frontier size is known
+            if (sparse_cap > 0 && (M > 0 ? M <= (int64_t)sparse_cap * P / 2 : F <= sparse_cap)) {
                 VGL_TRY(vgl_hip_bitmap_to_ids(c, words, cand, sparse_cap, my_list));
                 VGL_TRY(vgl_comm_allgather(m, my_list, all_lists, sizeof(int32_t) * (size_t)(1 + sparse_cap)));
                 VGL_HIP_TRY(hipMemsetAsync(front_new, 0, sizeof(uint64_t) * (size_t)words, c->stream));
                 {
                 vgl_timed_launch tl(c, "bfs_shard_resolve");
-                hipLaunchKernelGGL(vgl_k_shard_apply_ids, dim3(64), dim3(VGL_BLOCK), 0, c->stream, P, sparse_cap, (const int32_t *)all_lists, V, g->row_begin,
+                hipLaunchKernelGGL(vgl_k_shard_apply_ids, dim3(128), dim3(VGL_BLOCK), 0, c->stream, P, sparse_cap, (const int32_t *)all_lists, V, g->row_begin,
                                    g->row_end, visited, front_new, d_levels, level + 1, g->out.rowptr, partials, ticket, my_counts);
                 }
                 VGL_TRY(vgl_comm_allgather(m, my_counts, all_counts, sizeof(int64_t) * 4));

@@ -332,20 +332,21 @@ int vgl_comm_row_bounds(vgl_hip_comm *m, const vgl_hip_graph *g, const int64_t *
     auto it = m->bounds.find(g->uid);
     if (it == m->bounds.end()) {
         const int P = m->world;
-        std::vector<int64_t> mine = {g->row_begin, g->row_end}, all((size_t)2 * P);
-        int64_t *d_mine = m->d_small, *d_all = m->d_small + 2;
-        if (2 + 2 * P > VGL_COMM_SMALL) VGL_FAIL("comm row_bounds: too many ranks");
-        VGL_HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), sizeof(int64_t) * 2, hipMemcpyHostToDevice, m->ctx->stream));
+        std::vector<int64_t> mine = {g->row_begin, g->row_end, g->in.rowptr ? (int64_t)g->in_nz_rows : 0}, all((size_t)3 * P);
+        int64_t *d_mine = m->d_small, *d_all = m->d_small + 3;
+        if (3 + 3 * P > VGL_COMM_SMALL) VGL_FAIL("comm row_bounds: too many ranks");
+        VGL_HIP_TRY(hipMemcpyAsync(d_mine, mine.data(), sizeof(int64_t) * 3, hipMemcpyHostToDevice, m->ctx->stream));
         VGL_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
-        VGL_TRY(vgl_comm_allgather(m, d_mine, d_all, sizeof(int64_t) * 2));
-        VGL_TRY(vgl_comm_read_small(m, d_all, 2 * P, all.data()));
-        std::vector<int64_t> b((size_t)P + 1);
+        VGL_TRY(vgl_comm_allgather(m, d_mine, d_all, sizeof(int64_t) * 3));
+        VGL_TRY(vgl_comm_read_small(m, d_all, 3 * P, all.data()));
+        std::vector<int64_t> b((size_t)P + 2, 0);
         for (int p = 0; p < P; p++) {
-            if (all[(size_t)2 * p + 1] < all[(size_t)2 * p]) VGL_FAIL("sharded run: a rank reports an empty-inverted row range");
-            if (p > 0 && all[(size_t)2 * p] != all[(size_t)2 * p - 1]) VGL_FAIL("sharded run: the ranks' row ranges must tile [0, V) in rank order");
-            b[(size_t)p] = all[(size_t)2 * p];
+            if (all[(size_t)3 * p + 1] < all[(size_t)3 * p]) VGL_FAIL("sharded run: a rank reports an empty-inverted row range");
+            if (p > 0 && all[(size_t)3 * p] != all[(size_t)3 * p - 2]) VGL_FAIL("sharded run: the ranks' row ranges must tile [0, V) in rank order");
+            b[(size_t)p] = all[(size_t)3 * p];
+            b[(size_t)P + 1] += all[(size_t)3 * p + 2];                  // rows with incoming edges over all ranks (0: no incoming lists loaded)
         }
-        b[(size_t)P] = all[(size_t)2 * P - 1];
+        b[(size_t)P] = all[(size_t)3 * P - 2];
         if (b[0] != 0 || b[(size_t)P] != g->V) VGL_FAIL("sharded run: the ranks' row ranges must tile [0, V) in rank order");
         if (m->bounds.size() > 64) m->bounds.clear();
         it = m->bounds.emplace(g->uid, std::move(b)).first;

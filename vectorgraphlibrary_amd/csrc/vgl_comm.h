@@ -52,7 +52,8 @@ int vgl_comm_group_end(vgl_hip_comm *m);
 int vgl_comm_read_small(vgl_hip_comm *m, const int64_t *d_vals, int n, int64_t *h_out);
 // all-reduce of a few HOST values (setup paths; synchronises)
 int vgl_comm_allreduce_host_i64(vgl_hip_comm *m, int64_t *vals, int n, int op);
-// [row_begin, row_end) of every rank for this graph handle: world + 1 bounds when the ranges tile [0, V) in rank order, else an error
+// [row_begin, row_end) of every rank for this graph handle: world + 1 bounds when the ranges tile [0, V) in rank order, else an error;
+// bounds[world + 1] = the number of rows with incoming edges over all ranks (0 when a rank has no incoming lists)
 int vgl_comm_row_bounds(vgl_hip_comm *m, const vgl_hip_graph *g, const int64_t **bounds);
 
 // enqueue-only forms of the owned-row super-steps (no host read; defined next to their kernels)

@@ -148,6 +148,8 @@ int vgl_ensure_partials(vgl_hip_ctx *ctx, size_t n);
 int vgl_build_tile_rows(vgl_hip_ctx *ctx, struct vgl_dir_csr &d, int32_t nrows);
 // frontier from a bitmap over the owned words (bfs.hip): count = sizes to h_counters[C_FRONT / C_NEIGH] (waits), write = ids + edge offsets + tile table
 int vgl_bfs_bm_gnf(vgl_hip_ctx *c, struct vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1, bool advance = false);   // d.tile_row / d.ntiles from d.rowptr / d.edges (owned by the caller)
+// set bits of `words` 64-bit words as ids (64 * (word_base + word) + bit): d_out[0] = their number, d_out[1 .. 1 + cap) = the first cap handed out
+int vgl_bitmap_to_ids(vgl_hip_ctx *c, int64_t words, const uint64_t *d_bits, int64_t word_base, int32_t cap, int32_t *d_out);
 
 static inline int64_t vgl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
