@@ -38,7 +38,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bfs_init_all(int32_t V, int32
         visited[w] = bit; front[w] = bit; next[w] = 0;
     }
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < 3 * VGL_TICKET_WORDS; i += VGL_BLOCK) tickets[i] = 0;
+        for (int i = threadIdx.x; i < 4 * VGL_TICKET_WORDS; i += VGL_BLOCK) tickets[i] = 0;
 }
 
 // tile_first[t] = frontier position whose edge range contains edge t*VGL_TILE
@@ -61,11 +61,14 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_first(int32_t F, const i
 // (levels[dst] == -1 is what keeps the atomics few: asking the next-frontier bitmap instead -- 2 MiB in L2 against a random sector of
 // a 64 MiB array per unvisited edge -- lets every edge that arrives before the bit is visible issue its own atomicOr: 252 us per level
 // instead of 74.)
-template <bool EMIT>
+// COUNT (with EMIT): the vertex's one claimer -- the atomicOr whose return value lacks the bit -- also counts it and adds its out-degree; the
+// last workgroup leaves the sums in counters[C_NEXT_F / C_NEXT_M] for the count launch that follows (vgl_k_bm_gnf_count: when they say
+// "bottom-up next" it does not walk the new frontier's rows at all).
+template <bool EMIT, bool COUNT>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids, const int64_t *offs, const int32_t *tile_first,
                                                              int32_t F, int64_t M, const int64_t *rowptr, const int32_t *adj,
                                                              int32_t row_base, const uint64_t *visited, int32_t *levels,
-                                                             int32_t next_level, uint64_t *next)
+                                                             int32_t next_level, uint64_t *next, int64_t *partials, uint32_t *ticket, int64_t *counters)
 {
     __shared__ int s_map[VGL_TILE];
     __shared__ int64_t s_base[VGL_TILE];
@@ -96,16 +99,60 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
             dsts[j] = adj[base + e0 + i];
         }
     }
+    // Every load below is UNCONDITIONAL (a slot without an edge, or a destination the bitmap already rules out, reads entry 0 instead): a
+    // load under a per-lane condition is compiled as a branch whose result is awaited before the next one is issued -- eight visited
+    // words and eight levels, sixteen dependent round trips per thread, is what the first version of this kernel waited for.  And the
+    // levels are requested BEFORE the first store: a load after a store to the same array may alias it.
+    uint64_t vw[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) vw[j] = visited[max(dsts[j], 0) >> 6];
     bool unvis[VGL_EPT];
 #pragma unroll
-    for (int j = 0; j < VGL_EPT; j++)
-        unvis[j] = dsts[j] >= 0 && !((visited[dsts[j] >> 6] >> (dsts[j] & 63)) & 1ULL);
+    for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0 && !((vw[j] >> (dsts[j] & 63)) & 1ULL);
+    int32_t lv[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) lv[j] = levels[unvis[j] ? dsts[j] : 0];
+    bool fresh[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) fresh[j] = unvis[j] && lv[j] == -1;
+    if (!COUNT) {
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++)
+            if (fresh[j]) {
+                levels[dsts[j]] = next_level;
+                if (EMIT) atomicOr((unsigned long long *)&next[dsts[j] >> 6], 1ULL << (dsts[j] & 63));
+            }
+        return;
+    }
+    // the atomics of a thread's edges are issued together, their return values read afterwards
+    __shared__ int64_t s64[VGL_WAVES];
+    unsigned long long old[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        old[j] = ~0ULL;
+        if (fresh[j]) {
+            levels[dsts[j]] = next_level;
+            old[j] = atomicOr((unsigned long long *)&next[dsts[j] >> 6], 1ULL << (dsts[j] & 63));
+        }
+    }
+    int64_t cnt = 0, deg = 0;
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++)
-        if (unvis[j] && levels[dsts[j]] == -1) {
-            levels[dsts[j]] = next_level;
-            if (EMIT) atomicOr((unsigned long long *)&next[dsts[j] >> 6], 1ULL << (dsts[j] & 63));
+        if (dsts[j] >= 0 && !((old[j] >> (dsts[j] & 63)) & 1ULL)) {
+            const int64_t r = dsts[j] - row_base;
+            cnt++;
+            deg += rowptr[r + 1] - rowptr[r];
         }
+    cnt = vgl_block_reduce_add(cnt, s64);
+    deg = vgl_block_reduce_add(deg, s64);
+    uint32_t dep = 0;
+    if (threadIdx.x == 0) dep = vgl_put_agent(partials + 2 * blockIdx.x, cnt) ^ vgl_put_agent(partials + 2 * blockIdx.x + 1, deg);
+    if (!vgl_last_block(ticket, dep)) return;
+    int64_t a = 0, b = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += VGL_BLOCK) { a += vgl_load_agent(partials + 2 * i); b += vgl_load_agent(partials + 2 * i + 1); }
+    a = vgl_block_reduce_add(a, s64);
+    b = vgl_block_reduce_add(b, s64);
+    if (threadIdx.x == 0) { counters[C_NEXT_F] = a; counters[C_NEXT_M] = b; }
 }
 
 // ---- a large top-down level as a blocked pass (vgl_blocked.h; plan built by vgl_hip_bfs_prepare_blocked) ----
@@ -207,11 +254,27 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
                                                                 const int64_t *rowptr, int32_t *vt_cnt, int64_t *vt_deg,
                                                                 int32_t *vt_cnt_off, int64_t *vt_deg_off, int64_t *offs, int64_t *counters,
                                                                 uint32_t *ticket, volatile int64_t *host, int64_t seq, uint64_t *visited,
-                                                                uint64_t *next)
+                                                                uint64_t *next, int use_hint, vgl_do_hint hint)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
     const int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x;
+    if (ADVANCE && use_hint) {
+        // The launch before this one (an emitting top-down level, or the list kernel) left the size F and the out-degree sum M of the
+        // frontier it produced.  When the direction rule -- the host evaluates the same integers right after this launch -- turns the
+        // level bottom-up, nobody needs the rows' degrees or the compaction offsets: only the bitmaps move on (what vgl_k_bm_advance
+        // does) and the first workgroup hands F and M over at once.
+        const int64_t nf = counters[C_NEXT_F], nm = counters[C_NEXT_M];
+        if (nf > hint.prev_f && nm >= ((hint.V - hint.visited_total - nf) * hint.factor + hint.V) / VGL_DO_ALPHA) {
+            if (wi < nwords) {
+                const uint64_t w = next[word0 + wi];
+                front[word0 + wi] = w;
+                if (w) { visited[word0 + wi] |= w; next[word0 + wi] = 0; }
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) { host[C_SKIPPED] = 1; vgl_publish2(counters, host, seq, C_FRONT, nf, C_NEIGH, nm); }
+            return;
+        }
+    }
     int cnt = 0;
     int64_t deg = 0;
     if (wi < nwords) {
@@ -251,6 +314,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
     }
     if (threadIdx.x == 0) {
         offs[ctot] = dtot;
+        host[C_SKIPPED] = 0;
         vgl_publish2(counters, host, seq, C_FRONT, (int64_t)ctot, C_NEIGH, dtot);
     }
 }
@@ -401,8 +465,9 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(int3
         s_list[0][i] = v;
         if (list_count) atomicOr((unsigned long long *)&visited[v >> 6], 1ULL << (v & 63));
     }
-    int32_t level = level0, run = 0, last_f = 0, handed = 0;
-    int64_t edges = 0, later_front = 0, first_m = 0, exit_m = 0;
+    int32_t level = level0, run = 0, last_f = 0, handed = 0, hinted = 0;
+    int64_t edges = 0, later_front = 0, first_m = 0, exit_m = 0, next_m = 0;
+    __shared__ int64_t s_deg[NW];
     for (;;) {
         if (!usable) break;                                    // (uniform) empty or overflowed list: nothing is done
         __syncthreads();                                       // the list of this level is complete (and everyone has read the old s_cnt)
@@ -467,6 +532,7 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(int3
             for (int i = tid; i < F; i += NT) { const int32_t v = s_list[cur][i]; atomicAnd((unsigned long long *)&front[v >> 6], ~(1ULL << (v & 63))); }
         __syncthreads();                                       // offsets staged; (a discovery below can share a word with a bit cleared above)
         const int m = (int)M;
+        int64_t found_deg = 0;                                 // out-degrees of the vertices this thread claims on this level
         for (int e0 = 0; e0 < m; e0 += NT * U) {               // uniform trip count
             int32_t dst[U];
             unsigned long long word[U], old[U];
@@ -496,6 +562,7 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(int3
                 atomicOr((unsigned long long *)&next[dst[u] >> 6], bit);
                 const int pos = atomicAdd(&s_cnt, 1);
                 if (pos < VGL_SMALL_F) s_list[cur ^ 1][pos] = dst[u];
+                found_deg += rowptr[dst[u] + 1] - rowptr[dst[u]];
             }
         }
         __syncthreads();                                       // every append of this level has happened
@@ -503,12 +570,23 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(int3
         edges += M; run++; last_f = F;
         if (run > 1) later_front += F;
         F = Fn;
-        if (Fn == 0 || Fn > VGL_SMALL_F) break;                // finished, or the next frontier does not fit the list (it is all in `next`)
+        if (Fn > VGL_SMALL_F) {                                // the next frontier does not fit the list (it is all in `next`): leave its
+            found_deg = vgl_wave_incl_add(found_deg);          // size and out-degree sum for the count launch that follows (C_NEXT_F / C_NEXT_M)
+            if (lane == 63) s_deg[wave] = found_deg;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; w++) next_m += s_deg[w];
+            hinted = 1;
+            break;
+        }
+        if (Fn == 0) break;                                    // finished
         cur ^= 1; level++;
     }
     if (tid == 0) {
         counters[C_FRONT] = F; counters[C_TMP0] = run; counters[C_EDGES] = edges; counters[C_TMP1] = later_front; counters[C_JUMP] = last_f;
         counters[C_NEIGH] = first_m; counters[C_BU_FOUND] = n_list; counters[C_CHANGED] = bm_edges;
+        if (hinted) { counters[C_NEXT_F] = F; counters[C_NEXT_M] = next_m; }
+        host[C_HINT] = hinted;
         host[C_FRONT] = F; host[C_TMP0] = run; host[C_EDGES] = edges; host[C_TMP1] = later_front; host[C_JUMP] = last_f; host[C_NEIGH] = first_m;
         host[C_BU_FOUND] = n_list; host[C_CHANGED] = bm_edges; host[C_HEAVY] = handed; host[C_BU_EDGES] = exit_m;
         __threadfence_system();
@@ -958,20 +1036,27 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_apply_fold(int n, const int64
 static inline unsigned vgl_grid(int64_t n, int64_t cap = 8192) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, vgl_ceil_div(n, VGL_BLOCK))); }
 
 // expand frontier (ids/offs with F vertices, M edges already produced by a frontier-generation write pass)
+constexpr int64_t VGL_TD_COUNT_TILES = 8192;           // (the counting level's partial sums live in g->bu_partials: 4 * 4096 slots)
 static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_t M, int32_t *levels, int32_t next_level, bool emit,
-                             bool have_tile_first)
+                             bool have_tile_first, bool count = false)
 {
     if (F <= 0 || M <= 0) return 0;
     if (!have_tile_first) hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, F, g->offs, g->tile_first);
     const int64_t nt = vgl_ceil_div(M, VGL_TILE);
     {
         vgl_timed_launch tl(c, "bfs_top_down");
-        if (emit)
-            hipLaunchKernelGGL(vgl_k_td_expand<true>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next);
+        int64_t *no_i64 = nullptr;
+        uint32_t *no_u32 = nullptr;
+        if (emit && count)
+            hipLaunchKernelGGL((vgl_k_td_expand<true, true>), dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
+                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next, g->bu_partials,
+                               g->tickets + 3 * VGL_TICKET_WORDS, c->d_counters);
+        else if (emit)
+            hipLaunchKernelGGL((vgl_k_td_expand<true, false>), dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
+                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next, no_i64, no_u32, no_i64);
         else
-            hipLaunchKernelGGL(vgl_k_td_expand<false>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next);
+            hipLaunchKernelGGL((vgl_k_td_expand<false, false>), dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
+                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next, no_i64, no_u32, no_i64);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;
@@ -980,8 +1065,9 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
 // frontier of the current level from a frontier bitmap (owned words).  count: per-workgroup counts, their scan and F / M in
 // h_counters[C_FRONT] / [C_NEIGH] (one launch, the host waits for it); write: ids + edge offsets + tile_first (needs the M of
 // the count pass)
-int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known, bool advance)
+int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known, bool advance, const vgl_do_hint *hint)
 {
+    const vgl_do_hint no_hint = {0, 0, 0, 0};
     const int64_t word0 = g->row_begin >> 6;
     const int64_t nwords = vgl_ceil_div(g->row_end, 64) - word0;
     const unsigned nb = (unsigned)vgl_ceil_div(nwords, VGL_BLOCK);
@@ -992,11 +1078,13 @@ int vgl_bfs_bm_gnf(vgl_hip_ctx *c, vgl_hip_graph *g, const uint64_t *front, bool
             if (advance)                 // front == g->bm_front: rebuilt from g->bm_next first (whole-graph handles only)
                 hipLaunchKernelGGL(vgl_k_bm_gnf_count<true>, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin, g->bm_front,
                                    g->out.rowptr, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, g->offs, c->d_counters,
-                                   g->tickets + 0 * VGL_TICKET_WORDS, (volatile int64_t *)c->h_counters, seq, g->bm_visited, g->bm_next);
+                                   g->tickets + 0 * VGL_TICKET_WORDS, (volatile int64_t *)c->h_counters, seq, g->bm_visited, g->bm_next,
+                                   hint ? 1 : 0, hint ? *hint : no_hint);
             else
                 hipLaunchKernelGGL(vgl_k_bm_gnf_count<false>, dim3(nb), dim3(VGL_BLOCK), 0, c->stream, nwords, word0, g->row_begin,
                                    const_cast<uint64_t *>(front), g->out.rowptr, g->vt_cnt, g->vt_deg, g->vt_cnt_off, g->vt_deg_off, g->offs, c->d_counters,
-                                   g->tickets + 0 * VGL_TICKET_WORDS, (volatile int64_t *)c->h_counters, seq, (uint64_t *)nullptr, (uint64_t *)nullptr);
+                                   g->tickets + 0 * VGL_TICKET_WORDS, (volatile int64_t *)c->h_counters, seq, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                   0, no_hint);
         }
         VGL_HIP_TRY(hipGetLastError());
         VGL_TRY(vgl_wait_counters(c, seq));
@@ -1140,15 +1228,28 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     double blocked_share = 0.1;                          // top-down levels with at least this share of the edges take the blocked pass (when prepared;
                                                          // RMAT-24 top-down traversal: 1.83 ms at 0.2, 1.67 at 0.1, 1.66 at 0.05, 1.69 at 0.02)
     if (const char *e = getenv("VGL_BFS_BLOCKED_SHARE")) blocked_share = atof(e);
+    // hint_ready: the launch that produced the frontier about to be counted left its F and M on the device (a counting top-down level, or
+    // the list kernel leaving with a frontier too long for its list): the count launch may then skip everything but the bitmaps when the
+    // rule turns the level bottom-up (`skipped`; the rule below must -- and does, same integers -- come to the same conclusion)
+    bool hint_ready = false, skipped = false;
+    const bool use_hints = mode == VGL_HIP_BFS_DIRECTION_OPT && !(getenv("VGL_BFS_NO_HINT") && getenv("VGL_BFS_NO_HINT")[0] == '1');
     auto count_frontier = [&]() -> int {
-        if (front_valid) { VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false, -1, advance_pending)); counted_from_bitmap = true; advance_pending = false; }
+        skipped = false;
+        if (front_valid) {
+            const vgl_do_hint hint = {prevF, visited_total, (int64_t)V, factor};
+            const bool hinted = hint_ready && advance_pending && use_hints;
+            VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false, -1, advance_pending, hinted ? &hint : nullptr));
+            skipped = hinted && c->h_counters[C_SKIPPED] != 0;
+            counted_from_bitmap = true; advance_pending = false;
+        }
         else {
             vgl_pred_equal_i32 pred{d_levels, cur};
             VGL_TRY(vgl_gnf_run(c, g, pred, g->ids, g->offs, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, nullptr, false, true));
             front_valid = true; counted_from_bitmap = false;
         }
         F = c->h_counters[C_FRONT]; M = c->h_counters[C_NEIGH];
-        counted = true;
+        counted = !skipped;
+        hint_ready = false;
         return 0;
     };
     // small frontiers (the first and the last levels): several levels in one single-workgroup launch, vgl_k_bfs_small_levels.  The edge
@@ -1196,7 +1297,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         else if (c->h_counters[C_HEAVY] != 0) {                                // handed over: ids / offs / tile_first / bm_front describe level cur
             F = c->h_counters[C_FRONT]; M = c->h_counters[C_BU_EDGES];
             precounted = true; front_valid = true; advance_pending = false;
-        } else { advance_pending = true; front_valid = true; }                 // its discoveries wait in bm_next
+        } else { advance_pending = true; front_valid = true; hint_ready = c->h_counters[C_HINT] != 0; }      // its discoveries wait in bm_next
     };
     if (small_m > 0) {                                                         // level 1 = {source}
         VGL_TRY(small_levels(1, source));
@@ -1239,6 +1340,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             }
         }
         prevF = F;
+        if (skipped && !bottom_up) VGL_FAIL("bfs_run: internal error (the count launch and the host disagree on the direction rule)");
         if (!bottom_up && g->blk_bfs && front_valid && (double)M >= blocked_share * (double)E) {
             // a level that holds a large share of the edges: the blocked pass (bitmaps in, bitmap + levels out: the state afterwards is
             // that after an emitting top-down level)
@@ -1264,7 +1366,9 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                 continue;
             }
             const bool emit = M <= VGL_TD_EMIT_EDGES;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
-            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap));
+            const bool td_counts = emit && use_hints && vgl_ceil_div(M, VGL_TILE) <= VGL_TD_COUNT_TILES;
+            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap, td_counts));
+            hint_ready = td_counts;
             advance_pending = emit;          // a top-down level is always followed by count_frontier (or the loop ends below)
             front_valid = emit;
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
@@ -1310,9 +1414,9 @@ int vgl_hip_bfs_step_top_down(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_level
     if (F > 0 && M > 0) {
         hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, (int32_t)F, g->offs, g->tile_first);
         vgl_timed_launch tl(c, "bfs_top_down");
-        hipLaunchKernelGGL(vgl_k_td_expand<false>, dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
+        hipLaunchKernelGGL((vgl_k_td_expand<false, false>), dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
                            g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, visited, d_levels, level + 1,
-                           (uint64_t *)nullptr);
+                           (uint64_t *)nullptr, (int64_t *)nullptr, (uint32_t *)nullptr, (int64_t *)nullptr);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;                                    // enqueued; the caller's next call on this context orders after it
@@ -1330,9 +1434,9 @@ int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_
     if (local_edges) *local_edges = M;
     if (F > 0 && M > 0) {                                        // tile_first came with the write pass
         vgl_timed_launch tl(c, "bfs_top_down");
-        hipLaunchKernelGGL(vgl_k_td_expand<true>, dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
+        hipLaunchKernelGGL((vgl_k_td_expand<true, false>), dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
                            g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, d_visited_bits, d_levels, level + 1,
-                           d_next_bits);
+                           d_next_bits, (int64_t *)nullptr, (uint32_t *)nullptr, (int64_t *)nullptr);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;

@@ -301,8 +301,8 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_TRY(vgl_alloc(&g->heavy_cnt, (size_t)4096));
     VGL_TRY(vgl_alloc(&g->heavy_off, (size_t)4097));
     VGL_TRY(vgl_alloc(&g->bu_partials, (size_t)4096 * 4));
-    VGL_TRY(vgl_alloc(&g->tickets, (size_t)3 * VGL_TICKET_WORDS));
-    VGL_HIP_TRY(hipMemsetAsync(g->tickets, 0, 3 * VGL_TICKET_WORDS * sizeof(uint32_t), c->stream));
+    VGL_TRY(vgl_alloc(&g->tickets, (size_t)4 * VGL_TICKET_WORDS));
+    VGL_HIP_TRY(hipMemsetAsync(g->tickets, 0, 4 * VGL_TICKET_WORDS * sizeof(uint32_t), c->stream));
     VGL_TRY(vgl_alloc(&g->epoch, (size_t)V));
     VGL_TRY(vgl_alloc(&g->fscratch, (size_t)V));
     VGL_TRY(vgl_alloc(&g->fscratch2, (size_t)V));

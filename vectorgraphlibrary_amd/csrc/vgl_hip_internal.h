@@ -31,7 +31,10 @@ int vgl_set_error(const char *file, int line, const char *msg);
 // device counters (int64 slots in ctx->d_counters, mirrored into pinned host memory on demand)
 enum {
     C_FRONT = 0, C_NEIGH = 1, C_BU_FOUND = 2, C_BU_EDGES = 3, C_HEAVY = 4, C_CHANGED = 5,
-    C_EDGES = 6, C_TMP0 = 7, C_TMP1 = 8, C_JUMP = 9, C_NSLOTS = 32
+    C_EDGES = 6, C_TMP0 = 7, C_TMP1 = 8, C_JUMP = 9,
+    C_NEXT_F = 10, C_NEXT_M = 11,    // device only: size / out-degree sum of the frontier an emitting top-down level (or the list kernel) just produced
+    C_SKIPPED = 12, C_HINT = 13,     // host mirror only: the bitmap count skipped its degree pass (the level turns bottom-up) / the list kernel left C_NEXT_*
+    C_NSLOTS = 32
 };
 // sharded accumulators: kernels launched with very many workgroups add into shard (blockIdx & (VGL_NSHARD-1)) so that no
 // single address receives more than a few hundred device atomics; vgl_read_counters folds them into the counter slots.
@@ -147,7 +150,11 @@ int vgl_zero_counters(vgl_hip_ctx *ctx, int first, int count);
 int vgl_ensure_partials(vgl_hip_ctx *ctx, size_t n);
 int vgl_build_tile_rows(vgl_hip_ctx *ctx, struct vgl_dir_csr &d, int32_t nrows);
 // frontier from a bitmap over the owned words (bfs.hip): count = sizes to h_counters[C_FRONT / C_NEIGH] (waits), write = ids + edge offsets + tile table
-int vgl_bfs_bm_gnf(vgl_hip_ctx *c, struct vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1, bool advance = false);   // d.tile_row / d.ntiles from d.rowptr / d.edges (owned by the caller)
+// what the direction rule (gpu_change_state) needs besides the new frontier's F and M: with it the count launch may find on the device that
+// the level turns bottom-up and leave out everything a top-down level would need (degree sums, compaction offsets)
+struct vgl_do_hint { int64_t prev_f, visited_total, V, factor; };
+int vgl_bfs_bm_gnf(vgl_hip_ctx *c, struct vgl_hip_graph *g, const uint64_t *front, bool count, bool write, int64_t M_known = -1, bool advance = false,
+                   const vgl_do_hint *hint = nullptr);   // d.tile_row / d.ntiles from d.rowptr / d.edges (owned by the caller)
 // set bits of `words` 64-bit words as ids (64 * (word_base + word) + bit): d_out[0] = their number, d_out[1 .. 1 + cap) = the first cap handed out
 int vgl_bitmap_to_ids(vgl_hip_ctx *c, int64_t words, const uint64_t *d_bits, int64_t word_base, int32_t cap, int32_t *d_out);
 
