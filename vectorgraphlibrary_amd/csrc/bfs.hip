@@ -103,18 +103,31 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
     // load under a per-lane condition is compiled as a branch whose result is awaited before the next one is issued -- eight visited
     // words and eight levels, sixteen dependent round trips per thread, is what the first version of this kernel waited for.  And the
     // levels are requested BEFORE the first store: a load after a store to the same array may alias it.
+#ifndef VGL_TD_BATCH
+#define VGL_TD_BATCH 3
+#endif
     uint64_t vw[VGL_EPT];
+    bool unvis[VGL_EPT];
+    bool fresh[VGL_EPT];
+#if VGL_TD_BATCH & 1
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) vw[j] = visited[max(dsts[j], 0) >> 6];
-    bool unvis[VGL_EPT];
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0 && !((vw[j] >> (dsts[j] & 63)) & 1ULL);
+#else
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0 && !((visited[dsts[j] >> 6] >> (dsts[j] & 63)) & 1ULL);
+#endif
+#if VGL_TD_BATCH & 2
     int32_t lv[VGL_EPT];
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) lv[j] = levels[unvis[j] ? dsts[j] : 0];
-    bool fresh[VGL_EPT];
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) fresh[j] = unvis[j] && lv[j] == -1;
+#else
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) fresh[j] = unvis[j] && levels[dsts[j]] == -1;
+#endif
     if (!COUNT) {
 #pragma unroll
         for (int j = 0; j < VGL_EPT; j++)
@@ -136,13 +149,17 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
         }
     }
     int64_t cnt = 0, deg = 0;
+    int64_t lo[VGL_EPT], hi[VGL_EPT];
+    bool claimed[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {                     // (unconditional loads again: a slot that claimed nothing reads row 0)
+        claimed[j] = dsts[j] >= 0 && !((old[j] >> (dsts[j] & 63)) & 1ULL);
+        const int64_t r = claimed[j] ? dsts[j] - row_base : 0;
+        lo[j] = rowptr[r]; hi[j] = rowptr[r + 1];
+    }
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++)
-        if (dsts[j] >= 0 && !((old[j] >> (dsts[j] & 63)) & 1ULL)) {
-            const int64_t r = dsts[j] - row_base;
-            cnt++;
-            deg += rowptr[r + 1] - rowptr[r];
-        }
+        if (claimed[j]) { cnt++; deg += hi[j] - lo[j]; }
     cnt = vgl_block_reduce_add(cnt, s64);
     deg = vgl_block_reduce_add(deg, s64);
     uint32_t dep = 0;
@@ -562,7 +579,7 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(int3
                 atomicOr((unsigned long long *)&next[dst[u] >> 6], bit);
                 const int pos = atomicAdd(&s_cnt, 1);
                 if (pos < VGL_SMALL_F) s_list[cur ^ 1][pos] = dst[u];
-                found_deg += rowptr[dst[u] + 1] - rowptr[dst[u]];
+                else found_deg += rowptr[dst[u] + 1] - rowptr[dst[u]];       // (only a level that overflows the list gets here; the listed ones below)
             }
         }
         __syncthreads();                                       // every append of this level has happened
@@ -571,7 +588,13 @@ __global__ __launch_bounds__(VGL_SMALL_THREADS) void vgl_k_bfs_small_levels(int3
         if (run > 1) later_front += F;
         F = Fn;
         if (Fn > VGL_SMALL_F) {                                // the next frontier does not fit the list (it is all in `next`): leave its
-            found_deg = vgl_wave_incl_add(found_deg);          // size and out-degree sum for the count launch that follows (C_NEXT_F / C_NEXT_M)
+            {                                                  // size and out-degree sum for the count launch that follows (C_NEXT_F / C_NEXT_M)
+                static_assert(VGL_SMALL_F == 2 * NT, "two listed vertices per thread");
+                const int32_t v0 = s_list[cur ^ 1][tid], v1 = s_list[cur ^ 1][tid + NT];
+                const int64_t a0 = rowptr[v0], a1 = rowptr[v0 + 1], c0 = rowptr[v1], c1 = rowptr[v1 + 1];
+                found_deg += (a1 - a0) + (c1 - c0);
+            }
+            found_deg = vgl_wave_incl_add(found_deg);
             if (lane == 63) s_deg[wave] = found_deg;
             __syncthreads();
 #pragma unroll
@@ -701,13 +724,17 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bu_probe(int32_t nrows, int32
                 const int32_t u0[4] = {h.x, h.y, h.z, h.w};
                 uint32_t hit = 0;
                 int n = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (u0[q] >= 0) n = q + 1;
                 // the first in-neighbour alone first: when it is in the frontier (the common case once the frontier is large) the
-                // other three frontier words are never requested
-                if (u0[0] >= 0) { n = 1; hit = in_front(u0[0]); }
+                // other three frontier words are never requested.  (Requesting those three -- and the second plane's four -- together
+                // and unconditionally, the change that took 10 % off the top-down expansion, does nothing for THIS kernel: 60.2 against
+                // 59.2 us per launch, RMAT-27 533 against 517 -- its time does not follow a wavefront's dependent chain, see above.)
+                if (u0[0] >= 0) hit = in_front(u0[0]);
                 if (hit == 0) {
 #pragma unroll
                     for (int q = 1; q < 4; q++)
-                        if (u0[q] >= 0) { n = q + 1; hit |= in_front(u0[q]) << q; }
+                        if (u0[q] >= 0) hit |= in_front(u0[q]) << q;
                 }
                 bool longer = false;
                 if (hit == 0 && n == 4) {

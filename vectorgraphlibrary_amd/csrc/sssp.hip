@@ -93,39 +93,44 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax(const int64_t *row
         }
         int rows[VGL_EPT];
 #pragma unroll
-        for (int j = 0; j < VGL_EPT; j++) rows[j] = s_map[i0 + j];
-        // gather phase: issue all dist[dst] loads before any dependent work
+        for (int j = 0; j < VGL_EPT; j++) rows[j] = s_map[i0 + j < n ? i0 + j : i0];       // (i0 < n here)
+        // gather phase: every load unconditional and issued before any dependent work (a slot of the same row as its neighbour re-reads
+        // the same cached word; a slot that cannot relax reads dist[0]) -- loads under per-lane conditions are compiled as branches that
+        // are awaited one after the other, eight dependent round trips per thread in the first version of this kernel
         float olds[VGL_EPT];
         float dsrc[VGL_EPT];
-        int prev_row = -1;
-        float d = 0.0f;
-        bool live = false;
+        int32_t ep[VGL_EPT];
 #pragma unroll
-        for (int j = 0; j < VGL_EPT; j++) {
-            if (rows[j] != prev_row) {
-                prev_row = rows[j];
-                const int32_t u = row_base + r_first + rows[j];
-                d = dist[u];
-                live = Path::live(d);
-                if (ACTIVE_FILTER) live = live && (epoch[u] >= iter - 1);
-            }
-            const bool ok = live && (i0 + j < n);
-            dsrc[j] = ok ? d : Path::dead_value();
-            olds[j] = ok ? dist[dsts[j]] : 0.0f;
+        for (int j = 0; j < VGL_EPT; j++) dsrc[j] = dist[row_base + r_first + rows[j]];
+        if (ACTIVE_FILTER) {
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) ep[j] = epoch[row_base + r_first + rows[j]];
         }
 #pragma unroll
         for (int j = 0; j < VGL_EPT; j++) {
-            if (Path::live(dsrc[j])) {
-                const float nd = Path::extend(dsrc[j], ws[j]);       // shortest_paths.hpp:126-130 / widest_paths.hpp:45-50
-                if (Path::better(nd, olds[j])) {
-                    const int before = Path::update(dist + dsts[j], nd);
-                    if (Path::improved(before, nd)) {
-                        changed = 1;
-                        if (ACTIVE_FILTER) epoch[dsts[j]] = iter;
-                    }
-                }
-            }
+            bool ok = Path::live(dsrc[j]) && (i0 + j < n);
+            if (ACTIVE_FILTER) ok = ok && ep[j] >= iter - 1;
+            if (!ok) dsrc[j] = Path::dead_value();
         }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) olds[j] = dist[Path::live(dsrc[j]) ? dsts[j] : 0];
+        // the atomics of a thread's edges are issued together, their return values read afterwards
+        float nd[VGL_EPT];
+        int before[VGL_EPT];
+        bool tried[VGL_EPT];
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            nd[j] = Path::extend(dsrc[j], ws[j]);                    // shortest_paths.hpp:126-130 / widest_paths.hpp:45-50
+            tried[j] = Path::live(dsrc[j]) && Path::better(nd[j], olds[j]);
+            before[j] = 0;
+            if (tried[j]) before[j] = Path::update(dist + dsts[j], nd[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++)
+            if (tried[j] && Path::improved(before[j], nd[j])) {
+                changed = 1;
+                if (ACTIVE_FILTER) epoch[dsts[j]] = iter;
+            }
     }
     const int any_changed = __syncthreads_or(changed);
     if (threadIdx.x == 0) {
@@ -242,31 +247,64 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_sssp_relax_sparse(const int32
             s_d[k] = dist[u];
         }
     vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);      // ends with a barrier: s_base / s_d are visible too
+    // Loads are issued in rounds of VGL_EPT with nothing conditional about them (a slot past the tile's end reads the tile's first edge, a
+    // slot without a candidate reads dist[0]): a load under a per-lane condition is compiled as a branch whose result is awaited before
+    // the next one is issued -- the first version of this kernel made 8 x (adjacency, weight) dependent round trips per thread.
     int32_t dsts[VGL_EPT];
     float cand[VGL_EPT], olds[VGL_EPT];
+    if (staged) {
+        int64_t es[VGL_EPT];
+        float ds[VGL_EPT], wv[VGL_EPT];
+        bool ok[VGL_EPT];
 #pragma unroll
-    for (int j = 0; j < VGL_EPT; j++) {
-        const int i = threadIdx.x + j * VGL_BLOCK;          // strided slots => coalesced adjacency / weight reads
-        dsts[j] = -1;
-        cand[j] = Path::dead_value();
-        if (i < n) {
-            const int k = s_map[i];
-            const int32_t u = staged ? 0 : ids[p_first + k];
-            const int64_t base = staged ? s_base[k] : (rowptr[u - row_base] - offs[p_first + k]);
-            const float d = staged ? s_d[k] : dist[u];
-            const int64_t e = base + e0 + i;
-            dsts[j] = adj[e];
-            if (Path::live(d)) cand[j] = Path::extend(d, w[e]);
+        for (int j = 0; j < VGL_EPT; j++) {
+            const int i = threadIdx.x + j * VGL_BLOCK;      // strided slots => coalesced adjacency / weight reads
+            ok[j] = i < n;
+            const int ii = ok[j] ? i : 0;
+            const int k = s_map[ii];
+            es[j] = s_base[k] + e0 + ii;
+            ds[j] = s_d[k];
+        }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) dsts[j] = adj[es[j]];
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) wv[j] = w[es[j]];
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            cand[j] = ok[j] && Path::live(ds[j]) ? Path::extend(ds[j], wv[j]) : Path::dead_value();
+            if (!ok[j]) dsts[j] = -1;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            const int i = threadIdx.x + j * VGL_BLOCK;
+            dsts[j] = -1;
+            cand[j] = Path::dead_value();
+            if (i < n) {
+                const int k = s_map[i];
+                const int32_t u = ids[p_first + k];
+                const int64_t e = rowptr[u - row_base] - offs[p_first + k] + e0 + i;
+                const float d = dist[u];
+                dsts[j] = adj[e];
+                if (Path::live(d)) cand[j] = Path::extend(d, w[e]);
+            }
         }
     }
 #pragma unroll
-    for (int j = 0; j < VGL_EPT; j++) olds[j] = dsts[j] >= 0 ? dist[dsts[j]] : Path::dead_value();
+    for (int j = 0; j < VGL_EPT; j++) olds[j] = dist[dsts[j] >= 0 && Path::live(cand[j]) ? dsts[j] : 0];
+    // the atomics of a thread's edges are issued together, their return values read afterwards
+    int before[VGL_EPT];
+    bool tried[VGL_EPT];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        tried[j] = dsts[j] >= 0 && Path::live(cand[j]) && Path::better(cand[j], olds[j]);
+        before[j] = 0;
+        if (tried[j]) before[j] = Path::update(dist + dsts[j], cand[j]);
+    }
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++)
-        if (dsts[j] >= 0 && Path::live(cand[j]) && Path::better(cand[j], olds[j])) {
-            const int before = Path::update(dist + dsts[j], cand[j]);
-            if (Path::improved(before, cand[j])) atomicOr(reinterpret_cast<unsigned long long *>(changed + (dsts[j] >> 6)), 1ULL << (dsts[j] & 63));
-        }
+        if (tried[j] && Path::improved(before[j], cand[j]))
+            atomicOr(reinterpret_cast<unsigned long long *>(changed + (dsts[j] >> 6)), 1ULL << (dsts[j] & 63));
 }
 
 struct vgl_hip_sssp_pull_plan {
