@@ -37,23 +37,24 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_hook(const int64_t *rowptr
 #pragma unroll
             for (int j = 0; j < VGL_EPT; j++) dsts[j] = (i0 + j < n) ? adj[e0 + i0 + j] : 0;
         }
+        // loads unconditional and in rounds (a slot past the tile's end repeats the thread's first edge; guarded loads are compiled as
+        // branches that are awaited one after the other), the atomics issued together and their return values read afterwards
         int32_t csrc[VGL_EPT], cdst[VGL_EPT];
-        int prev_row = -1;
-        int32_t cs = 0;
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) csrc[j] = comp[row_base + r_first + s_map[i0 + j < n ? i0 + j : i0]];
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) cdst[j] = comp[dsts[j]];
+        int32_t before[VGL_EPT];
+        bool tried[VGL_EPT];
 #pragma unroll
         for (int j = 0; j < VGL_EPT; j++) {
-            const int row = s_map[i0 + j];
-            if (row != prev_row) { prev_row = row; cs = comp[row_base + r_first + row]; }
-            csrc[j] = cs;
-            cdst[j] = (i0 + j < n) ? comp[dsts[j]] : -1;
+            tried[j] = i0 + j < n && csrc[j] < cdst[j];
+            before[j] = 0;
+            if (tried[j]) before[j] = atomicMin(comp + dsts[j], csrc[j]);
         }
 #pragma unroll
-        for (int j = 0; j < VGL_EPT; j++) {
-            if (csrc[j] < cdst[j]) {
-                const int32_t before = atomicMin(comp + dsts[j], csrc[j]);
-                if (before > csrc[j]) changed = 1;
-            }
-        }
+        for (int j = 0; j < VGL_EPT; j++)
+            if (tried[j] && before[j] > csrc[j]) changed = 1;
     }
     if (__syncthreads_or(changed) && threadIdx.x == 0) counters[C_CHANGED] = 1;
 }
@@ -73,6 +74,17 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_jump(int32_t V, int32_t *c
 // ---- symmetric graphs: min-id union-find (the same fixed point as the hook/jump loop when every edge has its reverse) ----
 // comp[] is a parent forest with comp[x] <= x at all times; a root is x with comp[x] == x.  link() hooks the larger of the two
 // roots under the smaller one with a CAS and climbs when it loses a race, so the root of a finished tree is its smallest id.
+__device__ __forceinline__ void vgl_cc_link_from(int32_t p1, int32_t p2, int32_t *comp)      // p1 = comp[u], p2 = comp[v], read by the caller
+{
+    while (p1 != p2) {
+        const int32_t high = max(p1, p2), low = min(p1, p2);
+        const int32_t ph = comp[high];
+        if (ph == low) break;
+        if (ph == high && atomicCAS(comp + high, high, low) == high) break;
+        p1 = comp[comp[high]];
+        p2 = comp[low];
+    }
+}
 __device__ __forceinline__ void vgl_cc_link(int32_t u, int32_t v, int32_t *comp)
 {
     int32_t p1 = comp[u], p2 = comp[v];
@@ -115,15 +127,35 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_cc_link_rest(const int64_t *r
     const int r_first = tile_row[blockIdx.x];
     const int r_last = tile_row[blockIdx.x + 1];
     vgl_tile_row_map(s_map, s_w, rowptr, e0, r_first, r_last);
+    // the rows' parents (and row starts), then the neighbours, then the neighbours' parents: three rounds of loads with nothing conditional
+    // about the INSTRUCTIONS (guarded, each load was a branch awaited before the next was issued) -- a slot that skips its edge (row in
+    // `giant`, edge linked by the sampling rounds, past the tile's end) reads entry 0 of the tile / of comp instead, one shared line, so the
+    // adjacency of the rows in `giant` still is not fetched; a wavefront with nothing to link leaves after the first round
+    int32_t pu[VGL_EPT], vs[VGL_EPT], pv[VGL_EPT];
+    int64_t rb[VGL_EPT];
+    bool take[VGL_EPT];
 #pragma unroll
     for (int j = 0; j < VGL_EPT; j++) {
         const int i = threadIdx.x + j * VGL_BLOCK;
-        if (i < n) {
-            const int32_t r = r_first + s_map[i];
-            const int32_t u = row_base + r;
-            if (comp[u] != giant && e0 + i - rowptr[r] >= skip) vgl_cc_link(u, adj[e0 + i], comp);
-        }
+        const int32_t r = r_first + s_map[i < n ? i : 0];
+        pu[j] = comp[row_base + r];
+        rb[j] = rowptr[r];
     }
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) {
+        const int i = threadIdx.x + j * VGL_BLOCK;
+        take[j] = i < n && pu[j] != giant && e0 + i - rb[j] >= skip;
+        any = any || take[j];
+    }
+    if (!__any(any)) return;
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) vs[j] = adj[take[j] ? e0 + threadIdx.x + j * VGL_BLOCK : e0];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++) pv[j] = comp[take[j] ? vs[j] : 0];
+#pragma unroll
+    for (int j = 0; j < VGL_EPT; j++)
+        if (take[j]) vgl_cc_link_from(pu[j], pv[j], comp);
 }
 
 static inline unsigned vgl_grid2(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, vgl_ceil_div(n, VGL_BLOCK))); }

@@ -430,37 +430,59 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax(const int64_t *count
         vgl_tile_row_map(s_map, s_w, offs, e0, p_first, p_last);
         int32_t dsts[VGL_EPT];
         float nds[VGL_EPT], olds[VGL_EPT];
+        if (staged) {                                          // loads unconditional and in rounds (see vgl_k_sssp_relax_sparse)
+            int64_t es[VGL_EPT];
+            float ds[VGL_EPT], wv[VGL_EPT];
+            bool ok[VGL_EPT];
 #pragma unroll
-        for (int j = 0; j < VGL_EPT; j++) {
-            const int i = threadIdx.x + j * VGL_BLOCK;
-            dsts[j] = -1;
-            nds[j] = 0.0f;
-            if (i < n) {
-                const int k = s_map[i];
-                int64_t base; float d;
-                if (staged) { base = s_base[k]; d = s_dsrc[k]; }
-                else {
+            for (int j = 0; j < VGL_EPT; j++) {
+                const int i = threadIdx.x + j * VGL_BLOCK;
+                ok[j] = i < n;
+                const int ii = ok[j] ? i : 0;
+                const int k = s_map[ii];
+                es[j] = s_base[k] + e0 + ii;
+                ds[j] = s_dsrc[k];
+            }
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) dsts[j] = adj_p[es[j]];
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) wv[j] = w_p[es[j]];
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) {
+                nds[j] = __fadd_rn(ds[j], wv[j]);               // src_weight + weight (shortest_paths.hpp:126-130)
+                if (!ok[j]) dsts[j] = -1;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++) {
+                const int i = threadIdx.x + j * VGL_BLOCK;
+                dsts[j] = -1;
+                nds[j] = 0.0f;
+                if (i < n) {
+                    const int k = s_map[i];
                     const int p = p_first + k; const int32_t u = ids[p]; const int32_t r = u - row_base;
-                    base = prow[r] - offs[p];
-                    d = dist[u];
+                    const int64_t e = prow[r] - offs[p] + e0 + i;
+                    dsts[j] = adj_p[e];
+                    nds[j] = __fadd_rn(dist[u], w_p[e]);
                 }
-                const int64_t e = base + e0 + i;
-                dsts[j] = adj_p[e];
-                nds[j] = __fadd_rn(d, w_p[e]);                 // src_weight + weight (shortest_paths.hpp:126-130)
             }
         }
 #pragma unroll
-        for (int j = 0; j < VGL_EPT; j++) olds[j] = dsts[j] >= 0 ? dist[dsts[j]] : 0.0f;
+        for (int j = 0; j < VGL_EPT; j++) olds[j] = dist[max(dsts[j], 0)];
+        int before[VGL_EPT];
+        bool tried[VGL_EPT];
 #pragma unroll
         for (int j = 0; j < VGL_EPT; j++) {
-            if (dsts[j] >= 0 && olds[j] > nds[j]) {
-                const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
-                if (before > __float_as_int(nds[j])) {
-                    state[dsts[j]] = 3;                         // light and heavy edges pending again
-                    near += nds[j] < T;
-                }
-            }
+            tried[j] = dsts[j] >= 0 && olds[j] > nds[j];
+            before[j] = 0;
+            if (tried[j]) before[j] = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
         }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++)
+            if (tried[j] && before[j] > __float_as_int(nds[j])) {
+                state[dsts[j]] = 3;                             // light and heavy edges pending again
+                near += nds[j] < T;
+            }
     }
     __shared__ int s_near[VGL_WAVES];
     const int n_near = vgl_block_reduce_add(near, s_near);  // improvements that fall inside the current bucket (>= rows of the next light step)
@@ -543,34 +565,40 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_ds_relax_static(const int64_t
                 ws[j] = ok ? w_p[e0 + i0 + j] : 0.0f;
             }
         }
-        float olds[VGL_EPT], nds[VGL_EPT];
+        // every load unconditional and issued in rounds (rows' flags, rows' distances, destinations' distances, then the atomics): loads
+        // under per-lane conditions are compiled as branches that are awaited one after the other (see vgl_k_sssp_relax)
+        float olds[VGL_EPT], nds[VGL_EPT], ds[VGL_EPT];
         bool ok[VGL_EPT];
-        int prev_row = -1;
-        float d = 0.0f;
-        bool live = false;
+        int32_t us[VGL_EPT];
+        uint8_t act[VGL_EPT];
 #pragma unroll
         for (int j = 0; j < VGL_EPT; j++) {
-            const int row = s_map[i0 + j];
-            if (row != prev_row) {
-                prev_row = row;
-                const int32_t u = row_base + r_first + row;
-                live = active[u] != 0;
-                d = live ? dist[u] : 0.0f;
-            }
-            ok[j] = live && (i0 + j < n);
-            nds[j] = __fadd_rn(d, ws[j]);                      // src_weight + weight (shortest_paths.hpp:126-130)
-            olds[j] = ok[j] ? dist[dsts[j]] : 0.0f;
+            us[j] = row_base + r_first + s_map[i0 + j < n ? i0 + j : i0];
+            act[j] = active[us[j]];
         }
 #pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) ds[j] = dist[us[j]];
+#pragma unroll
         for (int j = 0; j < VGL_EPT; j++) {
-            if (ok[j] && olds[j] > nds[j]) {
-                const int before = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
-                if (before > __float_as_int(nds[j])) {
-                    state[dsts[j]] = 3;
-                    near += nds[j] < T;
-                }
-            }
+            ok[j] = act[j] != 0 && (i0 + j < n);
+            nds[j] = __fadd_rn(ds[j], ws[j]);                  // src_weight + weight (shortest_paths.hpp:126-130)
         }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) olds[j] = dist[ok[j] ? dsts[j] : 0];
+        int before[VGL_EPT];
+        bool tried[VGL_EPT];
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) {
+            tried[j] = ok[j] && olds[j] > nds[j];
+            before[j] = 0;
+            if (tried[j]) before[j] = atomicMin(reinterpret_cast<int *>(dist + dsts[j]), __float_as_int(nds[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++)
+            if (tried[j] && before[j] > __float_as_int(nds[j])) {
+                state[dsts[j]] = 3;
+                near += nds[j] < T;
+            }
     }
     const int n_near = vgl_block_reduce_add(near, s_near);
     if (threadIdx.x == 0 && n_near) {
