@@ -60,6 +60,24 @@ struct vgl_pred_nonzero_i32 {               // flags[v] != 0
 // ticket (optional): the last workgroup to finish also does the scan pass (exclusive offsets per tile, totals, offs[size], hand-over to the
 // host when `host` is given) -- a scan kernel of its own, however small, waits for this kernel's caches to be written back and
 // invalidated before it starts: 18 us per frontier generation on RMAT-24, in every super-step of every frontier-driven algorithm.
+// the VGL_EPT + 1 row offsets of a thread's eight consecutive rows in ONE round of loads (72 contiguous bytes): fetched one by one under
+// `if (bit j)` each was a branch awaited before the next -- up to eight dependent round trips for the same one or two cache lines.
+// nvalid < VGL_EPT (the last rows of the graph): entries past nvalid repeat the last offset (bits8 reports no such row).
+typedef long long vgl_ll2_u __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void vgl_load_row_offsets(const int64_t *p, int nvalid, int64_t (&rp)[VGL_EPT + 1])
+{
+    static_assert(VGL_EPT == 8, "eight rows per thread");
+    if (nvalid == VGL_EPT) {
+        const vgl_ll2_u a = *reinterpret_cast<const vgl_ll2_u *>(p), b = *reinterpret_cast<const vgl_ll2_u *>(p + 2),
+                        c = *reinterpret_cast<const vgl_ll2_u *>(p + 4), d = *reinterpret_cast<const vgl_ll2_u *>(p + 6);
+        const int64_t e = p[8];
+        rp[0] = a.x; rp[1] = a.y; rp[2] = b.x; rp[3] = b.y; rp[4] = c.x; rp[5] = c.y; rp[6] = d.x; rp[7] = d.y; rp[8] = e;
+    } else {
+#pragma unroll
+        for (int j = 0; j <= VGL_EPT; j++) rp[j] = p[min(j, nvalid)];
+    }
+}
+
 template <class Pred>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_count(Pred pred, int32_t nrows, int32_t row_base, const int64_t *rowptr,
                                                              int32_t *vt_cnt, int64_t *vt_deg, uint8_t *front_bytes,
@@ -79,8 +97,11 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_count(Pred pred, int32_t 
         const uint32_t bits = pred.bits8(v0, nvalid, &aux);
         cnt = __popc(bits);
         if (bits) {
-            for (int j = 0; j < nvalid; j++)
-                if ((bits >> j) & 1) deg += rowptr[r0 + j + 1] - rowptr[r0 + j];
+            int64_t rp[VGL_EPT + 1];
+            vgl_load_row_offsets(rowptr + r0, nvalid, rp);
+#pragma unroll
+            for (int j = 0; j < VGL_EPT; j++)
+                if ((bits >> j) & 1) deg += rp[j + 1] - rp[j];
         }
         if (front_bytes) front_bytes[v0 >> 3] = (uint8_t)bits;
         if (visited_bytes) visited_bytes[v0 >> 3] = (uint8_t)aux;
@@ -226,10 +247,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_write(Pred pred, int32_t 
         uint32_t aux;
         bits = pred.bits8(row_base + r0, nvalid, &aux);
         if (bits && offs) {
+            int64_t rp[VGL_EPT + 1];
+            vgl_load_row_offsets(rowptr + r0, nvalid, rp);
 #pragma unroll
             for (int j = 0; j < VGL_EPT; j++) {
                 degs[j] = 0;
-                if (j < nvalid && ((bits >> j) & 1)) { degs[j] = rowptr[r0 + j + 1] - rowptr[r0 + j]; deg += degs[j]; }
+                if ((bits >> j) & 1) { degs[j] = rp[j + 1] - rp[j]; deg += degs[j]; }
             }
         }
     }
