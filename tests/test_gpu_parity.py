@@ -861,9 +861,13 @@ def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
             seen = []
             # (edge bound of the list kernel, frontier bound of the bitmap-driven level at the bottom-up -> top-down switch, edge bound of the
             # top-down levels that emit their discoveries into the bitmap)
-            for cap, bm, emit in (("0", None, None), (None, None, None), ("1000000", None, None), (None, "0", None), (None, "1000000000", None),
-                                  ("256", "1000000000", None), (None, None, "0"), (None, None, "1000000000000"), ("0", "0", "0")):
-                for name, val in (("VGL_BFS_SMALL_M", cap), ("VGL_BFS_BM_EXPAND", bm), ("VGL_TD_EMIT_EDGES", emit)):
+            # ... and VGL_BFS_NO_HINT=1: the count launch before a bottom-up phase walks the new frontier instead of taking F and M from the
+            # level that produced it
+            for cap, bm, emit, nohint in (("0", None, None, None), (None, None, None, None), ("1000000", None, None, None), (None, "0", None, None),
+                                          (None, "1000000000", None, None), ("256", "1000000000", None, None), (None, None, "0", None),
+                                          (None, None, "1000000000000", None), ("0", "0", "0", None), (None, None, None, "1"),
+                                          ("0", None, "1000000000000", "1"), ("1000000", "0", None, "1")):
+                for name, val in (("VGL_BFS_SMALL_M", cap), ("VGL_BFS_BM_EXPAND", bm), ("VGL_TD_EMIT_EDGES", emit), ("VGL_BFS_NO_HINT", nohint)):
                     if val is None:
                         os.environ.pop(name, None)
                     else:
@@ -871,9 +875,9 @@ def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
                 try:
                     lv, st = api.bfs(g, source, mode)
                 finally:
-                    for name in ("VGL_BFS_SMALL_M", "VGL_BFS_BM_EXPAND", "VGL_TD_EMIT_EDGES"):
+                    for name in ("VGL_BFS_SMALL_M", "VGL_BFS_BM_EXPAND", "VGL_TD_EMIT_EDGES", "VGL_BFS_NO_HINT"):
                         os.environ.pop(name, None)
-                assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap, bm, emit)
+                assert np.array_equal(lv.cpu().numpy(), ref), (source, mode, cap, bm, emit, nohint)
                 seen.append((st["levels"], st["edges_examined"], st["frontier_total"], st["discovered"], st["td_steps"], st["bu_steps"]))
             assert all(x == seen[0] for x in seen), (source, mode, seen)
 
