@@ -23,6 +23,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# several ranks on one host: the host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); has to be in the
+# environment before the first HIP call of the process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 KERNEL_OF = {"bfs_bottom_up": "vgl_k_bu_probe<true>", "bfs_top_down": "vgl_k_td_expand", "gnf": "vgl_k_gnf_count<vgl_pred_equal_i32>",
