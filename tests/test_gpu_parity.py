@@ -883,6 +883,40 @@ def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_bfs_level_without_edges_leaves_no_stale_direction_hint(ctx, oracle):
+    """a top-down level whose frontier has no out-edges launches no expansion, so it must not announce the frontier size / out-degree sum
+    an expansion would have left on the device: the count launch would otherwise read another traversal's (found by tests/studies/fuzz_bfs.py:
+    right levels, but a bottom-up step that never happened in the statistics)"""
+    import os
+    import torch
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    scale, ef = 14, 16
+    V = 1 << scale
+    src, dst = O.gen_rmat(scale, ef, 5)
+    src, dst = src.copy(), dst.copy()
+    lonely = V - 1                                      # a vertex without out-edges (its in-edges stay)
+    keep = src != lonely
+    src, dst = src[keep], dst[keep]
+    rowptr, adj, _ = O.coo_to_csr(V, src, dst)
+    g = api.Graph.from_coo(ctx, V, torch.from_numpy(src).to(ctx.device), torch.from_numpy(dst).to(ctx.device))
+    hub = int(np.argmax(np.diff(rowptr)))
+    for small_m in (None, "0"):
+        os.environ.pop("VGL_BFS_SMALL_M", None)
+        lv, st = api.bfs(g, hub, api.BFS_DIRECTION_OPT)              # leaves the F and M of a real top-down -> bottom-up switch on the device
+        assert np.array_equal(lv.cpu().numpy(), O.bfs_top_down(rowptr, adj, hub)[0]) and st["bu_steps"] > 0
+        if small_m is not None:
+            os.environ["VGL_BFS_SMALL_M"] = small_m                  # list kernel off: the lonely source goes through count / expand launches
+        try:
+            lv, st = api.bfs(g, lonely, api.BFS_DIRECTION_OPT)
+        finally:
+            os.environ.pop("VGL_BFS_SMALL_M", None)
+        assert np.array_equal(lv.cpu().numpy(), O.bfs_top_down(rowptr, adj, lonely)[0])
+        assert (st["levels"], st["discovered"], st["bu_steps"], st["edges_examined"]) == (1, 1, 0, 0), (small_m, st)
+    g.close()
+
+
+@pytest.mark.gpu
 def test_sparse_exchange_primitives(ctx):
     """vgl_hip_bitmap_to_ids / vgl_hip_bfs_apply_ids (id-list exchange of tiny multi-GPU levels) against numpy: counts beyond the
     cap are reported, lists are a subset of the set bits, duplicates across parts and visited vertices are taken once / not at all"""

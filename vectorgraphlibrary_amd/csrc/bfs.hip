@@ -1395,7 +1395,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             const bool emit = M <= VGL_TD_EMIT_EDGES;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
             const bool td_counts = emit && use_hints && vgl_ceil_div(M, VGL_TILE) <= VGL_TD_COUNT_TILES;
             VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap, td_counts));
-            hint_ready = td_counts;
+            hint_ready = td_counts && F > 0 && M > 0;     // (a level without edges launches nothing: C_NEXT_* would be another traversal's)
             advance_pending = emit;          // a top-down level is always followed by count_frontier (or the loop ends below)
             front_valid = emit;
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
