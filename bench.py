@@ -839,15 +839,19 @@ def main():
         # reached source never has an unreached destination) -- checked on the all-gathered levels
         if comm is not None:
             vs.bfs_run_sharded(shard, comm, sources[-1], api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=True, levels=levels_buf, want_stats=False)
-        lv = levels_buf.long()
-        rows = torch.repeat_interleave(torch.arange(shard.row_begin, shard.row_end, device=ctx.device), (shard.out_rowptr[1:] - shard.out_rowptr[:-1]))
-        ls, ld = lv[rows], lv[shard.out_adj.long()]
-        reached = ls > 0
-        levels_ok = bool(((ld[reached] > 0) & (ld[reached] <= ls[reached] + 1)).all()) and int(lv[sources[-1]]) == 1
-        del lv, rows, ls, ld, reached
+        # ... both halves of the certificate (vd.bfs_levels_certificate): no out-edge of a reached vertex leads more than one level down or to an
+        # unreached vertex, and every reached vertex but the source has an in-neighbour one level up -- together: these ARE the breadth-first
+        # levels, proven at the full size by every rank on its own rows
+        edges_ok, parents_ok = vd.bfs_levels_certificate(levels_buf, shard, sources[-1])
+        levels_ok = edges_ok and parents_ok is not False
+        if world > 1:
+            flag = torch.tensor([1 if levels_ok else 0], dtype=torch.int32, device=ctx.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            levels_ok = bool(int(flag.item()))
         extra["verified_sharded_levels_consistent_over_owned_edges"] = levels_ok
+        extra["verified_sharded_every_reached_vertex_has_a_parent_one_level_up"] = bool(parents_ok) if parents_ok is not None else None
         if not levels_ok:
-            sys.exit("bench.py: sharded BFS levels violate the level property on rank %d" % rank)
+            sys.exit("bench.py: sharded BFS levels fail the breadth-first certificate on rank %d" % rank)
         kern = {}
         for name in ("bfs_bottom_up", "bfs_bottom_up_heavy", "bfs_top_down", "bfs_small_levels", "bfs_bitmap_expand", "gnf"):
             n, ms = ctx.timing_get(name)

@@ -41,7 +41,7 @@ for r in range(P):
 build_ctx.sync()
 print(f"RMAT-{scale}x{ef}: {P} dealt shards built in {time.time() - t0:.1f} s ({shards[0][1].numel() / 1e6:.0f} M out-edges each)", flush=True)
 
-results, errors = [None] * P, []
+results, certs, errors = [None] * P, [None] * P, []
 
 
 def rank_main(r):
@@ -61,6 +61,9 @@ def rank_main(r):
                 k = {n: ctx.timing_get(n) for n in KERNELS}
                 ctx.timing(False)
                 per.append((st, k, comm.stats()))
+            # the last source once more with the levels gathered: both halves of the breadth-first certificate on this rank's rows
+            vs.bfs_run_sharded(shard, comm, sources[-1], api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=True, levels=levels, want_stats=False)
+            certs[r] = vd.bfs_levels_certificate(levels, shard, sources[-1])
             results[r] = per
             comm.barrier()
             comm.close()
@@ -85,3 +88,7 @@ for i, s in enumerate(sources[1:]):
           + " ".join(f"{x:.3f}" for x in kern) + f"  (max {max(kern):.3f}, sum {sum(kern):.3f});  "
           + "rank 0 by kernel: " + ", ".join(f"{n} {c}x {ms:.3f}" for n, (c, ms) in rows[0][1].items())
           + f";  exchange per rank: {rows[0][2]['collectives']} collectives, {rows[0][2]['bytes_received'] / 2**20:.1f} MiB received, {rows[0][2]['sparse_levels']} id-list levels", flush=True)
+print("breadth-first certificate of the last traversal (out-edges never skip a level / every reached vertex has a parent one level up), per rank:",
+      " ".join("%s/%s" % ("ok" if e else "FAIL", "ok" if p else "FAIL") for e, p in certs), flush=True)
+if not all(e and p for e, p in certs):
+    sys.exit("certificate failed")

@@ -245,3 +245,42 @@ def test_sharded_bfs_eight_rank_threads_one_gpu(ctx, world, sparse_cap):
         os.environ.pop("VGL_SHARD_SPARSE_CAP", None)
     assert not errors, errors
     g.close()
+
+
+def test_bfs_levels_certificate_accepts_the_levels_and_nothing_else(ctx):
+    """vd.bfs_levels_certificate (what bench.py --gpus N proves on every rank at the full size): true levels pass on every shard of a cut
+    graph; a level raised, a level lowered, a reachable vertex left unreached, an unreachable one marked reached and a second level-1
+    vertex are each caught by at least one shard"""
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import distributed as vd
+    scale, ef, seed = 14, 8, 9
+    V = 1 << scale
+    src, dst = ctx.gen_rmat(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True)
+    deg = g.out_rowptr[1:] - g.out_rowptr[:-1]
+    source = int(torch.argmax(deg))
+    levels, _ = api.bfs(g, source, api.BFS_TOP_DOWN, raw=True)
+    bounds = [0, 64 * 37, 64 * 150, V]
+    shards = [g.shard(bounds[i], bounds[i + 1]) for i in range(3)]
+
+    def verdict(lv):
+        res = [vd.bfs_levels_certificate(lv, sh, source, chunk_rows=4096) for sh in shards]
+        return all(e for e, _ in res), all(p for _, p in res)
+
+    assert verdict(levels) == (True, True)
+    reached = torch.nonzero(levels > 2).flatten()
+    unreached = torch.nonzero((levels < 0) & (g.in_rowptr[1:] - g.in_rowptr[:-1] > 0)).flatten()
+    assert reached.numel() > 10
+    v = int(reached[reached.numel() // 2])
+    for name, edit in (("raised", lambda lv: lv.__setitem__(v, int(lv[v]) + 1)), ("lowered", lambda lv: lv.__setitem__(v, int(lv[v]) - 1)),
+                       ("dropped", lambda lv: lv.__setitem__(v, -1)), ("second source", lambda lv: lv.__setitem__(v, 1))):
+        lv = levels.clone()
+        edit(lv)
+        assert verdict(lv) != (True, True), name
+    if unreached.numel():
+        lv = levels.clone()
+        lv[int(unreached[0])] = int(levels.max()) + 1          # marked reached without a parent one level up
+        assert verdict(lv) != (True, True)
+    for sh in shards:
+        sh.close()
+    g.close()

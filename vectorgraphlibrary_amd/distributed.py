@@ -328,6 +328,48 @@ def build_generated_shard(ctx, scale, edge_factor, seed, rank, world, kind="rmat
     return g, outdeg, bounds
 
 
+def bfs_levels_certificate(levels, shard, source, chunk_rows=1 << 22):
+    """A size-independent proof that `levels` (int32[V], 1 at the source, -1 for unreached, all vertices) are breadth-first levels, checked on
+    ONE shard's rows (every rank checks its own; the conjunction over the ranks is the proof):
+      edges   : for every owned out-edge u -> v with u reached, v is reached and levels[v] <= levels[u] + 1   (no level is too large,
+                and everything reachable is reached);
+      parents : every owned reached vertex other than the source has an in-neighbour exactly one level below   (no level is too small,
+                and everything reached is reachable) -- needs the shard's incoming lists.
+    Returns (edges_ok, parents_ok); parents_ok is None without incoming lists.  Test / bench infrastructure: plain torch ops on the GPU."""
+    import torch
+    lv = levels.long()
+    lo, hi = int(shard.row_begin), int(shard.row_end)
+    dev = lv.device
+
+    def row_index(rowptr, r0, r1):
+        deg = rowptr[r0 + 1:r1 + 1] - rowptr[r0:r1]
+        return torch.repeat_interleave(torch.arange(lo + r0, lo + r1, device=dev), deg), int(rowptr[r0]), int(rowptr[r1])
+
+    edges_ok = int(lv[source]) == 1
+    nrows = hi - lo
+    for r0 in range(0, nrows, chunk_rows):
+        r1 = min(nrows, r0 + chunk_rows)
+        rows, e0, e1 = row_index(shard.out_rowptr, r0, r1)
+        ls, ld = lv[rows], lv[shard.out_adj[e0:e1].long()]
+        reached = ls > 0
+        edges_ok = edges_ok and bool(((ld[reached] > 0) & (ld[reached] <= ls[reached] + 1)).all())
+        del rows, ls, ld, reached
+    parents_ok = None
+    if shard.in_rowptr is not None and shard.in_adj is not None:
+        parents_ok = True
+        for r0 in range(0, nrows, chunk_rows):
+            r1 = min(nrows, r0 + chunk_rows)
+            rows, e0, e1 = row_index(shard.in_rowptr, r0, r1)
+            has = torch.zeros(r1 - r0, dtype=torch.int32, device=dev)
+            good = (lv[shard.in_adj[e0:e1].long()] == lv[rows] - 1) & (lv[rows] > 1)
+            has.index_add_(0, rows - (lo + r0), good.to(torch.int32))
+            mine = lv[lo + r0:lo + r1]
+            need = mine > 1                                            # reached, not the source
+            parents_ok = parents_ok and bool((has[need] > 0).all()) and bool(((mine == 1).sum() == (1 if lo + r0 <= source < lo + r1 else 0)))
+            del rows, has, good, mine, need
+    return edges_ok, parents_ok
+
+
 def _allreduce(t, op, group):
     if _exchanging(_world(group)[0]):
         dist.all_reduce(t, op=op, group=group)
