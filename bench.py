@@ -499,14 +499,29 @@ def leg_cc_sharded(api, vd, vs, comm, ctx, dist, world, rank, cc_scale, seed, ch
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dtc = float(tmax.item())
     ok = bool((comp[comp.long()] == comp).all())                 # labels are roots: idempotent under the pointer jump
+    # ... and constant along every stored edge of this rank's rows, never above the vertex's own id (min-label semantics)
+    edges_same = bool((comp <= torch.arange(cV, device=ctx.device, dtype=comp.dtype)).all())
+    step = 1 << 22
+    for r0 in range(0, int(shard.row_end - shard.row_begin), step):
+        r1 = min(int(shard.row_end - shard.row_begin), r0 + step)
+        e0, e1 = int(shard.out_rowptr[r0]), int(shard.out_rowptr[r1])
+        rows = torch.repeat_interleave(torch.arange(shard.row_begin + r0, shard.row_begin + r1, device=ctx.device),
+                                       shard.out_rowptr[r0 + 1:r1 + 1] - shard.out_rowptr[r0:r1])
+        edges_same = edges_same and bool((comp[rows] == comp[shard.out_adj[e0:e1].long()]).all())
+        del rows
+    ok = ok and edges_same
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctx.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(int(flag.item()))
     alg = 8 * int(shard.E) + 12 * cV
     extra["cc_rmat_symmetrised_sharded"] = {
         "scale": cc_scale, "stored_edges": cE, "teps": round(cE / dtc, 1), "ms": round(dtc * 1e3, 3), "hook_passes": passes, "shard_edges": int(shard.E),
-        "graph_build_s": round(t_build, 2), "exchange": st, "labels_idempotent": ok,
+        "graph_build_s": round(t_build, 2), "exchange": st, "labels_idempotent": ok, "labels_equal_along_owned_edges": edges_same,
         "rank0_hook_pass": {"path": path, "ms": round(ms / max(passes, 1), 4), "algorithmic_GBps": round(alg / (ms / max(passes, 1) * 1e-3) / 1e9, 1) if ms > 0 else None,
                             "frac_of_hbm_peak": frac(alg / (ms / max(passes, 1) * 1e-3) / 1e9) if ms > 0 else None}}
     if not ok:
-        sys.exit("bench.py: sharded CC labels are not idempotent")
+        sys.exit("bench.py: sharded CC labels are not idempotent / not constant along the stored edges")
     shard.close()
     del shard, comp
     torch.cuda.empty_cache()
