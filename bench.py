@@ -458,12 +458,29 @@ def leg_pr_sharded(api, vd, vs, comm, ctx, dist, world, rank, pscale, ef, seed, 
     alg = 8 * int(shard.E) + 28 * pV                              # this shard's edges; the V-proportional passes are replicated
     extra[f"pagerank_uniform{pscale}_sharded"] = {
         "teps": round(iters * pE / dtp, 1), "ms_per_iteration": round(dtp / iters * 1e3, 3), "iterations": iters, "ranks_sum": mass,
-        "shard_edges": int(shard.E), "graph_build_s": round(t_build, 2), "exchange": "vgl_hip_pr_run_sharded: all-gather of owned rank slices (RCCL, in place)",
+        "shard_edges": int(shard.E), "graph_build_s": round(t_build, 2), "exchange": "vgl_hip_pr_run_sharded: all-gather of owned rank slices (RCCL, in place); in-degrees summed over the ranks once per graph handle (in the warm-up call)",
         "received_bytes_per_iteration": st.get("bytes_received", 0) // iters, "collectives": st.get("collectives", 0),
         "rank0_pull_pass": {"ms": round(pass_ms, 4), "algorithmic_GBps": round(alg / (pass_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": frac(alg / (pass_ms * 1e-3) / 1e9),
                             "path": "blocked" if blocked else "adjacency-order chain"}}
     if abs(mass - 1.0) > 1e-3:
         sys.exit(f"bench.py: sharded PageRank lost mass ({mass})")
+    # an independent recomputation (torch, f64) of the LAST iteration on this rank's rows from the ranks one iteration earlier
+    before, _ = vs.pr_run_sharded(shard, comm, iters - 1, api.PR_AUTO)
+    before = before.clone()
+    after, _ = vs.pr_run_sharded(shard, comm, iters, api.PR_AUTO)
+
+    def add_other_ranks(t):
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    residual = vd.pagerank_step_residual(shard, before, after, add_other_ranks)
+    if world > 1:
+        rmax = torch.tensor([residual], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+        residual = float(rmax.item())
+    extra[f"pagerank_uniform{pscale}_sharded"]["last_iteration_max_rel_residual_vs_f64_recomputation"] = residual
+    if not residual <= 1e-5:
+        sys.exit(f"bench.py: sharded PageRank iteration differs from its f64 recomputation ({residual})")
+    del before, after
     shard.close()
     del shard, ranks
     torch.cuda.empty_cache()

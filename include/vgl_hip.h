@@ -425,7 +425,8 @@ int vgl_hip_exchange_changed_u32(vgl_hip_comm *comm, int32_t n, const void *d_be
  *   sssp / sswp : all-active push over the owned rows + changed-entries exchange (min / max)
  *   cc  : Shiloach-Vishkin hook over the owned rows + changed-entries exchange (min) + replicated pointer jumping
  *   pr  : owner-computes pull + all-gather of the owned slices; mode as vgl_hip_pr_run_mode, AUTO is resolved from the GLOBAL edge count
- *         and the GLOBAL longest row so that every rank takes the same path */
+ *         and the GLOBAL longest row so that every rank takes the same path.  The in-degrees minus self loops of all vertices (pr.hpp:31-65)
+ *         are counted and summed over the ranks on the first call with a graph handle and kept with it (the graph does not change) */
 int vgl_hip_bfs_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, int32_t source, int mode, int64_t global_edges,
                             int gather_levels, int32_t *d_levels, vgl_hip_bfs_stats *stats);
 int vgl_hip_sssp_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, const float *d_weights, int32_t source,

@@ -284,3 +284,43 @@ def test_bfs_levels_certificate_accepts_the_levels_and_nothing_else(ctx):
     for sh in shards:
         sh.close()
     g.close()
+
+
+def test_pagerank_step_residual_checks_an_iteration(ctx):
+    """vd.pagerank_step_residual (bench.py --gpus N runs it on every rank at full size): ranks after i + 1 iterations are the f64
+    recomputation of one reference iteration from the ranks after i, on every shard of a cut graph, with the in-degrees summed over the
+    shards; a perturbed entry and a skipped iteration are caught"""
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd import distributed as vd
+    for kind, scale, ef in (("rmat", 14, 8), ("ru", 13, 4)):
+        V = 1 << scale
+        src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, 11)
+        g = api.Graph.from_coo(ctx, V, src, dst, with_incoming=True)
+        r5, _ = api.page_rank(g, 5, raw=True)
+        r6, _ = api.page_rank(g, 6, raw=True)
+        r7, _ = api.page_rank(g, 7, raw=True)
+        bounds = [0, 64 * 29, 64 * 77, V]
+        shards = [g.shard(bounds[i], bounds[i + 1]) for i in range(3)]
+        # (in-degrees over ALL rows: every shard's call is handed the other shards' counts through the callback)
+        counts = []
+
+        def residual(old, new):
+            worst = 0.0
+            for i, sh in enumerate(shards):
+                def add_others(t, i=i):
+                    for j, other in enumerate(shards):
+                        if j != i:
+                            rows = torch.repeat_interleave(torch.arange(other.row_begin, other.row_end, device=t.device),
+                                                           other.out_rowptr[1:] - other.out_rowptr[:-1])
+                            nb = other.out_adj.long()
+                            t += torch.bincount(nb[nb != rows], minlength=V)
+                worst = max(worst, vd.pagerank_step_residual(sh, old, new, add_others, chunk_rows=2048))
+            return worst
+        assert residual(r5, r6) <= 1e-5 and residual(r6, r7) <= 1e-5, kind
+        assert residual(r5, r7) > 1e-4, kind                          # an iteration skipped
+        bad = r6.clone()
+        bad[V // 3] *= 1.001
+        assert residual(r5, bad) > 1e-4, kind
+        for sh in shards:
+            sh.close()
+        g.close()

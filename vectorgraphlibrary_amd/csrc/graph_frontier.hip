@@ -344,7 +344,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->in_nz_rank, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
                     g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->out.hub_rows, g->in.hub_rows, g->out.giant_rows, g->in.giant_rows, g->out.pull_blk_row,
-                    g->in.pull_blk_row, g->out.hub_chunks, g->in.hub_chunks, g->out.hub_chunk_sums, g->in.hub_chunk_sums};
+                    g->in.pull_blk_row, g->out.hub_chunks, g->in.hub_chunks, g->out.hub_chunk_sums, g->in.hub_chunk_sums, g->pr_indeg};
     for (void *p : ptrs) if (p) hipFree(p);
     delete g;
     return 0;

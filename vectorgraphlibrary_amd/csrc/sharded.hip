@@ -131,11 +131,17 @@ int vgl_hip_pr_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g
         VGL_TRY(vgl_comm_allreduce_host_i64(m, &longest, 1, VGL_OP_MAX));
         mode = (global_edges >= (1LL << 25) && longest <= 256) ? VGL_HIP_PR_BLOCKED : VGL_HIP_PR_EXACT_ORDER;
     }
-    int32_t *indeg = g->iscratch;
+    // in-degrees minus self loops of all vertices: a property of the graph (pr.hpp:31-65 recounts them in every run; here they are counted
+    // over the shard's edges -- one atomic per edge without incoming lists -- and summed over the ranks ONCE per graph handle, like a plan)
+    if (!g->pr_indeg_ready) {
+        if (!g->pr_indeg) VGL_HIP_TRY(hipMalloc((void **)&g->pr_indeg, sizeof(int32_t) * (size_t)std::max(V, 1)));
+        VGL_HIP_TRY(hipMemsetAsync(g->pr_indeg, 0, sizeof(int32_t) * (size_t)V, c->stream));
+        VGL_TRY(vgl_hip_indegree_noloops_add(c, g, g->pr_indeg));
+        VGL_TRY(vgl_comm_allreduce(m, g->pr_indeg, V, VGL_DT_I32, VGL_OP_SUM));
+        g->pr_indeg_ready = true;
+    }
+    const int32_t *indeg = g->pr_indeg;
     float *rdeg = g->fscratch2, *contrib = g->fscratch;
-    VGL_HIP_TRY(hipMemsetAsync(indeg, 0, sizeof(int32_t) * (size_t)V, c->stream));
-    VGL_TRY(vgl_hip_indegree_noloops_add(c, g, indeg));
-    VGL_TRY(vgl_comm_allreduce(m, indeg, V, VGL_DT_I32, VGL_OP_SUM));
     const int64_t *bounds = nullptr;
     std::vector<int64_t> bb((size_t)P + 1, 0);
     const bool active = vgl_comm_active(m);

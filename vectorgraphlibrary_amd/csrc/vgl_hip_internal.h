@@ -95,6 +95,8 @@ struct vgl_hip_graph {
                                      // candidates and used to take half of every 128-byte line of the planes
     int32_t *in_nz_rank = nullptr;   // per 64-row group: number of owned rows with incoming edges before the group
     int32_t in_nz_rows = 0;          // owned rows with incoming edges = records per plane
+    int32_t *pr_indeg = nullptr;     // sharded PageRank: in-degrees minus self loops of ALL vertices, summed over the ranks once per graph handle
+    bool pr_indeg_ready = false;
     uint64_t *bm_in_long = nullptr;  // bit v = owned vertex v has more than 8 incoming edges (deferred to the wavefront pass when it misses)
     int32_t *ids = nullptr;          // nrows
     int64_t *offs = nullptr;         // nrows+1

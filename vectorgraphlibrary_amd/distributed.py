@@ -370,6 +370,48 @@ def bfs_levels_certificate(levels, shard, source, chunk_rows=1 << 22):
     return edges_ok, parents_ok
 
 
+def pagerank_step_residual(shard, old, new, allreduce_sum=None, chunk_rows=1 << 22):
+    """One PageRank iteration of the reference recipe (pr.hpp:31-136; oracle/vgl_oracle.c:vgo_pagerank restates it expression for
+    expression) recomputed in f64 with plain torch on ONE shard's rows: max over the owned rows of |new - F(old)| / F(old), where
+    F(old)[u] = k + d * (sum over u's stored neighbours v != u of old[v] * rdeg[v] + dangling).  `old` / `new` are the rank vectors after
+    i and i + 1 iterations (all V entries); allreduce_sum(tensor) adds the in-degree counts of the other ranks' rows (None: one rank).
+    Test / bench infrastructure -- an independent check of a full-size iteration that needs neither the whole graph nor the CPU oracle."""
+    import torch
+    V = int(old.numel())
+    lo, hi = int(shard.row_begin), int(shard.row_end)
+    dev = old.device
+    d32 = torch.tensor(0.85, dtype=torch.float32)
+    k = float(((1.0 - d32.double()) / torch.tensor(float(V), dtype=torch.float32).double()).float())
+    d = float(d32)
+    indeg = torch.zeros(V, dtype=torch.int64, device=dev)
+    nrows = hi - lo
+    for r0 in range(0, nrows, chunk_rows):
+        r1 = min(nrows, r0 + chunk_rows)
+        e0, e1 = int(shard.out_rowptr[r0]), int(shard.out_rowptr[r1])
+        rows = torch.repeat_interleave(torch.arange(lo + r0, lo + r1, device=dev), shard.out_rowptr[r0 + 1:r1 + 1] - shard.out_rowptr[r0:r1])
+        nb = shard.out_adj[e0:e1].long()
+        indeg += torch.bincount(nb[nb != rows], minlength=V)
+        del rows, nb
+    if allreduce_sum is not None:
+        allreduce_sum(indeg)
+    rdeg = torch.where(indeg > 0, (1.0 / indeg.double()).float(), torch.zeros(V, dtype=torch.float32, device=dev)).double()
+    o = old.double()
+    dangling = float(((old / V).double()[indeg == 0]).sum().float())
+    contrib = o * rdeg
+    worst = 0.0
+    for r0 in range(0, nrows, chunk_rows):
+        r1 = min(nrows, r0 + chunk_rows)
+        e0, e1 = int(shard.out_rowptr[r0]), int(shard.out_rowptr[r1])
+        rows = torch.repeat_interleave(torch.arange(r0, r1, device=dev), shard.out_rowptr[r0 + 1:r1 + 1] - shard.out_rowptr[r0:r1])
+        nb = shard.out_adj[e0:e1].long()
+        vals = torch.where(nb != rows + lo, contrib[nb], torch.zeros((), dtype=torch.float64, device=dev))
+        acc = torch.zeros(r1 - r0, dtype=torch.float64, device=dev).index_add_(0, rows - r0, vals)
+        expect = k + d * (acc + dangling)
+        worst = max(worst, float(((new[lo + r0:lo + r1].double() - expect).abs() / expect).max()))
+        del rows, nb, vals, acc, expect
+    return worst
+
+
 def _allreduce(t, op, group):
     if _exchanging(_world(group)[0]):
         dist.all_reduce(t, op=op, group=group)
