@@ -284,7 +284,7 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
             if (sparse_cap > 0 && (M > 0 ? M <= (int64_t)sparse_cap * P / 2 : F <= sparse_cap)) {
                 VGL_TRY(vgl_hip_bitmap_to_ids(c, words, cand, sparse_cap, my_list));
                 VGL_TRY(vgl_comm_allgather(m, my_list, all_lists, sizeof(int32_t) * (size_t)(1 + sparse_cap)));
-                VGL_HIP_TRY(hipMemsetAsync(front_new, 0, sizeof(uint64_t) * (size_t)words, c->stream));
+                VGL_TRY(vgl_zero_words(c, front_new, words));
                 {
                 vgl_timed_launch tl(c, "bfs_shard_resolve");
                 hipLaunchKernelGGL(vgl_k_shard_apply_ids, dim3(128), dim3(VGL_BLOCK), 0, c->stream, P, sparse_cap, (const int32_t *)all_lists, V, g->row_begin,

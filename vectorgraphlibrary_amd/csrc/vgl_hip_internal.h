@@ -159,6 +159,7 @@ int vgl_bfs_bm_gnf(vgl_hip_ctx *c, struct vgl_hip_graph *g, const uint64_t *fron
                    const vgl_do_hint *hint = nullptr);   // d.tile_row / d.ntiles from d.rowptr / d.edges (owned by the caller)
 // set bits of `words` 64-bit words as ids (64 * (word_base + word) + bit): d_out[0] = their number, d_out[1 .. 1 + cap) = the first cap handed out
 int vgl_bitmap_to_ids(vgl_hip_ctx *c, int64_t words, const uint64_t *d_bits, int64_t word_base, int32_t cap, int32_t *d_out);
+int vgl_zero_words(vgl_hip_ctx *c, uint64_t *d_words, int64_t words);      // one launch (bfs.hip)
 
 static inline int64_t vgl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
