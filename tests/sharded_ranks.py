@@ -125,7 +125,10 @@ def main():
         shard = g.shard(lo, hi)
         e_lo, e_hi = g.out_edge_range(lo, hi)
         ws = w[e_lo:e_hi].clone()
-        for cap in ("4096", "0", "8"):                    # id-list exchange of the tiny levels: default bound, off, overflowing
+        for cap in ("4096", "0", "8", "emit0"):           # id-list exchange of the tiny levels: default bound, off, overflowing;
+            if cap == "emit0":                            # ... and every top-down level reading its candidate bitmap off `levels`
+                cap = "4096"
+                os.environ["VGL_SHARD_TD_EMIT_EDGES"] = "0"
             os.environ["VGL_SHARD_SPARSE_CAP"] = cap
             for s in (source, far):
                 for mode in (api.BFS_DIRECTION_OPT, api.BFS_TOP_DOWN):
@@ -135,6 +138,7 @@ def main():
                 levels, _ = vs.bfs_run_sharded(shard, comm, s, api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=False, want_stats=False)
                 assert torch.equal(levels[lo:hi], ref["td", s][lo:hi]), (name, cap, s, "owned only")
         os.environ.pop("VGL_SHARD_SPARSE_CAP")
+        os.environ.pop("VGL_SHARD_TD_EMIT_EDGES", None)
         d, st = vs.sssp_run_sharded(shard, comm, ws, source)
         assert torch.equal(bits(d), bits(d_ref)), name
         ex = comm.stats()

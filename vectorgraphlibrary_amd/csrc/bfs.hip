@@ -1468,16 +1468,33 @@ int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_
 {
     if (!c || !g || !d_levels || !d_visited_bits || !d_front_bits || !d_next_bits) VGL_FAIL("bfs_step_top_down_bits: null argument");
     if (g->row_begin & 63) VGL_FAIL("bfs_step_top_down_bits: the first owned row must be a multiple of 64");
-    VGL_TRY(vgl_zero_words(c, d_next_bits, vgl_ceil_div(g->V, 64)));
     VGL_TRY(vgl_bfs_bm_gnf(c, g, d_front_bits, true, true));     // owned part of the frontier: ids + edge offsets
     const int64_t F = c->h_counters[C_FRONT], M = c->h_counters[C_NEIGH];
     if (local_frontier) *local_frontier = F;
     if (local_edges) *local_edges = M;
+    // Small levels OR every discovery into the candidate bitmap (one device-scope atomic each); a level with many edges leaves its
+    // discoveries in `levels` only -- the value level + 1 is stored by this level and nobody else -- and the bitmap is read off `levels`
+    // afterwards: V * 4 bytes streamed against ~40 us per million edges of atomics (a 4.3 M-edge level of an RMAT-24 traversal: 180 us
+    // with the atomics; the fused traversal draws the same line at V / 24 edges, VGL_TD_EMIT_EDGES)
+    int64_t emit_edges = std::max<int64_t>(65536, (int64_t)g->V / 32);
+    if (const char *e = getenv("VGL_SHARD_TD_EMIT_EDGES")) emit_edges = atoll(e);
+    const bool emit = M <= emit_edges;
+    const int64_t words = vgl_ceil_div(g->V, 64);
+    if (emit) VGL_TRY(vgl_zero_words(c, d_next_bits, words));
     if (F > 0 && M > 0) {                                        // tile_first came with the write pass
         vgl_timed_launch tl(c, "bfs_top_down");
-        hipLaunchKernelGGL((vgl_k_td_expand<true, false>), dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
-                           g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, d_visited_bits, d_levels, level + 1,
-                           d_next_bits, (int64_t *)nullptr, (uint32_t *)nullptr, (int64_t *)nullptr);
+        if (emit)
+            hipLaunchKernelGGL((vgl_k_td_expand<true, false>), dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
+                               g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, d_visited_bits, d_levels, level + 1,
+                               d_next_bits, (int64_t *)nullptr, (uint32_t *)nullptr, (int64_t *)nullptr);
+        else
+            hipLaunchKernelGGL((vgl_k_td_expand<false, false>), dim3((unsigned)vgl_ceil_div(M, VGL_TILE)), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs,
+                               g->tile_first, (int32_t)F, M, g->out.rowptr, g->out.adj, g->row_begin, d_visited_bits, d_levels, level + 1,
+                               d_next_bits, (int64_t *)nullptr, (uint32_t *)nullptr, (int64_t *)nullptr);
+    }
+    if (!emit) {
+        vgl_timed_launch tl(c, "gnf");
+        hipLaunchKernelGGL(vgl_k_levels_to_bitmap<false>, dim3(vgl_grid(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, (const int32_t *)d_levels, level + 1, d_next_bits);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;
