@@ -61,7 +61,9 @@ def test_sharded_loops_world_of_one_equal_fused(ctx):
     assert torch.equal(wd.view(torch.int32), api.sswp(g, w, source, raw=True)[0].view(torch.int32))
     comp, st = vs.cc_run_sharded(g, None)
     comp_ref, st_ref = api.connected_components(g, raw=True)
-    assert torch.equal(comp, comp_ref) and st["hook_passes"] == st_ref["hook_passes"]
+    # (labels are the unique fixed point; the NUMBER of hook passes of the atomic kernel depends on which atomicMin lands first -- 2 or 3
+    # here from run to run -- so only the labels are compared)
+    assert torch.equal(comp, comp_ref) and st["hook_passes"] >= 1 and st_ref["hook_passes"] >= 1
     for mode in (api.PR_EXACT_ORDER, api.PR_BLOCKED):
         ranks, _ = vs.pr_run_sharded(g, None, 4, mode)
         assert torch.equal(ranks.view(torch.int32), api.page_rank(g, 4, raw=True, mode=mode)[0].view(torch.int32))
