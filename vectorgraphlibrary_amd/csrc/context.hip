@@ -2,6 +2,8 @@
 #include "vgl_hip_internal.h"
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <algorithm>
 
 static thread_local std::string g_last_error;
 
@@ -12,6 +14,33 @@ int vgl_set_error(const char *file, int line, const char *msg)
     snprintf(buf, sizeof(buf), "vgl_hip: %s (%s:%d)", msg, base ? base + 1 : file, line);
     g_last_error = buf;
     return 1;
+}
+
+// the library's own stream-ordered pool of a device (vgl_pool_alloc): created once, never the device's default pool
+static hipMemPool_t g_lib_pool[64];
+static bool g_lib_pool_tried[64];
+static std::mutex g_lib_pool_mutex;
+hipMemPool_t vgl_lib_pool(int device)
+{
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_lib_pool_mutex);
+    if (!g_lib_pool_tried[device]) {
+        g_lib_pool_tried[device] = true;
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof(props));
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = device;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+            uint64_t keep = 48ULL << 30;
+            if (const char *e = getenv("VGL_POOL_KEEP_GB")) keep = (uint64_t)std::max(0.0, atof(e)) << 30;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            g_lib_pool[device] = pool;
+        } else (void)hipGetLastError();
+    }
+    return g_lib_pool[device];
 }
 
 extern "C" {
@@ -38,11 +67,6 @@ int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out)
     VGL_HIP_TRY(hipMalloc((void **)&c->d_shards, sizeof(int64_t) * VGL_NSHARD));
     VGL_HIP_TRY(hipMemsetAsync(c->d_shards, 0, sizeof(int64_t) * VGL_NSHARD, c->stream));
     memset(c->h_counters, 0, sizeof(int64_t) * (C_NSLOTS + 8));
-    {   // keep freed pool memory cached (see vgl_pool_alloc)
-        hipMemPool_t pool = nullptr;
-        uint64_t keep = UINT64_MAX;
-        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
     *out = c;
     return 0;
 }
@@ -51,9 +75,7 @@ int vgl_hip_ctx_trim(vgl_hip_ctx *c)
 {
     if (!c) VGL_FAIL("null context");
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
-    hipMemPool_t pool = nullptr;
-    VGL_HIP_TRY(hipDeviceGetDefaultMemPool(&pool, c->device));
-    VGL_HIP_TRY(hipMemPoolTrimTo(pool, 0));
+    if (hipMemPool_t pool = vgl_lib_pool(c->device)) VGL_HIP_TRY(hipMemPoolTrimTo(pool, 0));
     return 0;
 }
 
@@ -62,6 +84,7 @@ int vgl_hip_ctx_destroy(vgl_hip_ctx *c)
     if (!c) return 0;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (hipMemPool_t pool = vgl_lib_pool(c->device)) (void)hipMemPoolTrimTo(pool, 0);      // cached plan-build memory goes back to the device
     for (auto &kv : c->slots)
         for (auto &p : kv.second.pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);

@@ -163,11 +163,19 @@ int vgl_zero_words(vgl_hip_ctx *c, uint64_t *d_words, int64_t words);      // on
 
 static inline int64_t vgl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Large, short-lived or plan-sized device buffers come from the device's stream-ordered memory pool (hipMallocAsync on the context's
-// stream; the pool keeps what is freed -- release threshold set at context creation): a plain hipMalloc right after tens of GB were
-// hipFree'd was measured to stall for 0.5 - 1.3 s on this driver, and fresh mappings cost ~14 ms per GB on first touch; pool memory that
-// has been used once costs neither.  vgl_hip_ctx_trim hands the cached memory back.
-static inline hipError_t vgl_pool_alloc(hipStream_t st, void **p, size_t bytes) { return hipMallocAsync(p, bytes ? bytes : 16, st); }
+// Large, short-lived or plan-sized device buffers come from a stream-ordered memory pool OWNED BY THIS LIBRARY (one per device, created on
+// first use: hipMemPoolCreate + hipMallocFromPoolAsync on the context's stream; the device's default pool, which other hipMallocAsync
+// users of the process share, is left as it was found).  The pool keeps what is freed up to VGL_POOL_KEEP_GB (default 48 GiB): a plain
+// hipMalloc right after tens of GB were hipFree'd was measured to stall for 0.5 - 1.3 s on this driver, and fresh mappings cost ~14 ms
+// per GB on first touch; pool memory that has been used once costs neither.  vgl_hip_ctx_trim / vgl_hip_ctx_destroy hand it back.
+hipMemPool_t vgl_lib_pool(int device);          // context.hip; nullptr when the pool could not be created (callers fall back to hipMallocAsync)
+static inline hipError_t vgl_pool_alloc(hipStream_t st, void **p, size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess)
+        if (hipMemPool_t pool = vgl_lib_pool(dev)) return hipMallocFromPoolAsync(p, bytes ? bytes : 16, pool, st);
+    return hipMallocAsync(p, bytes ? bytes : 16, st);
+}
 static inline void vgl_pool_free(hipStream_t st, void *p) { if (p) (void)hipFreeAsync(p, st); }
 
 // ---------------------------------------------------------------------------------------------

@@ -371,7 +371,7 @@ def bfs_levels_certificate(levels, shard, source, chunk_rows=1 << 22):
 
 
 def pagerank_step_residual(shard, old, new, allreduce_sum=None, chunk_rows=1 << 22):
-    """One PageRank iteration of the reference recipe (pr.hpp:31-136; oracle/vgl_oracle.c:vgo_pagerank restates it expression for
+    """One PageRank iteration of the reference recipe (pr.hpp:31-136; the CPU checker restates it expression for
     expression) recomputed in f64 with plain torch on ONE shard's rows: max over the owned rows of |new - F(old)| / F(old), where
     F(old)[u] = k + d * (sum over u's stored neighbours v != u of old[v] * rdeg[v] + dangling).  `old` / `new` are the rank vectors after
     i and i + 1 iterations (all V entries); allreduce_sum(tensor) adds the in-degree counts of the other ranks' rows (None: one rank).
