@@ -30,6 +30,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
                     env = {} if k == 0 else {"VGL_BFS_SMALL_M": str(int(rng.choice([0, 64, 300, 8192, 1000000]))), "VGL_BFS_BM_EXPAND": str(int(rng.choice([0, 100, 262144, 1 << 30])))}
                     if k == 2 and seed % 2: env["VGL_BFS_NO_HINT"] = "1"      # (round 3: the count launch walks the new frontier instead of taking F and M from its producer)
                     if k == 1 and seed % 3 == 0: env["VGL_TD_EMIT_EDGES"] = str(int(rng.choice([0, 4096, 1 << 40])))
+                    if k == 2 and seed % 3: env["VGL_BFS_NO_SCAN_BOUND"] = "1"    # (round 4: the scanning frontier generation with a lower bound of M)
+                    if k == 1 and seed % 2: env["VGL_TD_FILTER_SHARE"] = str(rng.choice([0, 2]))      # (round 4: visited-bitmap probe always / never)
                     os.environ.update(env)
                     try:
                         lv, st = api.bfs(g, source, mode)

@@ -64,7 +64,11 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_first(int32_t F, const i
 // COUNT (with EMIT): the vertex's one claimer -- the atomicOr whose return value lacks the bit -- also counts it and adds its out-degree; the
 // last workgroup leaves the sums in counters[C_NEXT_F / C_NEXT_M] for the count launch that follows (vgl_k_bm_gnf_count: when they say
 // "bottom-up next" it does not walk the new frontier's rows at all).
-template <bool EMIT, bool COUNT>
+// FILTER = false (round 4): the visited-bitmap probe is left out.  While a traversal is still growing almost no destination has its bit set, so
+// the probe is one scattered L2 request per edge that rules nothing out; `levels[dst] == -1` alone decides.  The caller keeps the probe once a
+// sizeable part of the vertices has been visited (the shrinking phase after the bottom-up levels), where it saves the levels sector.  Worth
+// 1.5 - 3 us per RMAT-24 traversal (profiles/r04_bfs_ab.log): this kernel does not follow its request count either.
+template <bool EMIT, bool COUNT, bool FILTER = true>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids, const int64_t *offs, const int32_t *tile_first,
                                                              int32_t F, int64_t M, const int64_t *rowptr, const int32_t *adj,
                                                              int32_t row_base, const uint64_t *visited, int32_t *levels,
@@ -110,13 +114,18 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_td_expand(const int32_t *ids,
     bool unvis[VGL_EPT];
     bool fresh[VGL_EPT];
 #if VGL_TD_BATCH & 1
+    if (FILTER) {
 #pragma unroll
-    for (int j = 0; j < VGL_EPT; j++) vw[j] = visited[max(dsts[j], 0) >> 6];
+        for (int j = 0; j < VGL_EPT; j++) vw[j] = visited[max(dsts[j], 0) >> 6];
 #pragma unroll
-    for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0 && !((vw[j] >> (dsts[j] & 63)) & 1ULL);
+        for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0 && !((vw[j] >> (dsts[j] & 63)) & 1ULL);
+    } else {
+#pragma unroll
+        for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0;
+    }
 #else
 #pragma unroll
-    for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0 && !((visited[dsts[j] >> 6] >> (dsts[j] & 63)) & 1ULL);
+    for (int j = 0; j < VGL_EPT; j++) unvis[j] = dsts[j] >= 0 && (!FILTER || !((visited[dsts[j] >> 6] >> (dsts[j] & 63)) & 1ULL));
 #endif
 #if VGL_TD_BATCH & 2
     int32_t lv[VGL_EPT];
@@ -335,6 +344,45 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
         vgl_publish2(counters, host, seq, C_FRONT, (int64_t)ctot, C_NEIGH, dtot);
     }
 }
+// ---- the frontier generation after a large (non-emitting) top-down level, when all the traversal may need of it is the BITMAPS ----
+// Such a level leaves its discoveries in `levels` only, and vgl_k_gnf_count<vgl_pred_equal_i32> rebuilds bitmaps, F and M from them: 64 MiB
+// of levels plus the row offsets of every frontier vertex (up to 128 MiB more) -- 52 us on RMAT-24, more than the level itself -- and right
+// after it the direction rule usually turns the traversal bottom-up, which needs the bitmaps and F but of M only "at least the threshold".
+// This pass reads the levels alone: bitmaps, F, and a LOWER BOUND of M from the per-tile frontier sizes times the smallest out-degree of
+// the tile (vt_min_deg; on a degree-sorted graph the rows of a tile have similar degrees, so the bound is tight where the edges are).
+// When the bound already satisfies the rule the traversal goes on bottom-up; otherwise the exact sizes are taken from the bitmap just built
+// (vgl_k_bm_gnf_count), not from a second scan of the levels.  Frontier generations 24.5 -> 17.5 us per RMAT-24 traversal.
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bfs_scan_bound(int32_t nrows, int32_t row_base, const int32_t *levels, int32_t level,
+                                                                 const int32_t *vt_min_deg, uint8_t *front_bytes, uint8_t *visited_bytes,
+                                                                 int64_t *partials, uint32_t *ticket, int64_t *counters,
+                                                                 volatile int64_t *host, int64_t seq)
+{
+    __shared__ int s32[VGL_WAVES];
+    __shared__ int64_t s64[VGL_WAVES];
+    const int32_t r0 = blockIdx.x * VGL_TILE + threadIdx.x * VGL_EPT;
+    int cnt = 0;
+    if (r0 < nrows) {
+        const int nvalid = min(VGL_EPT, nrows - r0);
+        const int32_t v0 = row_base + r0;
+        uint32_t aux;
+        const vgl_pred_equal_i32 pred{levels, level};
+        const uint32_t bits = pred.bits8(v0, nvalid, &aux);
+        cnt = __popc(bits);
+        front_bytes[v0 >> 3] = (uint8_t)bits;
+        visited_bytes[v0 >> 3] = (uint8_t)aux;
+    }
+    const int tc = vgl_block_reduce_add(cnt, s32);
+    uint32_t dep = 0;
+    if (threadIdx.x == 0)
+        dep = vgl_put_agent(partials + 2 * blockIdx.x, (int64_t)tc) ^ vgl_put_agent(partials + 2 * blockIdx.x + 1, (int64_t)tc * (int64_t)vt_min_deg[blockIdx.x]);
+    if (!vgl_last_block(ticket, dep)) return;
+    int64_t f = 0, m = 0;
+    for (int t = threadIdx.x; t < (int)gridDim.x; t += VGL_BLOCK) { f += vgl_load_agent(partials + 2 * t); m += vgl_load_agent(partials + 2 * t + 1); }
+    f = vgl_block_reduce_add(f, s64);
+    m = vgl_block_reduce_add(m, s64);
+    if (threadIdx.x == 0) vgl_publish2(counters, host, seq, C_FRONT, f, C_NEIGH, m);
+}
+
 // write pass; also fills tile_first (the frontier position that owns edge t*VGL_TILE, and, in entry [#tiles], the owner of the
 // last edge) -- every frontier vertex knows its own edge range, so the separate vgl_k_tile_first launch is not needed
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, int64_t word0, int32_t row_base, const uint64_t *front,
@@ -1065,7 +1113,7 @@ static inline unsigned vgl_grid(int64_t n, int64_t cap = 8192) { return (unsigne
 // expand frontier (ids/offs with F vertices, M edges already produced by a frontier-generation write pass)
 constexpr int64_t VGL_TD_COUNT_TILES = 8192;           // (the counting level's partial sums live in g->bu_partials: 4 * 4096 slots)
 static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_t M, int32_t *levels, int32_t next_level, bool emit,
-                             bool have_tile_first, bool count = false)
+                             bool have_tile_first, bool count = false, bool filter = true)
 {
     if (F <= 0 || M <= 0) return 0;
     if (!have_tile_first) hipLaunchKernelGGL(vgl_k_tile_first, dim3(vgl_grid(F)), dim3(VGL_BLOCK), 0, c->stream, F, g->offs, g->tile_first);
@@ -1074,16 +1122,21 @@ static int vgl_bfs_td_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t F, int64_
         vgl_timed_launch tl(c, "bfs_top_down");
         int64_t *no_i64 = nullptr;
         uint32_t *no_u32 = nullptr;
-        if (emit && count)
-            hipLaunchKernelGGL((vgl_k_td_expand<true, true>), dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next, g->bu_partials,
-                               g->tickets + 3 * VGL_TICKET_WORDS, c->d_counters);
-        else if (emit)
-            hipLaunchKernelGGL((vgl_k_td_expand<true, false>), dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next, no_i64, no_u32, no_i64);
-        else
-            hipLaunchKernelGGL((vgl_k_td_expand<false, false>), dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F, M,
-                               g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next, no_i64, no_u32, no_i64);
+#define VGL_TD_LAUNCH(E, C, F, PARTIALS, TICKET, COUNTERS)                                                                                          \
+        hipLaunchKernelGGL((vgl_k_td_expand<E, C, F>), dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, g->ids, g->offs, g->tile_first, F_, M, \
+                           g->out.rowptr, g->out.adj, g->row_begin, g->bm_visited, levels, next_level, g->bm_next, PARTIALS, TICKET, COUNTERS)
+        const int32_t F_ = F;
+        if (emit && count) {
+            if (filter) VGL_TD_LAUNCH(true, true, true, g->bu_partials, g->tickets + 3 * VGL_TICKET_WORDS, c->d_counters);
+            else VGL_TD_LAUNCH(true, true, false, g->bu_partials, g->tickets + 3 * VGL_TICKET_WORDS, c->d_counters);
+        } else if (emit) {
+            if (filter) VGL_TD_LAUNCH(true, false, true, no_i64, no_u32, no_i64);
+            else VGL_TD_LAUNCH(true, false, false, no_i64, no_u32, no_i64);
+        } else {
+            if (filter) VGL_TD_LAUNCH(false, false, true, no_i64, no_u32, no_i64);
+            else VGL_TD_LAUNCH(false, false, false, no_i64, no_u32, no_i64);
+        }
+#undef VGL_TD_LAUNCH
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;
@@ -1263,6 +1316,8 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     // 16 M edges 0.392 ms, 4 M 0.377, 2 M 0.381, 1 M 0.366, 512 K 0.361, 256 K 0.364.
     int64_t VGL_TD_EMIT_EDGES = std::max<int64_t>(65536, (int64_t)V / 24);
     if (const char *e = getenv("VGL_TD_EMIT_EDGES")) VGL_TD_EMIT_EDGES = atoll(e);
+    double td_filter_share = 0.125;
+    if (const char *e = getenv("VGL_TD_FILTER_SHARE")) td_filter_share = atof(e);
     int bu_in_a_row = 0;                                 // bottom-up levels since the last top-down one
     int later_heavy_blocks = 256;                        // RMAT-24 traversal: 0.376 ms with 2048, 0.368-0.370 with 512 / 256 / 128
     if (const char *e = getenv("VGL_BU_LATER_HEAVY_BLOCKS")) later_heavy_blocks = std::max(1, std::min(VGL_BU_BLOCKS, atoi(e)));
@@ -1274,6 +1329,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     // rule turns the level bottom-up (`skipped`; the rule below must -- and does, same integers -- come to the same conclusion)
     bool hint_ready = false, skipped = false;
     const bool use_hints = mode == VGL_HIP_BFS_DIRECTION_OPT && !(getenv("VGL_BFS_NO_HINT") && getenv("VGL_BFS_NO_HINT")[0] == '1');
+    const bool scan_bound = mode == VGL_HIP_BFS_DIRECTION_OPT && !(getenv("VGL_BFS_NO_SCAN_BOUND") && getenv("VGL_BFS_NO_SCAN_BOUND")[0] == '1');
     auto count_frontier = [&]() -> int {
         skipped = false;
         if (front_valid) {
@@ -1282,6 +1338,26 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false, -1, advance_pending, hinted ? &hint : nullptr));
             skipped = hinted && c->h_counters[C_SKIPPED] != 0;
             counted_from_bitmap = true; advance_pending = false;
+        }
+        else if (scan_bound && g->nvtiles <= 8192) {           // (per-tile partials live in g->bu_partials: 4 * 4096 slots)
+            const int64_t seq = vgl_next_seq(c);
+            {
+                vgl_timed_launch tl(c, "gnf");
+                hipLaunchKernelGGL(vgl_k_bfs_scan_bound, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->row_begin, (const int32_t *)d_levels,
+                                   cur, (const int32_t *)g->vt_min_deg, (uint8_t *)g->bm_front, (uint8_t *)g->bm_visited, g->bu_partials,
+                                   g->tickets + 0 * VGL_TICKET_WORDS, c->d_counters, (volatile int64_t *)c->h_counters, seq);
+            }
+            VGL_HIP_TRY(hipGetLastError());
+            VGL_TRY(vgl_wait_counters(c, seq));
+            front_valid = true; advance_pending = false;
+            const int64_t f = c->h_counters[C_FRONT], m_lb = c->h_counters[C_NEIGH];
+            if (f > prevF && m_lb >= ((V - (visited_total + f)) * factor + V) / VGL_DO_ALPHA) {
+                // bottom-up whatever the exact edge count is (the rule below sees M = the bound and comes to the same conclusion)
+                F = f; M = m_lb; counted = false; skipped = true; hint_ready = false;
+                return 0;
+            }
+            VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_front, true, false, -1, false, nullptr));      // exact sizes off the bitmap
+            counted_from_bitmap = true;
         }
         else {
             vgl_pred_equal_i32 pred{d_levels, cur};
@@ -1408,7 +1484,9 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
             }
             const bool emit = M <= VGL_TD_EMIT_EDGES;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
             const bool td_counts = emit && use_hints && vgl_ceil_div(M, VGL_TILE) <= VGL_TD_COUNT_TILES;
-            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap, td_counts));
+            // the visited-bitmap probe pays once a good part of the vertices is visited (VGL_TD_FILTER_SHARE of V; 0 = always, 2 = never)
+            const bool filter = (double)visited_total >= td_filter_share * (double)V;
+            VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap, td_counts, filter));
             hint_ready = td_counts && F > 0 && M > 0;     // (a level without edges launches nothing: C_NEXT_* would be another traversal's)
             advance_pending = emit;          // a top-down level is always followed by count_frontier (or the loop ends below)
             front_valid = emit;

@@ -47,6 +47,21 @@ __global__ __launch_bounds__(1024) void vgl_k_nz_rank(int64_t ngroups, const uin
     if (threadIdx.x == 0) rank[ngroups] = total;
 }
 
+// vt_min[t] = smallest degree among the rows of vertex tile t (2048 rows)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_tile_min_degree(int32_t nrows, const int64_t *rowptr, int32_t *vt_min)
+{
+    __shared__ int s_min[VGL_WAVES];
+    const int32_t r0 = blockIdx.x * VGL_TILE;
+    int64_t m = INT32_MAX;
+    for (int32_t r = r0 + threadIdx.x; r < min(nrows, r0 + VGL_TILE); r += VGL_BLOCK) m = min(m, rowptr[r + 1] - rowptr[r]);
+    int mi = (int)m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mi = min(mi, __shfl_xor(mi, o));
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mi;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < VGL_WAVES; w++) mi = min(mi, s_min[w]); vt_min[blockIdx.x] = mi; }
+}
+
 // The eight smallest distinct ids seen so far, ascending (INT32_MAX = free slot); `overflow` = a distinct id did not fit.
 struct vgl_small8 {
     int32_t a[8];
@@ -296,6 +311,8 @@ int vgl_hip_graph_create(vgl_hip_ctx *c, int32_t V, int32_t row_begin, int32_t r
     VGL_TRY(vgl_alloc(&g->vt_cnt_off, (size_t)g->nvtiles));
     VGL_TRY(vgl_alloc(&g->vt_deg, (size_t)g->nvtiles));
     VGL_TRY(vgl_alloc(&g->vt_deg_off, (size_t)g->nvtiles));
+    VGL_TRY(vgl_alloc(&g->vt_min_deg, (size_t)g->nvtiles));
+    hipLaunchKernelGGL(vgl_k_tile_min_degree, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, g->nrows, g->out.rowptr, g->vt_min_deg);
     VGL_TRY(vgl_alloc(&g->tile_first, (size_t)g->out.ntiles + 2));
     VGL_TRY(vgl_alloc(&g->heavy, (size_t)g->nrows + 4096 * VGL_BLOCK));
     VGL_TRY(vgl_alloc(&g->heavy_cnt, (size_t)4096));
@@ -344,7 +361,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->in_nz_rank, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
                     g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->out.hub_rows, g->in.hub_rows, g->out.giant_rows, g->in.giant_rows, g->out.pull_blk_row,
-                    g->in.pull_blk_row, g->out.hub_chunks, g->in.hub_chunks, g->out.hub_chunk_sums, g->in.hub_chunk_sums, g->pr_indeg};
+                    g->in.pull_blk_row, g->vt_min_deg, g->out.hub_chunks, g->in.hub_chunks, g->out.hub_chunk_sums, g->in.hub_chunk_sums, g->pr_indeg};
     for (void *p : ptrs) if (p) hipFree(p);
     delete g;
     return 0;

@@ -103,6 +103,7 @@ struct vgl_hip_graph {
     int32_t *vt_cnt = nullptr, *vt_cnt_off = nullptr;   // per vertex tile
     int64_t *vt_deg = nullptr, *vt_deg_off = nullptr;
     int64_t nvtiles = 0;
+    int32_t *vt_min_deg = nullptr;   // per vertex tile: smallest out-degree of its rows (lower bound of a frontier's edge count from its per-tile sizes)
     int32_t *tile_first = nullptr;   // out.ntiles + 2
     int32_t *heavy = nullptr;        // nrows + slack: per-workgroup segments of deferred bottom-up vertices
     int32_t *heavy_cnt = nullptr;    // one count per bottom-up workgroup
