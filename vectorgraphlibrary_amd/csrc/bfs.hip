@@ -1314,7 +1314,11 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     // An emitting level pays one device-scope atomicOr per discovery, a plain one a scan of `levels` (V * 4 bytes) by the next frontier
     // generation: the bitmap pays only while the level is small against V.  RMAT-24 (V = 16.8 M), direction-optimising traversal: bound
     // 16 M edges 0.392 ms, 4 M 0.377, 2 M 0.381, 1 M 0.366, 512 K 0.361, 256 K 0.364.
-    int64_t VGL_TD_EMIT_EDGES = std::max<int64_t>(65536, (int64_t)V / 24);
+    // Round 4: 64 K edges on RMAT-24 (V / 256).  The emitting form is dearer than round 2 priced it -- its atomics go to the memory side at
+    // ~2.6e10 /s when they scatter and SERIALISE at ~12 ns each when they meet (profiles/r04_atomic_scope_bench.log; every edge into a popular
+    // vertex that arrives before the first store is visible issues its own: a 500 K-edge level took 170 us) -- and the scan it avoids is
+    // cheaper (vgl_k_bfs_scan_bound: 13 us): V / 24 0.317 ms per traversal, V / 64 0.305, V / 256 0.3047, V / 1024 0.306, never 0.317.
+    int64_t VGL_TD_EMIT_EDGES = std::max<int64_t>(65536, (int64_t)V / 256);
     if (const char *e = getenv("VGL_TD_EMIT_EDGES")) VGL_TD_EMIT_EDGES = atoll(e);
     double td_filter_share = 0.125;
     if (const char *e = getenv("VGL_TD_FILTER_SHARE")) td_filter_share = atof(e);
@@ -1554,7 +1558,7 @@ int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_
     // discoveries in `levels` only -- the value level + 1 is stored by this level and nobody else -- and the bitmap is read off `levels`
     // afterwards: V * 4 bytes streamed against ~40 us per million edges of atomics (a 4.3 M-edge level of an RMAT-24 traversal: 180 us
     // with the atomics; the fused traversal draws the same line at V / 24 edges, VGL_TD_EMIT_EDGES)
-    int64_t emit_edges = std::max<int64_t>(65536, (int64_t)g->V / 32);
+    int64_t emit_edges = std::max<int64_t>(65536, (int64_t)g->V / 256);        // (round 4: as VGL_TD_EMIT_EDGES of the fused traversal)
     if (const char *e = getenv("VGL_SHARD_TD_EMIT_EDGES")) emit_edges = atoll(e);
     const bool emit = M <= emit_edges;
     const int64_t words = vgl_ceil_div(g->V, 64);
