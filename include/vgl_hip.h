@@ -384,11 +384,19 @@ typedef struct vgl_hip_comm vgl_hip_comm;
 #define VGL_HIP_COMM_ID_BYTES 128
 #define VGL_HIP_COMM_RCCL 0
 #define VGL_HIP_COMM_HOSTED 1
+#define VGL_HIP_COMM_PEER 2
 /* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any means (file, socket, MPI, torch store) */
 int vgl_hip_comm_unique_id(void *id_out);
 int vgl_hip_comm_create(vgl_hip_ctx *ctx, int rank, int world, const void *unique_id, vgl_hip_comm **out);
 /* name: shared-memory object name common to the ranks ("/vgl_job42"); slot_bytes: staging capacity per rank (larger payloads go in pieces) */
 int vgl_hip_comm_create_hosted(vgl_hip_ctx *ctx, int rank, int world, const char *name, size_t slot_bytes, vgl_hip_comm **out);
+/* Transport PEER (round 4; what the reference hand-rolls with MPI point-to-point messages, vgl_compute_api/common/mpi_exchange.hpp:110-187,222-271):
+ * every rank owns a window in device memory that the other ranks map (hipIpc; ranks = GPUs of one node over xGMI, or processes / threads
+ * sharing one GPU) and write into from kernels on their own streams; arrival and consumption flags live in the windows; the exchanges of
+ * a group share one flag round.  No collective library and no host in the data path.  name: shared-memory object used for the set-up
+ * handshake only; window_bytes: capacity of one of the two halves of a window (larger payloads go in pieces).  Fails -- on every rank alike --
+ * when a window cannot be mapped by a peer: fall back to vgl_hip_comm_create (RCCL). */
+int vgl_hip_comm_create_peer(vgl_hip_ctx *ctx, int rank, int world, const char *name, size_t window_bytes, vgl_hip_comm **out);
 int vgl_hip_comm_destroy(vgl_hip_comm *comm);
 int vgl_hip_comm_info(vgl_hip_comm *comm, int *rank, int *world, int *transport);
 int vgl_hip_comm_barrier(vgl_hip_comm *comm);            /* drains the stream, meets the other ranks */
@@ -440,7 +448,7 @@ int vgl_hip_pr_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *
  * used pair lists / the whole-array all-reduce / id lists (BFS) */
 typedef struct {
     int64_t collectives, bytes_received;
-    int32_t list_steps, dense_steps, sparse_levels, reserved;
+    int32_t list_steps, dense_steps, sparse_levels, exchanges;      /* exchanges: flag rounds of the PEER transport (the collectives of a group share one) */
 } vgl_hip_exchange_stats;
 int vgl_hip_comm_stats(vgl_hip_comm *comm, vgl_hip_exchange_stats *out);
 

@@ -4,14 +4,20 @@ its own context / stream / dealt shard of RMAT-<scale> and a communicator over t
 that between two exchanges the ranks work one at a time and every rank's HIP-event kernel times are those of its own work.  What it
 reports per traversal: kernel time per rank (step kernels, frontier generation, owner resolve), collectives and bytes received per rank --
 i.e. everything of an 8-GPU traversal except the time of the RCCL collectives themselves.
-usage: rehearse_sharded.py [scale=27] [ranks=8] [sources=4]"""
+usage: rehearse_sharded.py [scale=27] [ranks=8] [sources=4] [transport=hosted|peer]
+transport peer (round 4): the rank threads write into each other's device windows (PEER transport; nothing serialises them, so the kernel
+times include waiting for the other ranks that share the card): what it reports then is the protocol -- flag rounds and bytes per level."""
 import os
 import sys
 import threading
 import time
 import uuid
 
-os.environ["VGL_HOSTED_SERIALIZE"] = "1"
+TRANSPORT = sys.argv[4] if len(sys.argv) > 4 else "hosted"
+if TRANSPORT == "hosted":
+    os.environ["VGL_HOSTED_SERIALIZE"] = "1"
+else:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"            # every rank thread's stream on a hardware queue of its own: a polling kernel must not sit in front of a peer's put
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch  # noqa: E402
 from vectorgraphlibrary_amd import api  # noqa: E402
@@ -51,7 +57,7 @@ def rank_main(r):
             ctx = api.Context(0)                       # binds this thread's stream
             orp, oadj, irp, iadj, lo, hi = shards[r]
             shard = api.Graph(ctx, V, orp, oadj, irp, iadj, lo, hi)
-            comm = vs.Comm.hosted(ctx, r, P, name, slot_bytes=32 << 20)
+            comm = vs.Comm.hosted(ctx, r, P, name, slot_bytes=32 << 20) if TRANSPORT == "hosted" else vs.Comm.peer(ctx, r, P, name, window_bytes=48 << 20)
             levels = torch.empty(V, dtype=torch.int32, device=ctx.device)
             vs.bfs_run_sharded(shard, comm, sources[0], api.BFS_DIRECTION_OPT, global_edges=E, gather_levels=False, levels=levels, want_stats=False)   # warm-up
             per = []
@@ -87,7 +93,9 @@ for i, s in enumerate(sources[1:]):
     print(f"source {s}: {st0['levels']} levels ({st0['td_steps']} top-down, {st0['bu_steps']} bottom-up); kernel ms per rank: "
           + " ".join(f"{x:.3f}" for x in kern) + f"  (max {max(kern):.3f}, sum {sum(kern):.3f});  "
           + "rank 0 by kernel: " + ", ".join(f"{n} {c}x {ms:.3f}" for n, (c, ms) in rows[0][1].items())
-          + f";  exchange per rank: {rows[0][2]['collectives']} collectives, {rows[0][2]['bytes_received'] / 2**20:.1f} MiB received, {rows[0][2]['sparse_levels']} id-list levels", flush=True)
+          + f";  exchange per rank: {rows[0][2]['collectives']} collectives"
+          + (f" in {rows[0][2]['exchanges']} flag rounds ({rows[0][2]['exchanges'] / st0['levels']:.2f} per level)" if TRANSPORT == "peer" else "")
+          + f", {rows[0][2]['bytes_received'] / 2**20:.1f} MiB received, {rows[0][2]['sparse_levels']} id-list levels", flush=True)
 print("breadth-first certificate of the last traversal (out-edges never skip a level / every reached vertex has a parent one level up), per rank:",
       " ".join("%s/%s" % ("ok" if e else "FAIL", "ok" if p else "FAIL") for e, p in certs), flush=True)
 if not all(e and p for e, p in certs):

@@ -4,6 +4,7 @@ single-GPU fused results itself and compares the sharded results with them bit f
 
     python tests/sharded_ranks.py rccl   RANK WORLD ID_FILE     one GPU per rank (a world of one + VGL_SHARD_FORCE_COLLECTIVES=1 on the one-GPU box)
     python tests/sharded_ranks.py hosted RANK WORLD SHM_NAME    ranks share cuda:0 through the host-staged transport
+    python tests/sharded_ranks.py peer   RANK WORLD SHM_NAME    ranks share cuda:0 and write into each other's hipIpc-mapped windows (PEER)
 
 Prints 'SHARDED_RANK_OK' on success."""
 import os
@@ -83,9 +84,11 @@ def check_exchanges(ctx, comm):
 
 def main():
     transport, rank, world, token = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-    ctx = api.Context(0 if transport == "hosted" else int(os.environ.get("LOCAL_RANK", rank)))
+    ctx = api.Context(0 if transport in ("hosted", "peer") else int(os.environ.get("LOCAL_RANK", rank)))
     if transport == "hosted":
         comm = vs.Comm.hosted(ctx, rank, world, token, slot_bytes=1 << 16)          # small slots: every large payload goes in pieces
+    elif transport == "peer":
+        comm = vs.Comm.peer(ctx, rank, world, token, window_bytes=int(os.environ.get("VGL_TEST_PEER_WINDOW", 1 << 16)))      # small windows: pieces
     else:
         if rank == 0:
             with open(token + ".tmp", "wb") as f:

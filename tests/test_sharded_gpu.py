@@ -20,7 +20,7 @@ HELPER = os.path.join(ROOT, "tests", "sharded_ranks.py")
 
 
 def _run_ranks(transport, world, env_extra=None, timeout=900):
-    token = ("/vgl_t_%s" % uuid.uuid4().hex[:12]) if transport == "hosted" else os.path.join("/tmp", "vgl_id_%s" % uuid.uuid4().hex[:12])
+    token = ("/vgl_t_%s" % uuid.uuid4().hex[:12]) if transport in ("hosted", "peer") else os.path.join("/tmp", "vgl_id_%s" % uuid.uuid4().hex[:12])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, HELPER, transport, str(r), str(world), token], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
@@ -33,7 +33,7 @@ def _run_ranks(transport, world, env_extra=None, timeout=900):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        if transport != "hosted" and os.path.exists(token):
+        if transport not in ("hosted", "peer") and os.path.exists(token):
             os.remove(token)
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "SHARDED_RANK_OK" in o, "rank %d failed:\n%s\n%s" % (r, o[-3000:], e[-3000:])
@@ -82,6 +82,15 @@ def test_sharded_loops_one_rank_rccl_through_the_c_abi(ctx):
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_loops_ranks_sharing_the_gpu_hosted_transport(ctx, world):
     _run_ranks("hosted", world)
+
+
+@pytest.mark.parametrize("world,window", [(2, 1 << 16), (4, 1 << 16), (4, 8 << 20)])
+def test_sharded_loops_ranks_sharing_the_gpu_peer_transport(ctx, world, window):
+    """PEER transport (round 4): every rank is a PROCESS that maps the other ranks' device windows through hipIpc and writes its
+    contributions into them from kernels; arrival / consumption flags in device memory.  All exchanges and all five drivers, bit-identical to
+    the single-GPU results; 64 KiB windows send every large payload in pieces, 8 MiB windows send it whole.  (The box admits six processes on
+    the card: four ranks + this one; eight ranks run as threads of one process in profiles/microbench/rehearse_sharded.py.)"""
+    _run_ranks("peer", world, {"VGL_TEST_PEER_WINDOW": str(window)})
 
 
 def test_pagerank_auto_is_resolved_globally(ctx):

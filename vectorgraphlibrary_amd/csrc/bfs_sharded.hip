@@ -313,9 +313,14 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
             const bool hand_round = direction_opt && (bottom_up || !been_bottom_up);
             replicated = hand_round || !active;
             vgl_comm_group_begin(m);
-            if (active && hand_round) VGL_TRY(vgl_comm_allgatherv_inplace(m, front_new, word_bb.data()));
-            VGL_TRY(vgl_comm_allgather(m, my_counts, all_counts, sizeof(int64_t) * 4));
-            VGL_TRY(vgl_comm_group_end(m));
+            {
+                // (a failing collective must not leave the group open: every later collective would queue behind it for ever)
+                int rc = 0;
+                if (active && hand_round) rc = vgl_comm_allgatherv_inplace(m, front_new, word_bb.data());
+                if (!rc) rc = vgl_comm_allgather(m, my_counts, all_counts, sizeof(int64_t) * 4);
+                const int rc_end = vgl_comm_group_end(m);
+                if (rc || rc_end) return 1;
+            }
             VGL_TRY(vgl_comm_read_small(m, all_counts, 4 * P, h_counts));
         }
         F = 0; M = 0;

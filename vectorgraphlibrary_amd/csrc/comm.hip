@@ -42,7 +42,7 @@ static inline char *vgl_hosted_slot(vgl_hip_comm *m, int p) { return reinterpret
 
 // VGL_HOSTED_SERIALIZE=1 (rehearsals of more ranks than GPUs): between two barriers the ranks work ONE AT A TIME, in rank order, so that the
 // kernel times a rank measures with HIP events are those of its own work, not of P processes or threads sharing the card.
-static int vgl_hosted_barrier(vgl_hip_comm *m)
+int vgl_hosted_barrier(vgl_hip_comm *m)
 {
     vgl_hosted_header *h = m->shm;
     static const bool serialize = getenv("VGL_HOSTED_SERIALIZE") && getenv("VGL_HOSTED_SERIALIZE")[0] == '1';
@@ -176,7 +176,7 @@ static int vgl_fold_launch(vgl_hip_ctx *c, int64_t n, int parts, const void *in,
 
 static size_t vgl_dt_bytes(int dtype) { return (dtype == VGL_DT_I32 || dtype == VGL_DT_F32) ? 4 : 8; }
 
-static int vgl_fold(vgl_hip_ctx *c, int64_t n, int parts, const void *in, void *out, int dtype, int op)
+int vgl_fold(vgl_hip_ctx *c, int64_t n, int parts, const void *in, void *out, int dtype, int op)
 {
     switch (dtype) {
     case VGL_DT_I32: return vgl_fold_launch<int32_t>(c, n, parts, in, out, op);
@@ -206,11 +206,17 @@ int vgl_comm_scratch(vgl_hip_comm *m, int slot, size_t bytes, void **out)
 
 void vgl_comm_group_begin(vgl_hip_comm *m)
 {
-    if (vgl_comm_active(m) && m->transport == VGL_HIP_COMM_RCCL && !m->grouped) { ncclGroupStart(); m->grouped = true; }
+    if (!vgl_comm_active(m) || m->grouped) return;
+    if (m->transport == VGL_HIP_COMM_RCCL) { ncclGroupStart(); m->grouped = true; }
+    else if (m->transport == VGL_HIP_COMM_PEER) m->grouped = true;          // the exchanges queue up and share one arrival flag
 }
 int vgl_comm_group_end(vgl_hip_comm *m)
 {
-    if (m && m->grouped) { m->grouped = false; VGL_NCCL_TRY(ncclGroupEnd()); }
+    if (m && m->grouped) {
+        m->grouped = false;
+        if (m->transport == VGL_HIP_COMM_PEER) return vgl_peer_group_end(m);
+        VGL_NCCL_TRY(ncclGroupEnd());
+    }
     return 0;
 }
 
@@ -226,6 +232,7 @@ int vgl_comm_allreduce(vgl_hip_comm *m, void *d_buf, int64_t count, int dtype, i
         VGL_NCCL_TRY(ncclAllReduce(d_buf, d_buf, (size_t)count, dt[dtype], ro[op], m->nccl, m->ctx->stream));
         return 0;
     }
+    if (m->transport == VGL_HIP_COMM_PEER) return vgl_peer_allreduce(m, d_buf, count, dtype, op);
     void *all = nullptr;
     const size_t bytes = (size_t)count * vgl_dt_bytes(dtype);
     VGL_TRY(vgl_comm_scratch(m, 5, bytes * (size_t)m->world, &all));
@@ -245,6 +252,7 @@ int vgl_comm_allgather(vgl_hip_comm *m, const void *d_send, void *d_recv, int64_
         VGL_NCCL_TRY(ncclAllGather(d_send, d_recv, (size_t)bytes, ncclChar, m->nccl, m->ctx->stream));
         return 0;
     }
+    if (m->transport == VGL_HIP_COMM_PEER) return vgl_peer_allgather(m, d_send, d_recv, bytes);
     return vgl_hosted_allgather(m, d_send, d_recv, bytes);
 }
 
@@ -260,6 +268,7 @@ int vgl_comm_alltoall(vgl_hip_comm *m, const void *d_send, void *d_recv, int64_t
         VGL_NCCL_TRY(ncclAllToAll(d_send, d_recv, (size_t)bpr, ncclChar, m->nccl, m->ctx->stream));
         return 0;
     }
+    if (m->transport == VGL_HIP_COMM_PEER) return vgl_peer_alltoall(m, d_send, d_recv, bpr);
     return vgl_hosted_alltoall(m, d_send, d_recv, bpr);
 }
 
@@ -279,19 +288,23 @@ int vgl_comm_allgatherv_inplace(vgl_hip_comm *m, void *d_buf, const int64_t *bb)
         // MPI_Allgatherv in place = one broadcast per owner, fused into a single launch by the group
         const bool outer = m->grouped;
         if (!outer) VGL_NCCL_TRY(ncclGroupStart());
-        for (int p = 0; p < m->world; p++) {
+        ncclResult_t first = ncclSuccess;                // (a failing broadcast must not leave the local group open)
+        for (int p = 0; p < m->world && first == ncclSuccess; p++) {
             const int64_t n = bb[p + 1] - bb[p];
-            if (n > 0) VGL_NCCL_TRY(ncclBroadcast((const char *)d_buf + bb[p], (char *)d_buf + bb[p], (size_t)n, ncclChar, p, m->nccl, m->ctx->stream));
+            if (n > 0) first = ncclBroadcast((const char *)d_buf + bb[p], (char *)d_buf + bb[p], (size_t)n, ncclChar, p, m->nccl, m->ctx->stream);
         }
-        if (!outer) VGL_NCCL_TRY(ncclGroupEnd());
+        if (!outer) { const ncclResult_t e = ncclGroupEnd(); if (first == ncclSuccess) first = e; }
+        VGL_NCCL_TRY(first);
         return 0;
     }
+    if (m->transport == VGL_HIP_COMM_PEER) return vgl_peer_allgatherv_inplace(m, d_buf, bb);
     return vgl_hosted_allgatherv_inplace(m, d_buf, bb);
 }
 
-__global__ void vgl_k_comm_publish(const int64_t *src, int n, volatile int64_t *host, int64_t seq)
+__global__ void vgl_k_comm_publish(const int64_t *src, int n, volatile int64_t *host, int64_t seq, const unsigned long long *peer_error)
 {
     for (int i = threadIdx.x; i < n; i += blockDim.x) host[i] = src[i];
+    if (threadIdx.x == 0) host[VGL_COMM_SMALL + 1] = peer_error ? (int64_t)__hip_atomic_load(peer_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) { host[VGL_COMM_SMALL] = seq; __threadfence_system(); }
@@ -302,7 +315,8 @@ int vgl_comm_read_small(vgl_hip_comm *m, const int64_t *d_vals, int n, int64_t *
 {
     if (n < 0 || n > VGL_COMM_SMALL) VGL_FAIL("comm read_small: too many values");
     const int64_t seq = ++m->small_seq;
-    hipLaunchKernelGGL(vgl_k_comm_publish, dim3(1), dim3(64), 0, m->ctx->stream, d_vals, n, (volatile int64_t *)m->h_small, seq);
+    hipLaunchKernelGGL(vgl_k_comm_publish, dim3(1), dim3(64), 0, m->ctx->stream, d_vals, n, (volatile int64_t *)m->h_small, seq,
+                       m->transport == VGL_HIP_COMM_PEER ? vgl_peer_error_word(m) : (const unsigned long long *)nullptr);
     VGL_HIP_TRY(hipGetLastError());
     volatile int64_t *flag = (volatile int64_t *)m->h_small + VGL_COMM_SMALL;
     for (long spin = 0; *flag != seq; spin++) {
@@ -314,6 +328,7 @@ int vgl_comm_read_small(vgl_hip_comm *m, const int64_t *d_vals, int n, int64_t *
         __builtin_ia32_pause();
     }
     for (int i = 0; i < n; i++) h_out[i] = m->h_small[i];
+    if (m->h_small[VGL_COMM_SMALL + 1] != 0) VGL_FAIL("peer transport: a rank did not arrive at an exchange (timeout): the results of this run are void");
     return 0;
 }
 
@@ -398,20 +413,18 @@ int vgl_hip_comm_create(vgl_hip_ctx *c, int rank, int world, const void *unique_
     return 0;
 }
 
-int vgl_hip_comm_create_hosted(vgl_hip_ctx *c, int rank, int world, const char *name, size_t slot_bytes, vgl_hip_comm **out)
+// attaches (rank 0: creates) the shared-memory object `name` of `payload` bytes behind the 256-byte header; `check` must agree on all ranks
+static int vgl_shm_attach(vgl_hip_ctx *c, int rank, int world, const char *name, size_t payload, uint64_t check, int transport, vgl_hip_comm **out)
 {
-    if (!c || !out || !name || name[0] != '/') VGL_FAIL("comm_create_hosted: null argument or a name that does not start with '/'");
-    if (world < 1 || world > 64 || rank < 0 || rank >= world) VGL_FAIL("comm_create_hosted: rank / world out of range");
-    slot_bytes = (std::max<size_t>(slot_bytes, 4096) + 255) & ~(size_t)255;
-    const size_t total = sizeof(vgl_hosted_header) + slot_bytes * (size_t)world;
+    const size_t total = sizeof(vgl_hosted_header) + payload;
     int fd = -1;
     const auto t0 = std::chrono::steady_clock::now();
     auto waited = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (rank == 0) {
         shm_unlink(name);
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0) VGL_FAIL("comm_create_hosted: shm_open failed on rank 0");
-        if (ftruncate(fd, (off_t)total) != 0) { close(fd); shm_unlink(name); VGL_FAIL("comm_create_hosted: ftruncate failed (is /dev/shm large enough?)"); }
+        if (fd < 0) VGL_FAIL("comm_create: shm_open failed on rank 0");
+        if (ftruncate(fd, (off_t)total) != 0) { close(fd); shm_unlink(name); VGL_FAIL("comm_create: ftruncate failed (is /dev/shm large enough?)"); }
     } else {
         for (;;) {
             fd = shm_open(name, O_RDWR, 0600);
@@ -420,29 +433,52 @@ int vgl_hip_comm_create_hosted(vgl_hip_ctx *c, int rank, int world, const char *
                 if (fstat(fd, &st) == 0 && (size_t)st.st_size == total) break;
                 close(fd); fd = -1;
             }
-            if (waited() > VGL_HOSTED_TIMEOUT_S) VGL_FAIL("comm_create_hosted: rank 0's segment did not appear (timeout)");
+            if (waited() > VGL_HOSTED_TIMEOUT_S) VGL_FAIL("comm_create: rank 0's segment did not appear (timeout)");
             usleep(1000);
         }
     }
     void *p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
-    if (p == MAP_FAILED) VGL_FAIL("comm_create_hosted: mmap failed");
+    if (p == MAP_FAILED) VGL_FAIL("comm_create: mmap failed");
     vgl_hip_comm *m = new vgl_hip_comm();
-    m->ctx = c; m->rank = rank; m->world = world; m->transport = VGL_HIP_COMM_HOSTED;
-    m->shm = reinterpret_cast<vgl_hosted_header *>(p); m->shm_bytes = total; m->slot_bytes = slot_bytes; m->shm_name = name;
+    m->ctx = c; m->rank = rank; m->world = world; m->transport = transport;
+    m->shm = reinterpret_cast<vgl_hosted_header *>(p); m->shm_bytes = total; m->shm_name = name;
     if (rank == 0) {
         m->shm->arrived.store(0); m->shm->generation.store(0); m->shm->turn.store(0);
-        m->shm->world = (uint32_t)world; m->shm->slot_bytes = slot_bytes;
+        m->shm->world = (uint32_t)world; m->shm->slot_bytes = check;
+        memset(m->shm->pad, 0, sizeof(m->shm->pad));
         m->shm->magic.store(VGL_HOSTED_MAGIC, std::memory_order_release);
     } else {
         while (m->shm->magic.load(std::memory_order_acquire) != VGL_HOSTED_MAGIC) {
-            if (waited() > VGL_HOSTED_TIMEOUT_S) { munmap(p, total); delete m; VGL_FAIL("comm_create_hosted: rank 0 did not initialise the segment (timeout)"); }
+            if (waited() > VGL_HOSTED_TIMEOUT_S) { munmap(p, total); delete m; VGL_FAIL("comm_create: rank 0 did not initialise the segment (timeout)"); }
             usleep(200);
         }
-        if (m->shm->world != (uint32_t)world || m->shm->slot_bytes != slot_bytes) { munmap(p, total); delete m; VGL_FAIL("comm_create_hosted: the ranks disagree on world / slot size"); }
+        if (m->shm->world != (uint32_t)world || m->shm->slot_bytes != check) { munmap(p, total); delete m; VGL_FAIL("comm_create: the ranks disagree on world / buffer size"); }
     }
     if (vgl_comm_common_init(m) || vgl_hosted_barrier(m)) { munmap(p, total); delete m; return 1; }
     if (rank == 0) shm_unlink(name);            // everybody is attached: the object lives on until the last rank unmaps it
+    *out = m;
+    return 0;
+}
+
+int vgl_hip_comm_create_hosted(vgl_hip_ctx *c, int rank, int world, const char *name, size_t slot_bytes, vgl_hip_comm **out)
+{
+    if (!c || !out || !name || name[0] != '/') VGL_FAIL("comm_create_hosted: null argument or a name that does not start with '/'");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) VGL_FAIL("comm_create_hosted: rank / world out of range");
+    slot_bytes = (std::max<size_t>(slot_bytes, 4096) + 255) & ~(size_t)255;
+    VGL_TRY(vgl_shm_attach(c, rank, world, name, slot_bytes * (size_t)world, slot_bytes, VGL_HIP_COMM_HOSTED, out));
+    (*out)->slot_bytes = slot_bytes;
+    return 0;
+}
+
+int vgl_hip_comm_create_peer(vgl_hip_ctx *c, int rank, int world, const char *name, size_t window_bytes, vgl_hip_comm **out)
+{
+    if (!c || !out || !name || name[0] != '/') VGL_FAIL("comm_create_peer: null argument or a name that does not start with '/'");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) VGL_FAIL("comm_create_peer: rank / world out of range");
+    VGL_HIP_TRY(hipSetDevice(c->device));
+    vgl_hip_comm *m = nullptr;
+    VGL_TRY(vgl_shm_attach(c, rank, world, name, (size_t)128 * (size_t)world, (uint64_t)window_bytes, VGL_HIP_COMM_PEER, &m));
+    if (vgl_peer_setup(m, window_bytes)) { vgl_hip_comm_destroy(m); return 1; }
     *out = m;
     return 0;
 }
@@ -453,6 +489,7 @@ int vgl_hip_comm_destroy(vgl_hip_comm *m)
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     if (m->nccl) ncclCommDestroy(m->nccl);
+    if (m->peer) vgl_peer_teardown(m);
     if (m->shm) {
         // serialised rehearsal: leaving counts as the end of this rank's last phase (the next rank is waiting for its turn)
         if (getenv("VGL_HOSTED_SERIALIZE") && getenv("VGL_HOSTED_SERIALIZE")[0] == '1') m->shm->turn.fetch_add(1, std::memory_order_acq_rel);

@@ -133,6 +133,11 @@ int vgl_hip_pr_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g
     }
     // in-degrees minus self loops of all vertices: a property of the graph (pr.hpp:31-65 recounts them in every run; here they are counted
     // over the shard's edges -- one atomic per edge without incoming lists -- and summed over the ranks ONCE per graph handle, like a plan)
+    // (the flag is per graph handle: a rank that recreated its handle, or an earlier run that failed on some ranks only, must not leave the
+    // ranks disagreeing on whether the all-reduce below is issued -- they agree on the minimum first)
+    int64_t all_ready = g->pr_indeg_ready ? 1 : 0;
+    VGL_TRY(vgl_comm_allreduce_host_i64(m, &all_ready, 1, VGL_OP_MIN));
+    if (!all_ready) g->pr_indeg_ready = false;
     if (!g->pr_indeg_ready) {
         if (!g->pr_indeg) VGL_HIP_TRY(hipMalloc((void **)&g->pr_indeg, sizeof(int32_t) * (size_t)std::max(V, 1)));
         VGL_HIP_TRY(hipMemsetAsync(g->pr_indeg, 0, sizeof(int32_t) * (size_t)V, c->stream));

@@ -25,6 +25,7 @@ struct vgl_hip_comm {
     size_t shm_bytes = 0, slot_bytes = 0;
     std::string shm_name;
     uint32_t barrier_gen = 0;
+    void *peer = nullptr;                     // PEER transport state (peer.hip)
     // device scratch owned by the communicator, grown on demand (never shrinks)
     void *scratch[VGL_COMM_SCRATCH_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[VGL_COMM_SCRATCH_SLOTS] = {0, 0, 0, 0, 0, 0};
@@ -55,6 +56,19 @@ int vgl_comm_allreduce_host_i64(vgl_hip_comm *m, int64_t *vals, int n, int op);
 // [row_begin, row_end) of every rank for this graph handle: world + 1 bounds when the ranges tile [0, V) in rank order, else an error;
 // bounds[world + 1] = the number of rows with incoming edges over all ranks (0 when a rank has no incoming lists)
 int vgl_comm_row_bounds(vgl_hip_comm *m, const vgl_hip_graph *g, const int64_t **bounds);
+
+// host-side barrier of the ranks attached to m->shm (HOSTED data path; set-up and tear-down of PEER)
+int vgl_hosted_barrier(vgl_hip_comm *m);
+// PEER transport (peer.hip): windows in device memory mapped by every rank, arrival / consumption flags in the windows
+int vgl_peer_setup(vgl_hip_comm *m, size_t window_bytes);
+void vgl_peer_teardown(vgl_hip_comm *m);
+int vgl_peer_allreduce(vgl_hip_comm *m, void *d_buf, int64_t count, int dtype, int op);
+int vgl_peer_allgather(vgl_hip_comm *m, const void *d_send, void *d_recv, int64_t bytes);
+int vgl_peer_alltoall(vgl_hip_comm *m, const void *d_send, void *d_recv, int64_t bpr);
+int vgl_peer_allgatherv_inplace(vgl_hip_comm *m, void *d_buf, const int64_t *bb);
+int vgl_peer_group_end(vgl_hip_comm *m);
+const unsigned long long *vgl_peer_error_word(vgl_hip_comm *m);
+int vgl_fold(vgl_hip_ctx *c, int64_t n, int parts, const void *in, void *out, int dtype, int op);      // out[i] = fold over p of in[p * n + i] (comm.hip)
 
 // enqueue-only forms of the owned-row super-steps (no host read; defined next to their kernels)
 int vgl_sssp_relax_enqueue(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, float *d_dist, bool widest);

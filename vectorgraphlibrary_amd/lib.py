@@ -41,7 +41,7 @@ class CcStats(C.Structure):
 
 class ExchangeStats(C.Structure):
     _fields_ = [("collectives", C.c_int64), ("bytes_received", C.c_int64), ("list_steps", C.c_int32), ("dense_steps", C.c_int32),
-                ("sparse_levels", C.c_int32), ("reserved", C.c_int32)]
+                ("sparse_levels", C.c_int32), ("exchanges", C.c_int32)]
 
 
 _lib = None
@@ -136,6 +136,7 @@ _SIGNATURES = {
     "vgl_hip_comm_unique_id": [_p],
     "vgl_hip_comm_create": [_p, _int, _int, _p, _pp],
     "vgl_hip_comm_create_hosted": [_p, _int, _int, C.c_char_p, C.c_size_t, _pp],
+    "vgl_hip_comm_create_peer": [_p, _int, _int, C.c_char_p, C.c_size_t, _pp],
     "vgl_hip_comm_destroy": [_p],
     "vgl_hip_comm_info": [_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
     "vgl_hip_comm_barrier": [_p],

@@ -13,7 +13,7 @@ import torch
 from . import lib as _l
 from .api import BFS_DIRECTION_OPT, PR_AUTO, _ptr, _stats
 
-TRANSPORT_RCCL, TRANSPORT_HOSTED = 0, 1
+TRANSPORT_RCCL, TRANSPORT_HOSTED, TRANSPORT_PEER = 0, 1, 2
 ID_BYTES = 128
 
 
@@ -44,6 +44,14 @@ class Comm:
         return cls(ctx, h, rank, world)
 
     @classmethod
+    def peer(cls, ctx, rank, world, name, window_bytes=32 << 20):
+        """direct peer-to-peer transport: every rank's window in device memory is mapped by the others (hipIpc) and written from kernels;
+        raises VglHipError on every rank alike when the windows cannot be mapped (fall back to rccl())"""
+        h = C.c_void_p()
+        _l.check(ctx.L.vgl_hip_comm_create_peer(ctx.h, int(rank), int(world), name.encode(), int(window_bytes), C.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    @classmethod
     def from_torch_group(cls, ctx, group=None):
         """RCCL communicator for the ranks of an initialised torch.distributed group (the group only carries the id)"""
         import torch.distributed as dist
@@ -58,7 +66,7 @@ class Comm:
     def stats(self):
         st = _l.ExchangeStats()
         _l.check(self.ctx.L.vgl_hip_comm_stats(self.h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+        return {k: getattr(st, k) for k, _ in st._fields_}
 
     def close(self):
         if self.h:
