@@ -92,6 +92,50 @@ def cc_hook_pass(ctx):
     return max(ng, nf), msg + msa + msf, "blocked (LDS windows; dense block pairs as fused tiles)" if nf else "blocked (LDS windows)"
 
 
+def peer_comm_or_none(ctx, vs, dist, rank, world):
+    """The PEER transport (device windows mapped through hipIpc, written from kernels) when every rank can map every other
+    rank's window AND a short self-test of the exchanges the drivers use returns the right values on every rank; else None (RCCL).
+    The ranks decide together (a MIN over torch.distributed), so that all of them end up on the same transport."""
+    import torch
+    import uuid
+    from vectorgraphlibrary_amd.lib import VglHipError
+    box = ["/vgl_bench_%s" % uuid.uuid4().hex[:12] if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    old = os.environ.get("VGL_PEER_TIMEOUT_MS")
+    os.environ["VGL_PEER_TIMEOUT_MS"] = "5000"
+    comm, ok = None, 1
+    try:
+        comm = vs.Comm.peer(ctx, rank, world, box[0], window_bytes=64 << 20)
+        dev = ctx.device
+        n = 100003
+        base = torch.arange(n, device=dev, dtype=torch.int64)
+        mine = ((base * 7 + rank * 13) % 1000).to(torch.int32)
+        want = torch.stack([((base * 7 + r * 13) % 1000).to(torch.int32) for r in range(world)])
+        ok &= int(torch.equal(comm.allreduce(mine.clone(), "min"), want.min(0).values))
+        ok &= int(torch.equal(comm.allreduce(mine.clone(), "sum"), want.sum(0).to(torch.int32)))
+        recv = torch.empty(n * world, device=dev, dtype=torch.int32)
+        comm.allgather(mine, recv)
+        ok &= int(torch.equal(recv, want.flatten()))
+        comm.barrier()                                   # (reads the error word of the window: a spin that ran out fails here)
+    except VglHipError:
+        ok = 0
+    finally:
+        if old is None:
+            os.environ.pop("VGL_PEER_TIMEOUT_MS", None)
+        else:
+            os.environ["VGL_PEER_TIMEOUT_MS"] = old
+    flag = torch.tensor([ok], device=ctx.device if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag) == 1:
+        return comm
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:                                # noqa: BLE001
+            pass
+    return None
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # single-GPU legs
 # ------------------------------------------------------------------------------------------------------------------------
@@ -557,6 +601,8 @@ def main():
     ap.add_argument("--no-pr-cc", action="store_true", help="skip the PageRank (uniform-25) and CC (symmetrised RMAT) extras")
     ap.add_argument("--no-operator-api", action="store_true", help="skip the drop-in (operator API) apps leg")
     ap.add_argument("--cpu-sources", type=int, default=10)
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "peer"],
+                    help="N > 1: auto = the PEER transport when the ranks can map each other's device windows and its self-test passes, else RCCL")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU super-step path even with one rank (debug)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = RMAT scale+log2(N) built shard-by-shard (default), strong = the scale-24 graph cut N ways")
@@ -599,16 +645,34 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = env_world is not None                      # under torch.distributed.run (also with one rank: the driver's N = 1 .. 8 form)
+    # VGL_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank uses cuda:0, the launcher's process group is gloo (RCCL refuses two
+    # ranks on one device) and the data path must be the PEER transport, which does not care whose card a window is on
+    share_gpu = os.environ.get("VGL_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+            if args.transport == "auto":
+                args.transport = "peer"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = api.Context(local_rank if launched else 0)
     # the library's own RCCL communicator: torch.distributed only carries rank 0's 128-byte id to the other ranks (and the barriers /
     # max-over-ranks of the timing contract); every data-path collective is issued by libvgl_hip.so on the context's stream
     comm = None
+    transport = "none"
     if world > 1 or (args.force_sharded and os.environ.get("VGL_SHARD_FORCE_COLLECTIVES") == "1"):
-        comm = vs.Comm.from_torch_group(ctx) if launched else vs.Comm.rccl(ctx, 0, 1, vs.Comm.unique_id())
+        if launched and world > 1 and args.transport in ("auto", "peer"):
+            comm = peer_comm_or_none(ctx, vs, dist, rank, world)
+            transport = "peer" if comm is not None else "rccl"
+            if comm is None and args.transport == "peer":
+                sys.exit("bench.py: --transport peer, but the ranks' device windows cannot be mapped / the self-test failed")
+        if comm is None:
+            comm = vs.Comm.from_torch_group(ctx) if launched else vs.Comm.rccl(ctx, 0, 1, vs.Comm.unique_id())
+            transport = "rccl"
 
     scale, ef, seed = args.scale, args.edge_factor, args.seed
     renumber = None if args.renumber == "none" else args.renumber
@@ -921,7 +985,7 @@ def main():
             "metric": "TEPS (edges/s) BFS + SSSP on RMAT-%d; value = direction-optimising BFS, sssp_value_teps = direction-optimising Bellman-Ford" % scale, "value": round(args.steps * E / dt, 1), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": workload, "vertices": V, "edges": E, "seed": seed, "parallelism": f"edge-cut x{world}" + (" (64-vertex blocks dealt round-robin)" if weak else ""),
+            "config": {"workload": workload, "vertices": V, "edges": E, "seed": seed, "parallelism": f"edge-cut x{world}" + (" (64-vertex blocks dealt round-robin)" if weak else ""), "exchange_transport": transport,
                        "vertex_numbering": "identity" if args.renumber == "none" else f"degree-sorted ({args.renumber})",
                        "graph_build_s": round(t_build, 2)},
         }

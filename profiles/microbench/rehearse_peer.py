@@ -22,13 +22,23 @@ def rank_main(scale, P, nsrc, name, r):
     from vectorgraphlibrary_amd import sharded as vs
     ef, seed = 32, 1
     V, E = 1 << scale, (1 << scale) * ef
+    dbg = os.environ.get("VGL_REHEARSE_DEBUG") == "1"
+    if dbg: print(f"rank {r}: imports done", flush=True)
     ctx = api.Context(0)
-    shard, degrees, bounds = vd.build_generated_shard(ctx, scale, ef, seed, r, P, kind="rmat", renumber="total", placement="dealt")
+    if dbg: print(f"rank {r}: context up", flush=True)
+    # the shards are built ONE RANK AT A TIME (a file lock): four processes streaming and sorting 2^29 edges each at the same moment on one
+    # card did not finish in minutes at scale 24 (each alone: seconds) -- the build is not what is rehearsed here
+    import fcntl
+    with open("/tmp/vgl_rehearse_build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        shard, degrees, bounds = vd.build_generated_shard(ctx, scale, ef, seed, r, P, kind="rmat", renumber="total", placement="dealt")
+        ctx.sync()
+        torch.cuda.empty_cache()
+        fcntl.flock(lock, fcntl.LOCK_UN)
     nz = torch.nonzero(degrees > 0).flatten()
     g = torch.Generator(device="cpu").manual_seed(seed)
     sources = [int(nz[i]) for i in torch.randint(0, nz.numel(), (nsrc + 1,), generator=g)]
     del degrees
-    dbg = os.environ.get("VGL_REHEARSE_DEBUG") == "1"
     if dbg: print(f"rank {r}: shard built", flush=True)
     comm = vs.Comm.peer(ctx, r, P, name, window_bytes=int(os.environ.get("VGL_REHEARSE_WINDOW", 48 << 20)))
     if dbg: print(f"rank {r}: communicator up", flush=True)
@@ -65,6 +75,8 @@ if __name__ == "__main__":
     nsrc = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     name = "/vgl_rehearse_%s" % uuid.uuid4().hex[:10]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch  # noqa: F401  (no GPU call: only pages the libraries in, so that the ranks' imports do not take minutes on a fresh box)
+    print("parent: libraries paged in, starting the ranks", flush=True)
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(scale), str(P), str(nsrc), name, str(r)], env=env) for r in range(P)]
     rc = [p.wait() for p in procs]
     print("ranks exited with", rc, flush=True)

@@ -84,7 +84,8 @@ def check_exchanges(ctx, comm):
 
 def main():
     transport, rank, world, token = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-    ctx = api.Context(0 if transport in ("hosted", "peer") else int(os.environ.get("LOCAL_RANK", rank)))
+    per_rank_device = transport == "rccl" or os.environ.get("VGL_TEST_PEER_DEVICE_PER_RANK") == "1"
+    ctx = api.Context(int(os.environ.get("LOCAL_RANK", rank)) if per_rank_device else 0)
     if transport == "hosted":
         comm = vs.Comm.hosted(ctx, rank, world, token, slot_bytes=1 << 16)          # small slots: every large payload goes in pieces
     elif transport == "peer":

@@ -89,3 +89,22 @@ def test_bench_sharded_legs_through_the_library_rccl_communicator(ctx):
     assert line["bfs"]["exchange_last_traversal"]["collectives"] > 0                       # the RCCL path really ran
     assert line["pagerank_uniform16_sharded"]["collectives"] > 0 and abs(line["pagerank_uniform16_sharded"]["ranks_sum"] - 1.0) < 1e-3
     assert line["cc_rmat_symmetrised_sharded"]["labels_idempotent"] and line["cc_rmat_symmetrised_sharded"]["exchange"]["collectives"] > 0
+
+
+def test_bench_two_ranks_sharing_the_gpu_over_the_peer_transport(ctx):
+    """bench.py's N = 2 form as the driver launches it, rehearsed on ONE card (VGL_BENCH_SHARE_GPU=1: both ranks on cuda:0, the launcher's
+    group is gloo): the data path of every leg -- weak-scaling BFS, PageRank, Shiloach-Vishkin -- goes through the PEER transport (device
+    windows mapped through hipIpc), chosen by the bench's own self-test; the certificate and the PageRank residual are checked in the run."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", VGL_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29743",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "15", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sssp",
+           "--pr-scale", "16", "--cc-scale", "15", "--chunk-edges", str(1 << 18)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads([x for x in out.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["exchange_transport"] == "peer"
+    assert line["value"] > 0 and line["verified_sharded_levels_consistent_over_owned_edges"] is True
+    assert line["bfs"]["exchange_last_traversal"]["collectives"] > 0 and line["bfs"]["exchange_last_traversal"]["exchanges"] > 0
+    assert abs(line["pagerank_uniform16_sharded"]["ranks_sum"] - 1.0) < 1e-3
+    assert line["cc_rmat_symmetrised_sharded"]["labels_idempotent"]

@@ -79,6 +79,19 @@ def test_sharded_loops_one_rank_rccl_through_the_c_abi(ctx):
     _run_ranks("rccl", 1, {"VGL_SHARD_FORCE_COLLECTIVES": "1"})
 
 
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_sharded_loops_two_gpus(ctx, transport):
+    """where the box has two GPUs, one rank per GPU -- the RCCL paths for world > 1 (grouped per-owner broadcasts for unequal
+    slices, ncclAllToAll of candidate slices, in-place all-gathers inside a group, two communicators on a device) and the PEER transport
+    with windows on different cards -- bit for bit against the fused single-GPU results.  Skipped on the one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    if transport == "rccl":
+        _run_ranks("rccl", 2, {})
+    else:
+        _run_ranks("peer", 2, {"VGL_TEST_PEER_DEVICE_PER_RANK": "1", "VGL_TEST_PEER_WINDOW": str(8 << 20)})
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_loops_ranks_sharing_the_gpu_hosted_transport(ctx, world):
     _run_ranks("hosted", world)
