@@ -444,6 +444,9 @@ int vgl_hip_sswp_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph
 int vgl_hip_cc_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, int32_t *d_comp, vgl_hip_cc_stats *stats);
 int vgl_hip_pr_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, int iterations, int mode, float *d_ranks,
                            vgl_hip_pr_stats *stats);
+/* HITS over the shards (algorithms/hits/hits.hpp:32-91 with the exchanges at :52 and :79): replicated f64 authority / hub arrays, the owned
+ * rows pulled per rank, one f64 all-reduce (sum of squares) and one all-gather of the owned slices per half step */
+int vgl_hip_hits_run_sharded(vgl_hip_ctx *ctx, vgl_hip_comm *comm, vgl_hip_graph *g, int steps, double *d_auth, double *d_hub);
 /* exchange statistics of the last *_run_sharded on this communicator: collectives issued, bytes this rank received, super-steps that
  * used pair lists / the whole-array all-reduce / id lists (BFS) */
 typedef struct {

@@ -120,6 +120,7 @@ def main():
     comp_ref, _ = api.connected_components(g, raw=True)
     pr_ref, _ = api.page_rank(g, 5, raw=True, mode=api.PR_EXACT_ORDER)
     prb_ref, _ = api.page_rank(g, 5, raw=True, mode=api.PR_BLOCKED)
+    auth_ref, hub_ref = api.hits(g, 3, raw=True)
 
     equal = [p * (V // world) for p in range(world + 1)]
     balanced = ctx.partition_rows(g.out_rowptr, world)
@@ -157,6 +158,11 @@ def main():
         assert torch.equal(bits(ranks), bits(pr_ref)), name
         ranks, _ = vs.pr_run_sharded(shard, comm, 5, api.PR_BLOCKED)       # exact sums: independent of the cut into shards
         assert torch.equal(bits(ranks), bits(prb_ref)), name
+        # HITS: the sum of squares is folded rank by rank (an ulp on the norm): 1e-12 relative, the bar of the single-GPU tests
+        auth, hub = vs.hits_run_sharded(shard, comm, 3)
+        for got, want in ((auth, auth_ref), (hub, hub_ref)):
+            err = ((got - want).abs() / want.abs().clamp(min=1e-300)).max().item()
+            assert err <= 1e-12, (name, err)
         shard.close()
     comm.barrier()
     comm.close()

@@ -67,6 +67,9 @@ def test_sharded_loops_world_of_one_equal_fused(ctx):
     for mode in (api.PR_EXACT_ORDER, api.PR_BLOCKED):
         ranks, _ = vs.pr_run_sharded(g, None, 4, mode)
         assert torch.equal(ranks.view(torch.int32), api.page_rank(g, 4, raw=True, mode=mode)[0].view(torch.int32))
+    auth, hub = vs.hits_run_sharded(g, None, 3)
+    auth_ref, hub_ref = api.hits(g, 3, raw=True)
+    assert torch.equal(auth.view(torch.int64), auth_ref.view(torch.int64)) and torch.equal(hub.view(torch.int64), hub_ref.view(torch.int64))
     # argument checks fail loudly
     from vectorgraphlibrary_amd.lib import VglHipError
     with pytest.raises(VglHipError):

@@ -169,4 +169,41 @@ int vgl_hip_pr_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g
     return 0;
 }
 
+// HITS (algorithms/hits/hits.hpp:32-91; the reference distributes it with EXCHANGE_PRIVATE_DATA after each half step, :52 and :79): every
+// rank sums the hub values of the in-neighbours (then the authority values of the out-neighbours) for the rows it owns, the ranks add up
+// their shares of the sum of squares (one f64), every rank scales its rows and the owned slices are all-gathered in place.  A world of
+// one is bit-identical to vgl_hip_hits_run; over several ranks the sum of squares is folded rank by rank instead of workgroup by workgroup,
+// which moves the norm by an ulp (the reference's own OpenMP reduction order is unspecified; its runs differ by ~4e-15).
+int vgl_hip_hits_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g, int steps, double *d_auth, double *d_hub)
+{
+    if (!c || !g || !d_auth || !d_hub) VGL_FAIL("hits_run_sharded: null argument");
+    if (!g->in.rowptr) VGL_FAIL("hits_run_sharded: the incoming lists of the owned rows are required (authorities are sums over in-neighbours)");
+    if (steps < 0) VGL_FAIL("hits_run_sharded: negative step count");
+    vgl_solo_comm solo;
+    VGL_TRY(solo.init(c, given));
+    vgl_hip_comm *m = solo.m;
+    VGL_TRY(vgl_check_shard(c, m, g, "hits_run_sharded"));
+    const int P = m->world;
+    const bool active = vgl_comm_active(m);
+    std::vector<int64_t> bb((size_t)P + 1, 0);
+    if (active) {
+        const int64_t *bounds = nullptr;
+        VGL_TRY(vgl_comm_row_bounds(m, g, &bounds));
+        for (int p = 0; p <= P; p++) bb[(size_t)p] = bounds[p] * (int64_t)sizeof(double);
+    }
+    double *d_sumsq = reinterpret_cast<double *>(m->d_small + VGL_COMM_SMALL - 2);      // (a spare word of the hand-over buffer)
+    VGL_TRY(vgl_hits_init(c, g->V, d_auth, d_hub));
+    for (int step = 0; step < steps; step++)
+        for (int half = 0; half < 2; half++) {
+            const double *x = half == 0 ? d_hub : d_auth;
+            double *out = half == 0 ? d_auth : d_hub;
+            VGL_TRY(vgl_hits_pull_owned(c, g, half == 0, x, out, d_sumsq));
+            if (active) VGL_TRY(vgl_comm_allreduce(m, d_sumsq, 1, VGL_DT_F64, VGL_OP_SUM));
+            VGL_TRY(vgl_hits_scale_owned(c, g, out, d_sumsq));
+            if (active) VGL_TRY(vgl_comm_allgatherv_inplace(m, out, bb.data()));
+        }
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 }  // extern "C"

@@ -157,6 +157,7 @@ _SIGNATURES = {
     "vgl_hip_sswp_run_sharded": [_p, _p, _p, _p, _i32, _p, C.POINTER(SsspStats)],
     "vgl_hip_cc_run_sharded": [_p, _p, _p, _p, C.POINTER(CcStats)],
     "vgl_hip_pr_run_sharded": [_p, _p, _p, _int, _int, _p, C.POINTER(PrStats)],
+    "vgl_hip_hits_run_sharded": [_p, _p, _p, _int, _p, _p],
     "vgl_hip_timing_enable": [_p, _int],
     "vgl_hip_timing_only": [_p, C.c_char_p],
     "vgl_hip_timing_reset": [_p],

@@ -149,3 +149,12 @@ def pr_run_sharded(graph, comm, iterations, mode=PR_AUTO, ranks=None):
     st = _l.PrStats()
     _l.check(ctx.L.vgl_hip_pr_run_sharded(ctx.h, _h(comm), graph.h, int(iterations), int(mode), _ptr(ranks), C.byref(st)))
     return ranks, _stats(st)
+
+
+def hits_run_sharded(graph, comm, steps, auth=None, hub=None):
+    """vgl_hip_hits_run_sharded: replicated f64 authority / hub vectors after `steps` steps"""
+    ctx = graph.ctx
+    auth = torch.empty(graph.V, dtype=torch.float64, device=ctx.device) if auth is None else auth
+    hub = torch.empty(graph.V, dtype=torch.float64, device=ctx.device) if hub is None else hub
+    _l.check(ctx.L.vgl_hip_hits_run_sharded(ctx.h, _h(comm), graph.h, int(steps), _ptr(auth), _ptr(hub)))
+    return auth, hub
