@@ -14,27 +14,31 @@ struct ConnectedComponents {
         all.set_all_active();
         auto own_id = [components] __VGL_COMPUTE_ARGS__ { components[src_id] = src_id; };
         api.compute(graph, all, own_id);
-        int *flags;
-        MemoryAPI::allocate_array(&flags, 2);
-        int *hooked = flags, *jumped = flags + 1;
+        // the two loop flags live in device memory (vgl_device_words): the operators' stores stay on the card and no primitive has to end
+        // with a synchronisation; the host fetches a flag where the reference reads its managed word
+        vgl_device_words<2> flags;
+        int *hooked = flags.device(), *jumped = flags.device() + 1;
         do {
-            hooked[0] = 0;
+            flags.clear();
             auto hook = [components, hooked] __VGL_SCATTER_ARGS__ {
                 const int label = components[src_id];
                 if (label < components[dst_id]) { atomicMin(&components[dst_id], label); hooked[0] = 1; }
             };
             api.scatter(graph, all, hook);
+            const int any_hook = flags.fetch(0);
+            int any_jump;
             do {
-                jumped[0] = 0;
+                flags.clear();
                 auto shortcut = [components, jumped] __VGL_COMPUTE_ARGS__ {
                     const int label = components[src_id];
                     const int grand = components[label];
                     if (label != grand) { components[src_id] = grand; jumped[0] = 1; }
                 };
                 api.compute(graph, all, shortcut);
-            } while (jumped[0]);
-        } while (hooked[0]);
-        MemoryAPI::free_array(flags);
+                any_jump = flags.fetch(1);
+            } while (any_jump);
+            if (!any_hook) break;
+        } while (true);
         tm.end();
         performance_stats.print_algorithm_performance_stats("CC (Shiloach-Vishkin, operator API)", tm.get_time(), graph.get_edges_count());
         return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());

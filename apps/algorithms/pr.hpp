@@ -5,7 +5,11 @@
 
 struct PageRank {
     template <typename _T>
-    static double vgl_page_rank(VGL_Graph &graph, VerticesArray<_T> &page_ranks, _T, int max_iterations)
+    // deterministic: 0 = float atomics (gpu_pr.hpp's shape), 1 = sequential rows (one lane per vertex walks its edges between pre and post),
+    // 2 = pull inside compute(): the lane of a vertex sums its neighbours' contributions in a register (adjacency through a vgl_csr_view
+    // captured by value, as the reference's random_walk.hpp reads the graph inside compute lambdas).  1 and 2 are the multicore recipe
+    // (pr.hpp:105-124): products and sums in f32 in adjacency order -- seq_page_rank's chain, independent of the schedule.
+    static double vgl_page_rank(VGL_Graph &graph, VerticesArray<_T> &page_ranks, _T, int max_iterations, int deterministic = 0)
     {
         const int vertices_count = graph.get_vertices_count();
         VGL_GRAPH_ABSTRACTIONS graph_API(graph);
@@ -13,7 +17,8 @@ struct PageRank {
         VerticesArray<int> incoming_degrees_without_loops(graph, SCATTER);
         VerticesArray<_T> reversed_degrees(graph, SCATTER);
         VerticesArray<_T> old_page_ranks(graph, SCATTER);
-        graph_API.change_traversal_direction(SCATTER, frontier, incoming_degrees_without_loops, reversed_degrees, old_page_ranks, page_ranks);
+        VerticesArray<_T> contributions(graph, SCATTER);        // old rank * reversed degree, once per vertex instead of once per edge (the same f32 product)
+        graph_API.change_traversal_direction(SCATTER, frontier, incoming_degrees_without_loops, reversed_degrees, old_page_ranks, contributions, page_ranks);
         frontier.set_all_active();
         const _T d = 0.85;
         const _T k = (1.0 - d) / ((_T)vertices_count);
@@ -38,8 +43,9 @@ struct PageRank {
         Timer tm;
         tm.start();
         for (int it = 0; it < max_iterations; it++) {
-            auto save_old_ranks = [old_page_ranks, page_ranks] __VGL_COMPUTE_ARGS__ {
+            auto save_old_ranks = [old_page_ranks, page_ranks, contributions, reversed_degrees] __VGL_COMPUTE_ARGS__ {
                 old_page_ranks[src_id] = page_ranks[src_id];
+                contributions[src_id] = page_ranks[src_id] * reversed_degrees[src_id];
                 page_ranks[src_id] = 0;
             };
             graph_API.compute(graph, frontier, save_old_ranks);
@@ -47,13 +53,33 @@ struct PageRank {
                 return incoming_degrees_without_loops[src_id] == 0 ? old_page_ranks[src_id] / vertices_count : 0.0f;
             };
             const _T dangling_input = (_T)graph_API.template reduce<double>(graph, frontier, reduce_dangling_input, REDUCE_SUM);
-            auto edge_op = [page_ranks, old_page_ranks, reversed_degrees] __VGL_SCATTER_ARGS__ {
-                if (src_id != dst_id) VGL_SRC_ID_ADD(page_ranks[src_id], old_page_ranks[dst_id] * reversed_degrees[dst_id]);
-            };
             auto vertex_postprocess_op = [page_ranks, k, d, dangling_input] __VGL_ADVANCE_POSTPROCESS_ARGS__ {
                 page_ranks[src_id] = k + d * (page_ranks[src_id] + dangling_input);
             };
-            graph_API.scatter(graph, frontier, edge_op, EMPTY_VERTEX_OP, vertex_postprocess_op, edge_op, EMPTY_VERTEX_OP, vertex_postprocess_op);
+            if (deterministic == 2) {
+                const vgl_csr_view out = graph.get_direction_view(SCATTER);
+                auto pull = [page_ranks, contributions, out, k, d, dangling_input] __VGL_COMPUTE_ARGS__ {
+                    _T sum = 0;
+                    for (long long e = out.rowptr[src_id]; e < out.rowptr[src_id + 1]; e++) {
+                        const int dst_id = out.adj[e];
+                        if (src_id != dst_id) sum = sum + contributions[dst_id];
+                    }
+                    page_ranks[src_id] = k + d * (sum + dangling_input);
+                };
+                graph_API.compute(graph, frontier, pull);
+            } else if (deterministic == 1) {
+                auto edge_op_seq = [page_ranks, contributions] __VGL_SCATTER_ARGS__ {
+                    if (src_id != dst_id) page_ranks[src_id] = page_ranks[src_id] + contributions[dst_id];
+                };
+                graph_API.enable_sequential_rows();
+                graph_API.scatter(graph, frontier, edge_op_seq, EMPTY_VERTEX_OP, vertex_postprocess_op, edge_op_seq, EMPTY_VERTEX_OP, vertex_postprocess_op);
+                graph_API.disable_sequential_rows();
+            } else {
+                auto edge_op = [page_ranks, contributions] __VGL_SCATTER_ARGS__ {
+                    if (src_id != dst_id) VGL_SRC_ID_ADD(page_ranks[src_id], contributions[dst_id]);
+                };
+                graph_API.scatter(graph, frontier, edge_op, EMPTY_VERTEX_OP, vertex_postprocess_op, edge_op, EMPTY_VERTEX_OP, vertex_postprocess_op);
+            }
             graph_API.exchange_vertices_array(EXCHANGE_PRIVATE_DATA, graph, page_ranks);       // pr.hpp:127: the ranks of every owner's vertex range
         }
         tm.end();

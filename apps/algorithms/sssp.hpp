@@ -19,8 +19,9 @@ struct ShortestPaths {
         };
         frontier.set_all_active();
         graph_API.compute(graph, frontier, init_distances);
-        int *changes;
-        MemoryAPI::allocate_array(&changes, 1);
+        vgl_device_words<1> changes_word;                     // the reference's `changes[0]`, kept on the card (vgl_device_words)
+        int *changes = changes_word.device();
+        int any_change = 0;
         int iterations_count = 0;
         // several ranks (the reference's __USE_MPI__ flavour, shortest_paths.hpp:112-154): every rank relaxes the edges of its vertex range,
         // the copies of the distances are merged through exchange_vertices_array(EXCHANGE_RECENTLY_CHANGED, ..., min_op) and the loop
@@ -28,7 +29,7 @@ struct ShortestPaths {
         const bool several_ranks = vgl_library_data.get_mpi_proc_num() > 1;
         VerticesArray<_T> prev_distances(graph, SCATTER);
         do {
-            changes[0] = 0;
+            changes_word.clear();
             iterations_count++;
             if (several_ranks) {
                 auto save_old_distances = [prev_distances, distances] __VGL_COMPUTE_ARGS__ { prev_distances[src_id] = distances[src_id]; };
@@ -49,10 +50,9 @@ struct ShortestPaths {
                 auto min_op = [] __device__ (_T a, _T b) -> _T { return a < b ? a : b; };
                 graph_API.exchange_vertices_array(EXCHANGE_RECENTLY_CHANGED, graph, distances, prev_distances, min_op);      // shortest_paths.hpp:136-141
                 auto reduce_changes = [prev_distances, distances] __VGL_REDUCE_INT_ARGS__ { return prev_distances[src_id] != distances[src_id] ? 1 : 0; };
-                changes[0] = graph_API.template reduce<int>(graph, frontier, reduce_changes, REDUCE_SUM) > 0;                 // shortest_paths.hpp:143-152
-            }
-        } while (changes[0]);
-        MemoryAPI::free_array(changes);
+                any_change = graph_API.template reduce<int>(graph, frontier, reduce_changes, REDUCE_SUM) > 0;                 // shortest_paths.hpp:143-152
+            } else any_change = changes_word.fetch(0);
+        } while (any_change);
         tm.end();
         performance_stats.print_algorithm_performance_stats("SSSP (Bellman-Ford, all-active, push, operator API)", tm.get_time(), graph.get_edges_count());
         return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());

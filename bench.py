@@ -430,24 +430,37 @@ def leg_operator_api(scale, ef, extra):
     }
     out = {"note": "AVG_PERF (MTEPS, E / time) of apps/bin/*_hip WITHOUT -fused: user lambdas through GraphAbstractionsHIP::scatter / compute / "
                    "reduce / generate_new_frontier; `fused` = the same app with -fused (its fastest library schedule), for scale"}
+    # PageRank: the app's deterministic form (-deterministic: GraphAbstractionsHIP::enable_sequential_rows -- one lane per vertex adds its
+    # neighbours' contributions in adjacency order between the pre and post operators, the multicore recipe: 1e-6 of the oracle, bit-identical
+    # from run to run; no load balancing, so for graphs without hubs like this uniform one) is what `operator_api` quotes; the float-atomics
+    # form (gpu_pr.hpp's shape, 2e-5, any graph) rides along as operator_api_atomics_mteps
+    variants = {"pagerank_5_iterations": [("operator_api", ["-deterministic"]), ("operator_api_atomics", [])]}
     for name, (app, argv, fused) in runs.items():
         exe = os.path.join(root, "apps", "bin", app)
         if not os.path.exists(exe):
             out[name] = {"error": "apps/bin/%s not built" % app}
             continue
         row = {"command": " ".join([app] + argv)}
-        for label, more in (("operator_api", []), ("fused", fused)):
+        for label, more in variants.get(name, [("operator_api", [])]) + [("fused", fused)]:
             try:
                 r = subprocess.run([exe] + argv + more, capture_output=True, text=True, timeout=600)
                 m = re.search(r"AVG_PERF: ([0-9.eE+-]+) MTEPS", r.stdout)
                 row[label + "_mteps"] = float(m.group(1)) if (m and r.returncode == 0) else None
-                if label == "operator_api":
-                    for prim in ("Advance", "Compute", "Reduce", "GNF"):
-                        pm = re.search(prim + r"\s*: ([0-9.eE+-]+) \(ms\), ([0-9.eE+-]+) %", r.stdout)
-                        if pm:
-                            row.setdefault("wall_share_percent", {})[prim.lower()] = float(pm.group(2))
+                if more and label != "fused":
+                    row[label + "_flags"] = " ".join(more)
             except subprocess.TimeoutExpired:
                 row[label + "_mteps"] = None
+        # shares of the primitives: a second, shorter run with every primitive bracketed by HIP events (VGL_PRIMITIVE_TIMERS=1; the host-clock
+        # shares of round 3 charged asynchronous primitives to the next synchronising call)
+        try:
+            env = dict(os.environ, VGL_PRIMITIVE_TIMERS="1")
+            r = subprocess.run([exe] + argv + variants.get(name, [("operator_api", [])])[0][1], capture_output=True, text=True, timeout=600, env=env)
+            for prim in ("Advance", "Compute", "Reduce", "GNF"):
+                pm = re.search(prim + r"\s*: ([0-9.eE+-]+) \(ms\), ([0-9.eE+-]+) %", r.stdout)
+                if pm:
+                    row.setdefault("stream_time_share_percent", {})[prim.lower()] = float(pm.group(2))
+        except subprocess.TimeoutExpired:
+            pass
         if row.get("operator_api_mteps") and row.get("fused_mteps"):
             row["operator_api_over_fused"] = round(row["operator_api_mteps"] / row["fused_mteps"], 3)
         out[name] = row

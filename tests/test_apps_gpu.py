@@ -109,6 +109,19 @@ def test_pr_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
     assert "error count: 0" in out
     got = np.fromfile(dump, np.float32)
     assert np.max(np.abs(got - ref) / ref) < 2e-5
+    # ... and with -deterministic (round 4): one lane per vertex adds the products in adjacency order without atomics
+    # (GraphAbstractionsHIP::enable_sequential_rows, the execution shape of the reference's multicore kernels): within north_star's 1e-6 of
+    # the multicore recipe -- the same f32 chain; only the dangling term is folded in another (fixed) f64 order
+    out, dump = run_app("pr", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 5, "-check", "-deterministic"], tmp_path)
+    assert "error count: 0" in out
+    got = np.fromfile(dump, np.float32)
+    assert np.max(np.abs(got - ref) / ref) <= 1e-6
+    out2, dump2 = run_app("pr", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 5, "-deterministic"], tmp_path)
+    assert (np.fromfile(dump2, np.float32).view(np.int32) == got.view(np.int32)).all()          # run to run: bit-identical
+    # -pull: the same chain summed in a register inside compute() (adjacency through a view captured by the lambda): the same bits
+    out3, dump3 = run_app("pr", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 5, "-check", "-pull"], tmp_path)
+    assert "error count: 0" in out3
+    assert (np.fromfile(dump3, np.float32).view(np.int32) == got.view(np.int32)).all()
 
 
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)

@@ -188,6 +188,22 @@ struct MemoryAPI {
     template <class T> static void free_device_array(T *p) { if (p) vgl_hip_free(VGL_RUNTIME::ctx(), p); }
 };
 
+// A few flag / counter words in DEVICE memory with a host mirror (round 4).  The reference's GPU variants keep such words in managed memory and
+// write them from edge operators (`changes[0] = 1`, gpu_shortest_paths.hpp:92-113); MemoryAPI::allocate_array gives pinned HOST memory for
+// that, which costs every storing wavefront a PCIe write and makes every primitive end with a stream synchronisation (live_host_arrays).
+// Operators write `flags.device()[i]` instead; the host calls clear() before and fetch(i) after the primitives of a super-step.
+template <int N>
+struct vgl_device_words {
+    int *d = nullptr;
+    int h[N];
+    vgl_device_words() { MemoryAPI::allocate_device_array(&d, N); clear(); }
+    ~vgl_device_words() { MemoryAPI::free_device_array(d); }
+    vgl_device_words(const vgl_device_words &) = delete;
+    int *device() const { return d; }
+    void clear() { VGL_HIP_CALL(vgl_hip_memset(VGL_RUNTIME::ctx(), d, 0, sizeof(int) * N)); }
+    int fetch(int i) { VGL_HIP_CALL(vgl_hip_memcpy_d2h(VGL_RUNTIME::ctx(), h, d, sizeof(int) * N)); return h[i]; }      // (synchronises)
+};
+
 // per-lane scratch "registers" of the reference's algorithm sources (vgl_compute_api/gpu/vector_register/vector_registers.h:3-70):
 // VECTOR_LENGTH words in memory both sides can touch, plus the host folds over them
 #define VEC_REGISTER_INT(name, value) int *reg_##name; MemoryAPI::allocate_array(&reg_##name, VECTOR_LENGTH); for (int i = 0; i < VECTOR_LENGTH; i++) reg_##name[i] = value;
@@ -223,27 +239,78 @@ public:
 // PerformanceStats (performance_stats.h:11-100, performance_stats.hpp:13-120,248-330): wall time per abstraction and the bytes the
 // reference's accounting charges them (work items x INT elements x 4 B -- VGL's own model, not measured traffic), so that
 // print_timers_stats() reports the same "total bandwidth / edges rate" lines a VGL user compares across backends.
-struct vgl_stopwatch {                        // primitives end with a stream sync: plain host clocks bracket them
+// Timers per abstraction.  advance / compute are ASYNCHRONOUS unless a host-visible array is alive (MemoryAPI::live_host_arrays), so a host
+// clock around them measures the enqueue and charges the kernel to whichever later call synchronises (round 3's statistics showed "reduce
+// 99.6 %" for PageRank that way).  VGL_PRIMITIVE_TIMERS=1: every primitive is bracketed by a pair of HIP events on the runtime's stream instead
+// and the pairs are resolved when the statistics are printed -- stream time of the primitive's own launches (~5 us of stream time per pair,
+// which is why it is opt-in).  Without it the lines are labelled as host wall time.
+static inline bool vgl_event_timers() { static const bool on = getenv("VGL_PRIMITIVE_TIMERS") && getenv("VGL_PRIMITIVE_TIMERS")[0] == '1'; return on; }
+struct vgl_event_pairs {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+    static vgl_event_pairs &get() { static vgl_event_pairs e; return e; }
+};
+struct vgl_stopwatch {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    int ticket = -1;
+    vgl_stopwatch()
+    {
+        if (!vgl_event_timers()) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        hipEventRecord(a, VGL_RUNTIME::stream());
+        ticket = (int)vgl_event_pairs::get().pairs.size();
+        vgl_event_pairs::get().pairs.emplace_back(a, b);
+    }
+    // host seconds, or -(ticket + 1) when the primitive is bracketed by events (resolved by PerformanceStats::resolve)
+    double seconds() const
+    {
+        if (ticket < 0) return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        hipEventRecord(vgl_event_pairs::get().pairs[(size_t)ticket].second, VGL_RUNTIME::stream());
+        return -(double)(ticket + 1);
+    }
 };
 struct PerformanceStats {
     double inner_wall_time = 0, advance_time = 0, gather_time = 0, scatter_time = 0, compute_time = 0, reduce_time = 0, gnf_time = 0;
     size_t bytes_requested = 0, edges_visited = 0;
-    void reset_timers() { *this = PerformanceStats(); }
-    void update_advance_stats(double t, size_t bytes, size_t edges, bool gather)
-    { advance_time += t; (gather ? gather_time : scatter_time) += t; inner_wall_time += t; bytes_requested += bytes; edges_visited += edges; }
-    void update_compute_stats(double t, size_t vertices) { compute_time += t; inner_wall_time += t; bytes_requested += (size_t)(vertices * COMPUTE_INT_ELEMENTS * sizeof(int)); }
-    void update_reduce_stats(double t, size_t vertices) { reduce_time += t; inner_wall_time += t; bytes_requested += (size_t)(vertices * REDUCE_INT_ELEMENTS * sizeof(int)); }
-    void update_gnf_stats(double t, size_t vertices) { gnf_time += t; inner_wall_time += t; bytes_requested += (size_t)(vertices * GNF_INT_ELEMENTS * sizeof(int)); }
-    double get_sustained_bandwidth() const { return inner_wall_time > 0 ? bytes_requested / (inner_wall_time * 1e9) : 0.0; }    // GB/s
-    double get_edges_rate() const { return inner_wall_time > 0 ? edges_visited / (inner_wall_time * 1e6) : 0.0; }               // MTEPS
-    void print_timers_stats() const
+    std::vector<std::pair<int, int>> pending;          // (kind, ticket) of event-bracketed primitives: 0 gather, 1 scatter, 2 compute, 3 reduce, 4 gnf
+    void reset_timers() { resolve(); *this = PerformanceStats(); }
+    void add_time(int kind, double t)
     {
+        if (t < 0) { pending.emplace_back(kind, (int)(-t) - 1); return; }
+        inner_wall_time += t;
+        if (kind <= 1) { advance_time += t; (kind == 0 ? gather_time : scatter_time) += t; }
+        else if (kind == 2) compute_time += t;
+        else if (kind == 3) reduce_time += t;
+        else gnf_time += t;
+    }
+    void resolve()
+    {
+        if (pending.empty()) return;
+        hipStreamSynchronize(VGL_RUNTIME::stream());
+        std::vector<std::pair<int, int>> todo;
+        todo.swap(pending);
+        for (const auto &p : todo) {
+            auto &ev = vgl_event_pairs::get().pairs[(size_t)p.second];
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) add_time(p.first, ms * 1e-3);
+            hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+        }
+    }
+    void update_advance_stats(double t, size_t bytes, size_t edges, bool gather) { add_time(gather ? 0 : 1, t); bytes_requested += bytes; edges_visited += edges; }
+    void update_compute_stats(double t, size_t vertices) { add_time(2, t); bytes_requested += (size_t)(vertices * COMPUTE_INT_ELEMENTS * sizeof(int)); }
+    void update_reduce_stats(double t, size_t vertices) { add_time(3, t); bytes_requested += (size_t)(vertices * REDUCE_INT_ELEMENTS * sizeof(int)); }
+    void update_gnf_stats(double t, size_t vertices) { add_time(4, t); bytes_requested += (size_t)(vertices * GNF_INT_ELEMENTS * sizeof(int)); }
+    double get_sustained_bandwidth() { resolve(); return inner_wall_time > 0 ? bytes_requested / (inner_wall_time * 1e9) : 0.0; }    // GB/s
+    double get_edges_rate() { resolve(); return inner_wall_time > 0 ? edges_visited / (inner_wall_time * 1e6) : 0.0; }               // MTEPS
+    void print_timers_stats()
+    {
+        resolve();
         auto line = [this](const char *name, double t) {
             if (t > 0) std::cout << name << " : " << t * 1e3 << " (ms), " << (inner_wall_time > 0 ? 100.0 * t / inner_wall_time : 0.0) << " %" << std::endl;
         };
-        std::cout << std::endl;
+        std::cout << std::endl << (vgl_event_timers() ? "(stream time of each primitive's launches, HIP events)"
+                                                      : "(host wall time per call: asynchronous primitives are charged to the next call that synchronises; VGL_PRIMITIVE_TIMERS=1 brackets them with events)")
+                  << std::endl;
         line("Inner wall    ", inner_wall_time); line("Advance       ", advance_time); line("Gather        ", gather_time); line("Scatter       ", scatter_time);
         line("Compute       ", compute_time); line("Reduce        ", reduce_time); line("GNF           ", gnf_time);
         std::cout << std::endl << "total bandwidth: " << get_sustained_bandwidth() << " GB/s" << std::endl << "edges rate: " << get_edges_rate() << " MTEPS" << std::endl
@@ -981,6 +1048,53 @@ __global__ __launch_bounds__(VGL_ADV_THREADS) void vgl_k_advance_sparse(const in
     for (int j = 0; j < EPT; j++)
         if (srcs[j] >= 0) edge_op(srcs[j], dsts[j], locals[j], process_shift + es[j], (int)(threadIdx.x & 63));
 }
+// advance with SEQUENTIAL ROWS (GraphAbstractionsHIP::enable_sequential_rows): one lane walks the edges of an active vertex in adjacency order
+// between its pre and post operators -- the execution shape of the reference's vector-core kernels (multicore/advance_worker.hpp:62-149: one
+// thread per vertex), whose algorithms accumulate into per-vertex state without atomics and therefore sum in adjacency order.  An operator that
+// only stores to src-indexed data needs no atomics here, and its sums are the reference's chains bit for bit (apps/algorithms/pr.hpp).  No load
+// balancing: a hub row is one lane's loop -- meant for graphs without hubs or for results that must not depend on the schedule.
+template <int MODE, class EdgeOp, class PreOp, class PostOp>     // 0 all-active, 1 dense (flags), 2 sparse (ids)
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_rows(int n, const long long *rowptr, const int *adj, const int *flags, const int *ids, long long process_shift,
+                                                                int row_lo, int row_hi, EdgeOp edge_op, PreOp pre_op, PostOp post_op)
+{
+    if (MODE == 2) {                                    // listed vertices: rows anywhere, adjacency read by the lane itself
+        for (int i = blockIdx.x * VGL_BLOCK + threadIdx.x; i < n; i += gridDim.x * VGL_BLOCK) {
+            const int src = ids[i];
+            if (src < row_lo || src >= row_hi) continue;
+            const long long lo = rowptr[src], hi = rowptr[src + 1];
+            const int lane = (int)(threadIdx.x & 63);
+            pre_op(src, (int)(hi - lo), lane);
+            for (long long e = lo; e < hi; e++) edge_op(src, adj[e], (int)(e - lo), process_shift + e, lane);
+            post_op(src, (int)(hi - lo), lane);
+        }
+        return;
+    }
+    // all vertices / flagged vertices: a workgroup owns 256 consecutive rows, i.e. one contiguous run of the adjacency, and streams it through
+    // LDS in chunks (coalesced loads); every lane then takes its row's entries of the chunk from LDS, in order.  (A lane reading its own row from
+    // memory touches a line of its own per step: the PageRank pull fetched 13.8 x its algorithmic bytes that way, profiles/r04_operator_roofline.json.)
+    constexpr int CHUNK = 4096;
+    __shared__ int s_adj[CHUNK];
+    const int lane = (int)(threadIdx.x & 63);
+    for (int r0 = blockIdx.x * VGL_BLOCK; r0 < n; r0 += gridDim.x * VGL_BLOCK) {
+        const int src = r0 + (int)threadIdx.x;
+        const bool mine = src < n && src >= row_lo && src < row_hi && (MODE != 1 || flags[src] > 0);
+        long long lo = 0, hi = 0;
+        if (src < n) { lo = rowptr[src]; hi = rowptr[src + 1]; }
+        const long long e_first = rowptr[r0], e_last = rowptr[min(r0 + VGL_BLOCK, n)];
+        if (mine) pre_op(src, (int)(hi - lo), lane);
+        for (long long c0 = e_first; c0 < e_last; c0 += CHUNK) {
+            const int m = (int)min((long long)CHUNK, e_last - c0);
+            __syncthreads();                            // (the chunk before has been consumed)
+            for (int k = threadIdx.x; k < m; k += VGL_BLOCK) s_adj[k] = adj[c0 + k];
+            __syncthreads();
+            if (mine) {
+                const long long a = max(lo, c0), b = min(hi, c0 + m);
+                for (long long e = a; e < b; e++) edge_op(src, s_adj[(int)(e - c0)], (int)(e - lo), process_shift + e, lane);
+            }
+        }
+        if (mine) post_op(src, (int)(hi - lo), lane);
+    }
+}
 // per-vertex operator over all vertices / flagged vertices / listed vertices (compute_worker, multicore/compute.hpp:6-58)
 template <int MODE, class Op>     // 0 all-active, 1 dense (flags), 2 sparse (ids)
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_vertex_op(int n, const long long *rowptr, const int *flags, const int *ids, int row_lo, int row_hi, Op op)
@@ -1100,6 +1214,7 @@ static const vgl_empty_edge_op EMPTY_EDGE_OP;
 class GraphAbstractionsHIP {
     VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
     double *reduce_partials = nullptr;          // one per workgroup of a reduce (+ the folded maximum)
+    bool sequential_rows = false;               // enable_sequential_rows()
 
     static int active_count(VGL_Graph &g, VGL_Frontier &f) { return f.get_sparsity_type() == ALL_ACTIVE_FRONTIER ? g.get_vertices_count() : f.size(); }
     static unsigned grid_for(long long n) { long long b = (n + VGL_BLOCK - 1) / VGL_BLOCK; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
@@ -1142,9 +1257,21 @@ class GraphAbstractionsHIP {
         // several ranks (inner_mpi_processing, common/advance.hpp:28-31, nec/advance_worker.hpp:239-251): this rank's vertex range only
         const std::pair<int, int> range = g.get_mpi_thresholds(dir);
         const int row_lo = range.first, row_hi = range.second;
-        if (!is_empty_vertex_op<PreOp>()) vertex_pass(g, f, dir, pre_op, row_lo, row_hi);
         const FrontierSparsityType t = f.get_sparsity_type();
         using E = typename std::decay<EdgeOp>::type;
+        if (sequential_rows) {
+            using P = typename std::decay<PreOp>::type; using Q = typename std::decay<PostOp>::type;
+            const int V = g.get_vertices_count();
+            work = t == ALL_ACTIVE_FRONTIER ? v.edges : f.get_neighbours_count();
+            if (t == ALL_ACTIVE_FRONTIER) hipLaunchKernelGGL((vgl_k_advance_rows<0, E, P, Q>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, v.adj, f.get_flags(), f.get_ids(), process_shift, row_lo, row_hi, edge_op, pre_op, post_op);
+            else if (t == DENSE_FRONTIER) hipLaunchKernelGGL((vgl_k_advance_rows<1, E, P, Q>), dim3(grid_for(V)), dim3(VGL_BLOCK), 0, st, V, v.rowptr, v.adj, f.get_flags(), f.get_ids(), process_shift, row_lo, row_hi, edge_op, pre_op, post_op);
+            else if (f.size() > 0) hipLaunchKernelGGL((vgl_k_advance_rows<2, E, P, Q>), dim3(grid_for(f.size())), dim3(VGL_BLOCK), 0, st, f.size(), v.rowptr, v.adj, f.get_flags(), f.get_ids(), process_shift, row_lo, row_hi, edge_op, pre_op, post_op);
+            VGL_HIP_RT(hipGetLastError());
+            if (sync_after_primitive()) VGL_RUNTIME::sync();
+            performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, dir == GATHER);
+            return;
+        }
+        if (!is_empty_vertex_op<PreOp>()) vertex_pass(g, f, dir, pre_op, row_lo, row_hi);
         if (t == SPARSE_FRONTIER) {
             const int64_t *offs; const int32_t *tile_first; int64_t M;
             VGL_HIP_CALL(vgl_hip_frontier_advance_plan(c, g.get_handle(), f.get_handle(), dir == GATHER, &offs, &tile_first, &M));
@@ -1412,6 +1539,9 @@ private:
     }
 
 public:
+    // advance with one lane per active vertex, edges in adjacency order between pre and post (vgl_k_advance_rows): the reference's vector-core shape
+    void enable_sequential_rows() { sequential_rows = true; }
+    void disable_sequential_rows() { sequential_rows = false; }
     void enable_safe_stores() {}         // no-op off NEC (graph_abstractions_multicore.h:295-296)
     void disable_safe_stores() {}
 };
