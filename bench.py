@@ -229,6 +229,17 @@ def leg_sssp(api, ctx, g, w, E, V, sources, args, extra, cpu):
                               "plan_build_call_wall_ms": res["bellman_ford_direction_optimising"]["plan_build_call_wall_ms"]}
     extra["sssp_value_note"] = ("direction-optimising Bellman-Ford (push <-> blocked pull); the blocked plan is built once per weights and is "
                                 "not in the time; the bucketed schedule (sssp.delta_stepping, plan likewise excluded) is faster still")
+    # what ONE source costs when nothing is prepared: the plan build (wall time of the call) + one run; and the number of sources from which
+    # the plan has paid for itself against the schedule that needs none (all-active push)
+    do, push = res["bellman_ford_direction_optimising"], res["bellman_ford_push_all_active"]
+    ds = res["delta_stepping"]
+    single_ms = do["plan_build_call_wall_ms"] + do["ms"]
+    ds_single_ms = ds["plan_build_ms_once_per_weights_NOT_in_ms"] + ds["ms"]
+    extra["sssp_single_source_plan_inclusive"] = {
+        "direction_optimising": {"ms": round(single_ms, 2), "teps": round(E / (single_ms * 1e-3), 1),
+                                 "break_even_sources_vs_push_all_active": (int(do["plan_build_call_wall_ms"] / max(push["ms"] - do["ms"], 1e-9)) + 1) if push["ms"] > do["ms"] else None},
+        "delta_stepping": {"ms": round(ds_single_ms, 2), "teps": round(E / (ds_single_ms * 1e-3), 1)},
+        "push_all_active_no_plan": {"ms": push["ms"], "teps": push["teps"]}}
     if cpu is not None:
         O, threads = cpu
         rp, adj, wh = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy(), w.cpu().numpy()

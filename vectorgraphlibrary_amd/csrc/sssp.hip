@@ -335,6 +335,7 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     // instead of the V * 4 of an epoch array (two 50 us scans per step of RMAT-24 before, 2.8 of 17.7 ms).  An empty frontier ends the run
     // (do { ... } while(changes), shortest_paths.hpp:112-154); its edge share picks the direction of a DIRECTION_OPT step.
     const int64_t words = vgl_ceil_div(g->V, 64);
+    const bool debug = getenv("VGL_HIP_DEBUG") != nullptr;
     uint64_t *front = g->bm_front, *next = g->bm_next;
     hipLaunchKernelGGL(vgl_k_sssp_seed_bits, dim3(vgl_grid1(words)), dim3(VGL_BLOCK), 0, c->stream, words, source, front, next);
     for (int32_t iter = 1;; iter++) {
@@ -343,6 +344,8 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
         if (F == 0) break;
         st.iterations = iter;
         const bool pull = mode == VGL_HIP_SSSP_PULL || (double)M > share * (double)g->out.edges;
+        if (debug) fprintf(stderr, "[vgl_hip] %s step %d: %lld changed rows, %lld edges (%.3f of all) -> %s\n", who, iter, (long long)F, (long long)M,
+                           (double)M / (double)std::max<int64_t>(g->out.edges, 1), pull ? "pull" : "push");
         if (pull) {
             const vgl_path_blk_op<Path> op{d_dist, next, g->row_begin};
             VGL_TRY((vgl_blocked_pass<vgl_path_blk_op<Path>, true, false>(c, plan->blk, op, "sssp_pull_gather", "sssp_pull_accumulate", false, "sssp_pull_fused")));
