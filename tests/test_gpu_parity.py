@@ -408,6 +408,15 @@ def test_large_scale_properties(kind, scale, ctx):
         finally:
             del os.environ["VGL_DS_SMALL"], os.environ["VGL_DS_WIDE"]
         assert torch.equal(d1.view(torch.int32), d4.view(torch.int32)), f"VGL_DS_WIDE={wide} VGL_DS_SMALL={small}"
+    # round 4: dense steps as blocked passes over the heavy part (1) or both parts (2), every step forced dense, with and without fused tiles
+    for blocked, fuse in (("1", "0"), ("2", "0"), ("2", "64")):
+        os.environ["VGL_DS_BLOCKED"], os.environ["VGL_BLK_FUSE_MIN"], os.environ["VGL_DS_DENSE"], os.environ["VGL_DS_DENSE_BLK"] = blocked, fuse, "0", "0"
+        try:
+            for delta in (3.0, 16.0):
+                d5, _ = api.sssp(g, w, source, api.SSSP_DELTA_STEPPING, delta=delta)
+                assert torch.equal(d1.view(torch.int32), d5.view(torch.int32)), f"VGL_DS_BLOCKED={blocked} fuse {fuse} delta {delta}"
+        finally:
+            del os.environ["VGL_DS_BLOCKED"], os.environ["VGL_BLK_FUSE_MIN"], os.environ["VGL_DS_DENSE"], os.environ["VGL_DS_DENSE_BLK"]
     assert s1["edges_relaxed"] <= s2["edges_relaxed"]
     fin = d1[csr_src] < 3.0e38
     cand = d1[csr_src][fin] + w[fin]

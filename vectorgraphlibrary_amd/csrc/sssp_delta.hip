@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <rocprim/rocprim.hpp>
+#include "vgl_blocked.h"
 
 constexpr int VGL_DS_BLOCKS = 2048;       // persistent grid of the relax kernel
 
@@ -50,6 +51,56 @@ struct vgl_hip_sssp_plan {
     int32_t *vt_aux = nullptr;    // per vertex tile: rows with heavy pending below T
     int64_t *partials = nullptr;  // min-pending reduction (1024) followed by the relax kernels' near-improvement counts (+ 1 flag word)
     uint32_t *tickets = nullptr;  // arrival counters of the min_pending kernel ([1]; [0] unused)
+    // round 4: the two parts laid out for the blocked advance as well (vgl_blocked.h, fused tiles for the dense block pairs): a DENSE step then
+    // streams its part at ~5 TB/s with every random access in LDS instead of one L2 line per gather (the heavy step of the first bucket of an
+    // RMAT-24 run: 465 M edges, 3.4 ms as a static sweep -- the push relax kernel at 0.21 of the HBM peak -- a quarter of the run)
+    vgl_blocked_plan *blk[2] = {nullptr, nullptr};
+};
+
+// the relax of a DENSE step as a blocked pass over a part: rows that are not scheduled load +inf and contribute nothing, every improvement
+// sets both pending bits of its vertex (the robustness rule above) and the improvements below T are counted per wavefront step
+struct vgl_ds_blk_op {
+    typedef uint32_t acc_t;
+    static constexpr bool MARK = true;
+    float *dist;
+    uint8_t *state;
+    const uint8_t *active;
+    float T;
+    int64_t *near_partials;
+    int32_t g_base;
+    __device__ __forceinline__ uint32_t load(int32_t i) const { return active[g_base + i] ? __float_as_uint(dist[g_base + i]) : __float_as_uint(FLT_MAX); }
+    __device__ __forceinline__ uint32_t edge(uint32_t x, float w) const
+    {
+        const float d = __uint_as_float(x);
+        return __float_as_uint(d < FLT_MAX ? __fadd_rn(d, w) : FLT_MAX);        // src_weight + weight (shortest_paths.hpp:126-130)
+    }
+    __device__ __forceinline__ uint32_t identity() const { return __float_as_uint(FLT_MAX); }
+    __device__ __forceinline__ void accumulate(uint32_t *p, uint32_t v) const
+    { __hip_atomic_fetch_min(reinterpret_cast<int *>(p), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) const { return b < a ? b : a; }
+    __device__ __forceinline__ bool finish_m(int32_t v, uint32_t acc) const
+    {
+        const float cand = __uint_as_float(acc);
+        if (!(cand < dist[v])) return false;
+        dist[v] = cand;
+        state[v] = 3;
+        return cand < T;
+    }
+    __device__ __forceinline__ bool partial_m(int32_t v, uint32_t acc) const
+    {
+        const float cand = __uint_as_float(acc);
+        if (!(cand < dist[v])) return false;
+        if (atomicMin(reinterpret_cast<int *>(dist + v), (int)acc) <= (int)acc) return false;
+        state[v] = 3;
+        return cand < T;
+    }
+    __device__ __forceinline__ void mark(int32_t v0, unsigned long long mask, bool) const
+    {
+        atomicAdd((unsigned long long *)&near_partials[(v0 >> 6) & (VGL_DS_BLOCKS - 1)], (unsigned long long)__popcll(mask));
+        near_partials[VGL_DS_BLOCKS] = 1;
+    }
+    __device__ __forceinline__ void finish(int32_t v, uint32_t acc) const { (void)finish_m(v, acc); }
+    __device__ __forceinline__ bool partial(int32_t v, uint32_t acc) const { (void)partial_m(v, acc); return true; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -716,6 +767,25 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     VGL_HIP_TRY(hipMemsetAsync(p->partials, 0, 2 * sizeof(int64_t), st));
     VGL_HIP_TRY(hipStreamSynchronize(st));
     hipFree(temp); hipFree(flags); hipFree(S);
+    // blocked layout of the HEAVY part for its dense steps (VGL_DS_BLOCKED: 0 never, 1 the heavy part, 2 both parts; default: the heavy part
+    // from 2^25 edges -- the build costs about four static sweeps of the part, once per plan).  The light part keeps the static sweep: a
+    // blocked pass streams the WHOLE part and sees the distances of the step's start (Jacobi), so the light rounds of the first bucket took
+    // ten passes of 0.5 ms instead of five sweeps of 0.5 - 0.9 ms over the active rows' edges (RMAT-24: 11.5 ms per run with both parts
+    // blocked against 11.85 with none); the heavy step runs once per bucket over nearly all of its part: 3.37 -> 1.27 ms.
+    {
+        const char *e = getenv("VGL_DS_BLOCKED");
+        const int level = (e && *e) ? atoi(e) : (E >= (1LL << 25) ? 1 : 0);
+        const bool want = level > 0;
+        const char *fm = getenv("VGL_BLK_FUSE_MIN");
+        for (int k = level >= 2 ? 0 : 1; k < 2 && want; k++) {
+            if (part_edges[k] < (1LL << 20) && !(e && *e)) continue;
+            const int fuse_min = (fm && *fm) ? atoi(fm) : (part_edges[k] >= (1LL << 22) ? 16384 : 0);
+            if (vgl_blocked_plan_build(c, p->part[k], g->nrows, g->row_begin, g->V, 1, 0, p->pw[k], VGL_BLK_BITS, &p->blk[k], 32, fuse_min)) {
+                vgl_hip_sssp_plan_destroy(c, p);
+                return 1;
+            }
+        }
+    }
     *out = p;
     return 0;
 }
@@ -726,6 +796,7 @@ int vgl_hip_sssp_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_plan *p)
     if (c) hipStreamSynchronize(c->stream);
     for (int k = 0; k < 2; k++) { hipFree(p->prow[k]); hipFree(p->padj[k]); hipFree(p->pw[k]); hipFree(p->part[k].tile_row); }
     hipFree(p->state); hipFree(p->active); hipFree(p->vt_aux); hipFree(p->partials); hipFree(p->tickets);
+    for (int k = 0; k < 2; k++) if (p->blk[k]) vgl_blocked_plan_destroy(p->blk[k]);
     delete p;
     return 0;
 }
@@ -757,9 +828,14 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
                                p->active, g->vt_cnt, g->vt_deg, p->vt_aux);
             hipLaunchKernelGGL(vgl_k_ds_scan, dim3(1), dim3(VGL_DS_SCAN_THREADS), 0, st, (int)g->nvtiles, g->vt_cnt, g->vt_deg, p->vt_aux, g->vt_cnt_off,
                                g->vt_deg_off, c->d_counters, g->offs);
-            vgl_timed_launch tl(c, "sssp_relax");
-            hipLaunchKernelGGL(vgl_k_ds_relax_static, dim3((unsigned)p->part[k].ntiles), dim3(VGL_BLOCK), 0, st, p->prow[k], p->padj[k], p->pw[k],
-                               p->part[k].tile_row, p->part[k].edges, g->row_begin, p->active, T, d_dist, p->state, near_partials);
+            if (p->blk[k]) {
+                const vgl_ds_blk_op op{d_dist, p->state, p->active, T, near_partials, g->row_begin};
+                VGL_TRY((vgl_blocked_pass<vgl_ds_blk_op, true, false>(c, p->blk[k], op, "sssp_relax", "sssp_relax", false, "sssp_relax")));
+            } else {
+                vgl_timed_launch tl(c, "sssp_relax");
+                hipLaunchKernelGGL(vgl_k_ds_relax_static, dim3((unsigned)p->part[k].ntiles), dim3(VGL_BLOCK), 0, st, p->prow[k], p->padj[k], p->pw[k],
+                                   p->part[k].tile_row, p->part[k].edges, g->row_begin, p->active, T, d_dist, p->state, near_partials);
+            }
         } else {
             if (wide_select) {
                 const int nblk = (int)vgl_ceil_div((int64_t)nvt, VGL_DS_WIDE_TILES);
@@ -808,6 +884,8 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     const int64_t edges_lo = (int64_t)envf("VGL_DS_ELO", std::max<double>(1.0e6, (double)g->out.edges / 16.0));
     const double grow = envf("VGL_DS_GROW", 16.0);
     const double dense_frac = envf("VGL_DS_DENSE", 0.4);    // dense when the predicted rows exceed this share of the part's non-empty rows
+    const double dense_frac_blk = envf("VGL_DS_DENSE_BLK", 0.4);       // ... of a part that has a blocked layout (a blocked pass streams the whole part whatever is scheduled: 0.25 9.7 ms, 0.4 8.8, 0.1 10.8 per RMAT-24 run)
+    auto dense_share = [&](int k) { return p->blk[k] ? dense_frac_blk : dense_frac; };
     int64_t bucket_rows = 0, bucket_edges = 0;
     int64_t pred_light_rows = 0;                             // improvements below T seen by the last relax: the next light frontier, roughly
     // small = expected to schedule at most `small_rows` rows: one selection pass with a packed atomic cursor instead of count + scan +
@@ -816,7 +894,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     const int64_t small_rows = (int64_t)envf("VGL_DS_SMALL", 4096.0);
     bool fresh_bucket = true;
     for (;;) {
-        VGL_TRY(step(1, (double)pred_light_rows > dense_frac * (double)p->rows_nonempty[0], !fresh_bucket && pred_light_rows <= small_rows));
+        VGL_TRY(step(1, (double)pred_light_rows > dense_share(0) * (double)p->rows_nonempty[0], !fresh_bucket && pred_light_rows <= small_rows));
         fresh_bucket = false;
         pred_light_rows = c->h_counters[C_TMP0];
         bucket_rows += c->h_counters[C_FRONT];
@@ -826,7 +904,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
         const bool near = c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0;
         if (near) continue;                                             // the bucket received improvements: light edges again
         if (c->h_counters[C_TMP1] > 0) {                                // bucket settled: its heavy edges, once
-            VGL_TRY(step(2, (double)c->h_counters[C_TMP1] > dense_frac * (double)p->rows_nonempty[1], c->h_counters[C_TMP1] <= small_rows));
+            VGL_TRY(step(2, (double)c->h_counters[C_TMP1] > dense_share(1) * (double)p->rows_nonempty[1], c->h_counters[C_TMP1] <= small_rows));
             pred_light_rows = c->h_counters[C_TMP0];
             bucket_edges += c->h_counters[C_NEIGH];
             if (c->h_counters[C_FRONT] > 0 && c->h_counters[C_TMP0] != 0) continue;
