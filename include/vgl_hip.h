@@ -461,6 +461,8 @@ int vgl_hip_timing_enable(vgl_hip_ctx *ctx, int enable);
 /* restrict the bracketing to ONE kernel name (NULL or "" = all): two event records cost ~4-5 us of stream time per launch, which is
  * 10 % of a BFS traversal when every kernel is bracketed -- the timed region of bench.py brackets only the kernel it reports */
 int vgl_hip_timing_only(vgl_hip_ctx *ctx, const char *kernel_name);
+/* of the launches that would be bracketed only every stride-th is (1 = all): sampling instead of perturbing a launch-bound loop */
+int vgl_hip_timing_stride(vgl_hip_ctx *ctx, int stride);
 int vgl_hip_timing_reset(vgl_hip_ctx *ctx);
 /* kernel_name: "bfs_bottom_up", "bfs_top_down", "gnf", "sssp_relax", "pr_pull", "cc_hook"; returns launches and total ms */
 int vgl_hip_timing_get(vgl_hip_ctx *ctx, const char *kernel_name, int64_t *launches, double *total_ms);

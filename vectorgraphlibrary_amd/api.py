@@ -51,10 +51,12 @@ class Context:
         return torch.empty(int(n), dtype=dtype, device=self.device)
 
     # ---- timing hooks (bench.py roofline) ----
-    def timing(self, enable=True, only=None):
-        """bracket kernel launches with HIP events (only: one kernel name; the rest then run without the event records)"""
+    def timing(self, enable=True, only=None, stride=1):
+        """bracket kernel launches with HIP events (only: one kernel name; the rest then run without the event records; stride: only every
+        stride-th of the bracketed launches)"""
         _l.check(self.L.vgl_hip_timing_enable(self.h, int(enable)))
         _l.check(self.L.vgl_hip_timing_only(self.h, only.encode() if only else None))
+        _l.check(self.L.vgl_hip_timing_stride(self.h, int(stride)))
         _l.check(self.L.vgl_hip_timing_reset(self.h))
 
     def timing_get(self, name):

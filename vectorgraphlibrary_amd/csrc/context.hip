@@ -149,6 +149,16 @@ int vgl_hip_timing_enable(vgl_hip_ctx *c, int enable)
     c->timing = enable != 0;
     return 0;
 }
+// bracket only every stride-th launch that would be bracketed (1 = all): two event records cost ~5 us of stream time, three bracketed
+// launches per BFS traversal are 5 % of it; a stride that is not a multiple of the launches per traversal samples every level evenly
+int vgl_hip_timing_stride(vgl_hip_ctx *c, int stride)
+{
+    if (!c) VGL_FAIL("null context");
+    c->timing_stride = stride > 1 ? stride : 1;
+    c->timing_seen = 0;
+    return 0;
+}
+
 int vgl_hip_timing_only(vgl_hip_ctx *c, const char *kernel_name)
 {
     if (!c) VGL_FAIL("null context");
@@ -201,6 +211,7 @@ vgl_timed_launch::vgl_timed_launch(vgl_hip_ctx *c, const char *name) : ctx(c), s
 {
     if (!c->timing) return;
     if (!c->timing_only.empty() && c->timing_only != name) return;      // only the named kernel pays for its two event records
+    if (c->timing_stride > 1 && (c->timing_seen++ % c->timing_stride) != 0) return;          // ... and only every stride-th of its launches
     slot = &c->slots[name];
     a = vgl_get_event(c);
     b = vgl_get_event(c);

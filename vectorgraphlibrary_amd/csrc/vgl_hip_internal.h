@@ -58,6 +58,8 @@ struct vgl_hip_ctx {
     size_t partials_cap = 0;
     bool timing = false;
     std::string timing_only;          // when not empty: only launches under this name are bracketed by events
+    int timing_stride = 1;            // ... and of those only every stride-th
+    int64_t timing_seen = 0;
     std::map<std::string, vgl_timing_slot> slots;
     std::vector<hipEvent_t> event_pool;
 };

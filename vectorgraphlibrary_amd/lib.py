@@ -161,6 +161,7 @@ _SIGNATURES = {
     "vgl_hip_timing_enable": [_p, _int],
     "vgl_hip_timing_only": [_p, C.c_char_p],
     "vgl_hip_timing_reset": [_p],
+    "vgl_hip_timing_stride": [_p, _int],
     "vgl_hip_timing_get": [_p, C.c_char_p, C.POINTER(_i64), C.POINTER(_dbl)],
 }
 _SPECIAL = {
