@@ -110,6 +110,11 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *ctx, vgl_hip_graph *g);
 #define VGL_HIP_FRONTIER_ALL_ACTIVE 2
 int vgl_hip_frontier_create(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_frontier **out);
 int vgl_hip_frontier_destroy(vgl_hip_ctx *ctx, vgl_hip_frontier *f);
+/* a handle over flags / ids arrays the caller owns (device-accessible int32[V] each) -- for a backend bound to the reference's own frontier
+ * containers (FrontierCSR / FrontierVectorCSR, base_frontier.h:5-62), whose host code reads and writes those arrays; set_state tells the handle
+ * what they hold (size, sum of degrees, sparsity as VGL_HIP_FRONTIER_*) and which graph handle (direction container) the frontier refers to. */
+int vgl_hip_frontier_create_on(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t *d_flags, int32_t *d_ids, vgl_hip_frontier **out);
+int vgl_hip_frontier_set_state(vgl_hip_ctx *ctx, vgl_hip_frontier *f, vgl_hip_graph *g, int32_t size, int64_t neighbours, int sparsity);
 int vgl_hip_frontier_set_all_active(vgl_hip_ctx *ctx, vgl_hip_frontier *f);      /* frontier/.../modification.hpp set_all_active */
 int vgl_hip_frontier_clear(vgl_hip_ctx *ctx, vgl_hip_frontier *f);
 int vgl_hip_frontier_add_vertex(vgl_hip_ctx *ctx, vgl_hip_frontier *f, int32_t v); /* only into an empty frontier (modification.hpp:33-36) */

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Adds the __USE_HIP__ architecture to a COPY of the VGL source tree.
+
+    python3 integration/apply_hip_binding.py /tmp/vgl_with_hip        # the directory holds a copy of the reference checkout
+
+What a maintainer would commit, expressed as anchored edits instead of a unified diff (a diff would carry lines of the reference's source as
+context; the anchors below are the shortest strings that locate each edit):
+  * the new backend directory vgl_compute_api/hip/ (copied from integration/vgl_compute_api/hip/)
+  * architecture_independent_api.h : device-lambda argument macros, VGL_GRAPH_ABSTRACTIONS, the atomic VGL_SRC_ID_ADD / VGL_INC / VGL_DEC
+  * settings.h                      : VECTOR_LENGTH = 64 (one wavefront), thresholds
+  * common dispatch (advance.hpp, compute.hpp) : call the workers directly, not inside an OpenMP parallel region
+  * common/graph_abstractions.h     : include the backend header
+  * MemoryAPI                       : hipMallocManaged / hipFree
+  * VerticesArray / EdgesArray / container accessors : callable from device code
+  * frontier containers             : friend class GraphAbstractionsHIP
+  * apps/Makefile                   : a hip stanza
+Every rule must apply (an anchor that is not found is an error): the script is also the test that the reference still has the shape the
+binding was written against.  tests/test_reference_binding.py applies it to a copy in /tmp and compiles apps/bfs/bfs.cpp with hipcc."""
+import os
+import re
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GPU_OR_HIP = "#if defined(__USE_GPU__) || defined(__USE_HIP__)"
+
+# (file, kind, anchor regex, text[, expected count[, which]])   kinds: sub = replace every match; after / before = insert a block next to the
+# line of match number `which` (default 0)
+RULES = [
+    # ---- architecture selection ----
+    ("architecture_independent_api.h", "sub", r"^#ifdef __USE_GPU__$(?!\n#define VGL_GRAPH_ABSTRACTIONS)", GPU_OR_HIP, 5),
+    ("architecture_independent_api.h", "before", r"^#define VGL_FRONTIER VGL_Frontier",
+     "#ifdef __USE_HIP__\n#define VGL_GRAPH_ABSTRACTIONS GraphAbstractionsHIP\n#endif\n\n"),
+    ("settings.h", "before", r"^// ARM/Intel/AMD multicore properties",
+     "// AMD Instinct (HIP) properties: a vector is one 64-lane wavefront\n"
+     "/////////////////////////////////////////////////////////////////////////////////////////////////////////////////////\n\n"
+     "#ifdef __USE_HIP__\n#define VECTOR_LENGTH 64\n#define VECTOR_LENGTH_POW 6\n#define MAX_SX_AURORA_THREADS 8\n#define LLC_CACHE_SIZE 4*1024*1024\n#endif\n\n"
+     "/////////////////////////////////////////////////////////////////////////////////////////////////////////////////////\n"),
+    # ---- common dispatch: workers launch kernels, they are not OpenMP bodies ----
+    ("vgl_compute_api/common/advance.hpp", "sub", r"^(\s*)#ifdef __USE_GPU__$", r"\1" + GPU_OR_HIP, 8),
+    ("vgl_compute_api/common/compute.hpp", "sub", r"^(\s*)#ifdef __USE_GPU__$", r"\1" + GPU_OR_HIP, 4),
+    ("vgl_compute_api/common/graph_abstractions.h", "before", r"^#if defined\(__USE_MULTICORE__\)$",
+     "#ifdef __USE_HIP__\n#include \"vgl_compute_api/hip/graph_abstractions_hip.h\"\n#endif\n\n"),
+    # ---- algorithm headers whose operator lambdas cannot be device code under clang: coloring.hpp calls its host-only helpers (clear_bit,
+    #      smallest_bit_pos) from them, tc.hpp hands a device lambda to the host-side copy_if (nvcc accepts both in never-instantiated templates) ----
+    ("graph_library.h", "sub", r'^(#include "algorithms/coloring/coloring.h")$', r"#ifndef __USE_HIP__\n\1\n#endif"),
+    ("graph_library.h", "sub", r'^(#include "algorithms/tc/tc.h")$', r"#ifndef __USE_HIP__\n\1\n#endif"),
+    # ---- memory: managed allocations, as the CUDA flavour (__USE_MANAGED_MEMORY__, settings.h) ----
+    ("vgl_runtime/helpers/memory_API/memory_API.hpp", "before", r"^\s*#elif defined\(__USE_KNL__\)$",
+     "    #elif defined(__USE_HIP__)\n    if(hipMallocManaged((void**)_ptr, _size * sizeof(_T)) != hipSuccess) throw \"Error in MemoryAPI::allocate_array : hipMallocManaged failed\";\n", 2, 0),
+    ("vgl_runtime/helpers/memory_API/memory_API.hpp", "before", r"^\s*#elif defined\(__USE_KNL__\)$",
+     "        #elif defined(__USE_HIP__)\n        hipFree((void*)_ptr);\n", 2, 1),
+    ("vgl_runtime/helpers/memory_API/memory_API.h", "before", r"^class MemoryAPI", "#ifdef __USE_HIP__\n#include <hip/hip_runtime.h>\n#endif\n\n"),
+    # ---- user data and containers readable from device code ----
+    ("vgl_datastructures/vertices_array/vertices_array.h", "sub", r"#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)", GPU_OR_HIP),
+    ("vgl_datastructures/edges_array/edges_array.h", "sub", r"#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)", GPU_OR_HIP),
+    # ---- host-side container code that exists per architecture: take the plain C++ variant of the CUDA flavour ----
+    ("vgl_datastructures/graphs/undirected_containers/edges_list/preprocess_into_segmented.hpp", "sub",
+     r"^#ifdef __USE_GPU__$(?=\nvoid EdgesListGraph::preprocess_into_segmented)", GPU_OR_HIP),
+    ("vgl_runtime/helpers/sorter/sorter.h", "sub", r"^(\s*)#ifdef __USE_MULTICORE__$", r"\1#if defined(__USE_MULTICORE__) || defined(__USE_HIP__)"),
+    ("vgl_datastructures/graphs/undirected_containers/csr/reorder.hpp", "sub", r"defined\(__USE_NEC_SX_AURORA__\) \|\| defined\(__USE_MULTICORE__\)$",
+     "defined(__USE_NEC_SX_AURORA__) || defined(__USE_MULTICORE__) || defined(__USE_HIP__)", 2),
+    ("vgl_datastructures/graphs/undirected_containers/vect_csr/reorder.hpp", "sub", r"defined\(__USE_NEC_SX_AURORA__\) \|\| defined\(__USE_MULTICORE__\)$",
+     "defined(__USE_NEC_SX_AURORA__) || defined(__USE_MULTICORE__) || defined(__USE_HIP__)", 2),
+    # ---- the backend writes the frontier containers, like the other backends ----
+    ("vgl_datastructures/frontier/containers/csr/frontier_csr.h", "after", r"friend class GraphAbstractionsGPU;", "    friend class GraphAbstractionsHIP;\n"),
+    ("vgl_datastructures/frontier/containers/vect_csr/frontier_vect_csr.h", "after", r"friend class GraphAbstractionsGPU;", "    friend class GraphAbstractionsHIP;\n"),
+    ("vgl_datastructures/frontier/containers/csr_vg/frontier_csr_vg.h", "after", r"friend class GraphAbstractionsGPU;", "    friend class GraphAbstractionsHIP;\n"),
+    ("vgl_datastructures/frontier/containers/edges_list/frontier_edges_list.h", "after", r"friend class GraphAbstractionsGPU;", "    friend class GraphAbstractionsHIP;\n"),
+]
+
+
+def apply_tree_rule(root, rule):
+    """("*", "sub_tree", regex, replacement, expected total, excluded files): every header and source below the tree except the CUDA backend"""
+    _, _, anchor, text, expected, excluded = rule
+    rx = re.compile(anchor, re.M)
+    total = 0
+    for d, _dirs, files in os.walk(root):
+        rel = os.path.relpath(d, root)
+        if rel.startswith(".git") or rel.startswith(os.path.join("vgl_compute_api", "gpu")):
+            continue
+        for name in files:
+            if not name.endswith((".h", ".hpp", ".cpp")) or os.path.normpath(os.path.join(rel, name)) in excluded:
+                continue
+            full = os.path.join(d, name)
+            with open(full, errors="ignore") as f:
+                src = f.read()
+            n = len(rx.findall(src))
+            if n:
+                with open(full, "w") as f:
+                    f.write(rx.sub(text, src))
+                total += n
+    if total != expected:
+        raise SystemExit(f"apply_hip_binding: tree rule /{anchor}/ matched {total} places, expected {expected}")
+
+
+def apply_rule(root, rule):
+    if rule[1] == "sub_tree":
+        return apply_tree_rule(root, rule)
+    path, kind, anchor, text = rule[:4]
+    expected = rule[4] if len(rule) > 4 else 1
+    which = rule[5] if len(rule) > 5 else 0
+    full = os.path.join(root, path)
+    with open(full) as f:
+        src = f.read()
+    rx = re.compile(anchor, re.M)
+    found = len(rx.findall(src))
+    if found != expected:
+        raise SystemExit(f"apply_hip_binding: {path}: anchor /{anchor}/ found {found} times, expected {expected}")
+    if kind == "sub":
+        src = rx.sub(text, src)
+    else:
+        m = list(rx.finditer(src))[which]
+        line_start = src.rfind("\n", 0, m.start()) + 1
+        line_end = src.find("\n", m.end())
+        line_end = len(src) if line_end < 0 else line_end + 1
+        pos = line_start if kind == "before" else line_end
+        src = src[:pos] + text + src[pos:]
+    with open(full, "w") as f:
+        f.write(src)
+
+
+def main():
+    if len(sys.argv) != 2 or not os.path.isfile(os.path.join(sys.argv[1], "graph_library.h")):
+        raise SystemExit("usage: apply_hip_binding.py <directory holding a copy of the VGL source tree>")
+    root = os.path.abspath(sys.argv[1])
+    if os.path.exists(os.path.join(root, "vgl_compute_api", "hip")):
+        raise SystemExit("apply_hip_binding: this tree already has vgl_compute_api/hip")
+    for rule in RULES:
+        apply_rule(root, rule)
+    shutil.copytree(os.path.join(HERE, "vgl_compute_api", "hip"), os.path.join(root, "vgl_compute_api", "hip"))
+    print(f"apply_hip_binding: {len(RULES)} edits applied, vgl_compute_api/hip added")
+
+
+if __name__ == "__main__":
+    main()

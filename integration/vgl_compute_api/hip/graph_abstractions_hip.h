@@ -1,0 +1,512 @@
+// graph_abstractions_hip.h -- the MI355X backend class ON THE REFERENCE'S OWN CONTAINERS.  This file is what a VGL maintainer adds as
+// vgl_compute_api/hip/graph_abstractions_hip.h (integration/apply_hip_binding.py copies it there and makes the few edits of INTEGRATION.md
+// section 2 to the surrounding files): a class derived from GraphAbstractions, selected by -D __USE_HIP__ through VGL_GRAPH_ABSTRACTIONS
+// (architecture_independent_api.h), with the worker set the common dispatch layer calls (common/advance.hpp, compute.hpp, reduce.hpp,
+// generate_new_frontier.hpp) -- the shape of vgl_compute_api/template/graph_abstractions_template.h:5-107 and of the CUDA backend
+// vgl_compute_api/gpu/graph_abstractions_gpu.h:17-190.  It reads CSRGraph / VectorCSRGraph through their public accessors and writes
+// FrontierCSR / FrontierVectorCSR through friend access, exactly like GraphAbstractionsGPU / GraphAbstractionsMulticore.
+//
+//   kernels   : vectorgraphlibrary_amd/hip/vgl_hip_kernels.hpp (templated on the user's device lambdas; plain pointers only)
+//   library   : libvgl_hip.so through the C ABI include/vgl_hip.h -- graph handles BORROW the containers' vertex_pointers / adjacent_ids,
+//               frontier handles BORROW the containers' flags / ids (vgl_hip_frontier_create_on), so host code of the reference that reads or
+//               writes those arrays (add_vertex, print, the seq_* checkers) sees what the kernels see
+//   memory    : MemoryAPI::allocate_array is hipMallocManaged under __USE_HIP__ (the reference's own __USE_MANAGED_MEMORY__ scheme, settings.h:81)
+//
+// Containers served: CSR_GRAPH (advance_worker.hpp:62-149, generate_new_frontier.hpp:113-164) and VECTOR_CSR_GRAPH with its three degree
+// ranges and the padded vector extension (advance_worker.hpp:204-319, advance_{all_active,dense,sparse}.hpp, generate_new_frontier.hpp:29-111):
+// the collective range of an ALL_ACTIVE or DENSE frontier walks the VE copy of the adjacency and hands the collective operators VE-space
+// global_edge_pos (process shift of VE_STORAGE + segment start + edge_pos * VECTOR_LENGTH + lane), a SPARSE frontier hands them CSR positions,
+// as the reference does.  EDGES_LIST_GRAPH and CSR_VG_GRAPH throw (as the CUDA backend does for what it lacks, gpu/advance.hpp:37).
+// Every primitive returns synchronised (SAFE_KERNEL_CALL of the CUDA backend, cuda_error_handling.h:15-27).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <type_traits>
+#include "vgl_hip_kernels.hpp"          // -I <repository>/vectorgraphlibrary_amd/hip
+#include "vector_register/vector_registers.h"
+
+#define VGL_HIP_BIND_CALL(expr) do { if ((expr) != 0) throw vgl_hip_last_error(); } while (0)
+#define VGL_HIP_BIND_RT(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw hipGetErrorString(_e); } while (0)
+
+// the collective range of a VECTOR_CSR_GRAPH over its vector extension: one wavefront per segment of VECTOR_LENGTH = 64 vertices, lane i owns vertex
+// first + i and walks its entries in order between its pre and post operators (advance_all_active.hpp:134-225, advance_dense.hpp:137-235); the
+// loads of ve_adjacent_ids are one coalesced 256-byte row per step.  DENSE: edges of flagged vertices only; pre / post for every vertex of the
+// range (advance_dense.hpp:161-166,226-232 call them unconditionally -- kept as the reference has it).
+template <bool DENSE, class EdgeOp, class PreOp, class PostOp>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_vector_extension(int segments, int starting_vertex, int vertices_count, const long long *vertex_pointers,
+                                                                            const long long *group_ptrs, const int *group_sizes, const int *ve_adjacent_ids,
+                                                                            const int *flags, long long process_shift, EdgeOp edge_op, PreOp pre_op, PostOp post_op)
+{
+    const int segment = (int)((blockIdx.x * (unsigned)VGL_BLOCK + threadIdx.x) >> 6);
+    const int lane = (int)(threadIdx.x & 63);
+    if (segment >= segments) return;
+    const int src_id = segment * 64 + starting_vertex + lane;
+    const long long segment_edges_start = group_ptrs[segment];
+    const int segment_connections_count = group_sizes[segment];
+    const bool present = src_id < vertices_count;
+    int connections_count = 0;
+    if (present && segment_connections_count > 0) connections_count = (int)(vertex_pointers[src_id + 1] - vertex_pointers[src_id]);
+    const bool walks = present && (!DENSE || flags[src_id] > 0);
+    if (present) pre_op(src_id, connections_count, lane);
+    for (int edge_pos = 0; edge_pos < segment_connections_count; edge_pos++) {
+        const long long internal_edge_pos = segment_edges_start + (long long)edge_pos * 64 + lane;
+        if (walks && edge_pos < connections_count) edge_op(src_id, ve_adjacent_ids[internal_edge_pos], edge_pos, process_shift + internal_edge_pos, lane);
+    }
+    if (present) post_op(src_id, connections_count, lane);
+}
+// sizes and degree sums of the three parts of a FrontierVectorCSR (estimate_sorted_frontier_part_size, generate_new_frontier.hpp:3-27) from the flags
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_frontier_parts(int vertices_count, const int *flags, const long long *vertex_pointers, int ve_threshold, int vc_threshold,
+                                                                  unsigned long long *out)      // out[0..2] sizes, out[3..5] neighbours
+{
+    unsigned long long n[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    for (int v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < vertices_count; v += gridDim.x * VGL_BLOCK)
+        if (flags[v] > 0) {
+            const int part = v < ve_threshold ? 0 : (v < vc_threshold ? 1 : 2);
+            n[part] += 1; d[part] += (unsigned long long)(vertex_pointers[v + 1] - vertex_pointers[v]);
+        }
+    for (int p = 0; p < 3; p++) {
+        for (int o = 32; o > 0; o >>= 1) { n[p] += __shfl_xor(n[p], o); d[p] += __shfl_xor(d[p], o); }
+        if ((threadIdx.x & 63) == 0 && (n[p] | d[p])) { atomicAdd(&out[p], n[p]); atomicAdd(&out[3 + p], d[p]); }
+    }
+}
+// SPARSE frontier of a VECTOR_CSR_GRAPH: ids below the vector-core threshold take (edge_op, pre, post), the others the collective set; ids are
+// degree-sorted positions, so the classes ARE id ranges (vect_csr_graph.h:40-41)
+template <class A, class B>
+struct vgl_range_edge_op {
+    A first; B collective; int threshold;
+    __device__ __forceinline__ void operator()(int src, int dst, int local, long long global, int lane) const
+    {
+        if (src < threshold) first(src, dst, local, global, lane);
+        else collective(src, dst, local, global, lane);
+    }
+};
+template <class A, class B>
+struct vgl_range_vertex_op {
+    A first; B collective; int threshold;
+    __device__ __forceinline__ void operator()(int src, int connections, int lane) const
+    {
+        if (src < threshold) first(src, connections, lane);
+        else collective(src, connections, lane);
+    }
+};
+
+class GraphAbstractionsHIP : public GraphAbstractions
+{
+private:
+    vgl_hip_ctx *ctx;
+    hipStream_t stream;
+    double *reduce_partials;                        // 1024 partials + the folded maximum
+    unsigned long long *part_counters;              // managed: vgl_k_frontier_parts
+    std::map<void *, vgl_hip_graph *> graph_handles;        // one per direction container (its vertex_pointers / adjacent_ids are borrowed)
+    std::map<void *, vgl_hip_frontier *> frontier_handles;  // one per frontier container (its flags / ids are borrowed)
+
+    static int grid_for(long long n) { return (int)std::min<long long>(4096, std::max<long long>(1, (n + VGL_BLOCK - 1) / VGL_BLOCK)); }
+    static int sparsity_code(FrontierSparsityType t)
+    { return t == ALL_ACTIVE_FRONTIER ? VGL_HIP_FRONTIER_ALL_ACTIVE : (t == DENSE_FRONTIER ? VGL_HIP_FRONTIER_DENSE : VGL_HIP_FRONTIER_SPARSE); }
+    void finish() { VGL_HIP_BIND_RT(hipGetLastError()); VGL_HIP_BIND_RT(hipStreamSynchronize(stream)); }
+
+    template <typename GraphContainer>
+    vgl_hip_graph *handle_of(GraphContainer &_graph)
+    {
+        auto it = graph_handles.find((void *)&_graph);
+        if (it != graph_handles.end()) return it->second;
+        vgl_hip_graph *h = nullptr;
+        VGL_HIP_BIND_CALL(vgl_hip_graph_create(ctx, _graph.get_vertices_count(), 0, _graph.get_vertices_count(), (const int64_t *)_graph.get_vertex_pointers(),
+                                               _graph.get_adjacent_ids(), _graph.get_edges_count(), nullptr, nullptr, 0, &h));
+        graph_handles[(void *)&_graph] = h;
+        return h;
+    }
+    // the frontier container may have been changed by host code since the last primitive (add_vertex, clear, set_all_active write its fields and
+    // arrays directly): its description is taken as it stands before every use
+    template <typename FrontierContainer>
+    vgl_hip_frontier *handle_of(FrontierContainer &_frontier, vgl_hip_graph *_graph_handle)
+    {
+        vgl_hip_frontier *h = nullptr;
+        auto it = frontier_handles.find((void *)&_frontier);
+        if (it != frontier_handles.end()) h = it->second;
+        else {
+            VGL_HIP_BIND_CALL(vgl_hip_frontier_create_on(ctx, _graph_handle, _frontier.flags, _frontier.ids, &h));
+            frontier_handles[(void *)&_frontier] = h;
+        }
+        VGL_HIP_BIND_CALL(vgl_hip_frontier_set_state(ctx, h, _graph_handle, _frontier.size, _frontier.neighbours_count, sparsity_code(_frontier.sparsity_type)));
+        return h;
+    }
+
+    // per-vertex operator over the active vertices of a range of ids
+    template <typename Op>
+    void vertex_pass(int _vertices_count, const long long *_vertex_pointers, FrontierSparsityType _type, int *_flags, int *_ids, int _frontier_size,
+                     int _row_lo, int _row_hi, Op &&op)
+    {
+        using O = typename std::decay<Op>::type;
+        if (_type == ALL_ACTIVE_FRONTIER)
+            hipLaunchKernelGGL((vgl_k_vertex_op<0, O>), dim3(grid_for(_vertices_count)), dim3(VGL_BLOCK), 0, stream, _vertices_count, _vertex_pointers, _flags, _ids, _row_lo, _row_hi, op);
+        else if (_type == DENSE_FRONTIER)
+            hipLaunchKernelGGL((vgl_k_vertex_op<1, O>), dim3(grid_for(_vertices_count)), dim3(VGL_BLOCK), 0, stream, _vertices_count, _vertex_pointers, _flags, _ids, _row_lo, _row_hi, op);
+        else if (_frontier_size > 0)
+            hipLaunchKernelGGL((vgl_k_vertex_op<2, O>), dim3(grid_for(_frontier_size)), dim3(VGL_BLOCK), 0, stream, _frontier_size, _vertex_pointers, _flags, _ids, _row_lo, _row_hi, op);
+    }
+    template <typename Op> static constexpr bool is_empty_op() { return std::is_empty<typename std::decay<Op>::type>::value && std::is_same<typename std::decay<Op>::type, decltype(EMPTY_VERTEX_OP)>::value; }
+
+    // edges of the active vertices with ids in [_row_lo, _row_hi): static edge tiles (ALL_ACTIVE / DENSE) or the frontier's own edge space (SPARSE)
+    template <typename GraphContainer, typename FrontierContainer, typename EdgeOp>
+    void edge_pass(GraphContainer &_graph, FrontierContainer &_frontier, long long _process_shift, int _row_lo, int _row_hi, EdgeOp &&edge_op)
+    {
+        using E = typename std::decay<EdgeOp>::type;
+        LOAD_FRONTIER_DATA(_frontier);
+        long long *vertex_pointers = _graph.get_vertex_pointers();
+        int *adjacent_ids = _graph.get_adjacent_ids();
+        const long long edges_count = _graph.get_edges_count();
+        vgl_hip_graph *gh = handle_of(_graph);
+        if (_frontier.get_sparsity_type() == SPARSE_FRONTIER) {
+            if (frontier_size == 0) return;
+            vgl_hip_frontier *fh = handle_of(_frontier, gh);
+            const int64_t *offs; const int32_t *tile_first; int64_t M;
+            VGL_HIP_BIND_CALL(vgl_hip_frontier_advance_plan(ctx, gh, fh, 0, &offs, &tile_first, &M));
+            if (M > 0)
+                hipLaunchKernelGGL((vgl_k_advance_sparse<E>), dim3((unsigned)((M + VGL_TILE - 1) / VGL_TILE)), dim3(VGL_ADV_THREADS), 0, stream, frontier_ids, offs, tile_first,
+                                   frontier_size, (long long)M, vertex_pointers, adjacent_ids, _process_shift, _row_lo, _row_hi, edge_op);
+            return;
+        }
+        if (edges_count == 0 || _row_hi <= _row_lo) return;
+        const int32_t *tile_row; int64_t ntiles;
+        VGL_HIP_BIND_CALL(vgl_hip_graph_tile_rows(gh, 0, &tile_row, &ntiles));
+        // rows are stored in id order: the tiles past the last edge of row _row_hi - 1 hold nothing of the range
+        const long long last_edge = vertex_pointers[_row_hi];
+        const long long first_edge = vertex_pointers[_row_lo];
+        if (last_edge <= first_edge) return;
+        const unsigned tiles = (unsigned)std::min<long long>(ntiles, (last_edge + VGL_TILE - 1) / VGL_TILE);
+        if (_frontier.get_sparsity_type() == DENSE_FRONTIER)
+            hipLaunchKernelGGL((vgl_k_advance_static<true, E>), dim3(tiles), dim3(VGL_BLOCK), 0, stream, vertex_pointers, adjacent_ids, tile_row, edges_count, _process_shift,
+                               frontier_flags, _row_lo, _row_hi, edge_op);
+        else
+            hipLaunchKernelGGL((vgl_k_advance_static<false, E>), dim3(tiles), dim3(VGL_BLOCK), 0, stream, vertex_pointers, adjacent_ids, tile_row, edges_count, _process_shift,
+                               frontier_flags, _row_lo, _row_hi, edge_op);
+    }
+
+    // compute inner implementation
+    template <typename ComputeOperation, typename GraphContainer, typename FrontierContainer>
+    void compute_worker(GraphContainer &_graph, FrontierContainer &_frontier, ComputeOperation &&compute_op);
+    template <typename ComputeOperation>
+    void compute_worker(CSRGraph &_graph, FrontierCSR &_frontier, ComputeOperation &&compute_op)
+    { compute_on_csr_pointers(_graph, _frontier, compute_op); }
+    template <typename ComputeOperation>
+    void compute_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, ComputeOperation &&compute_op)
+    { compute_on_csr_pointers(_graph, _frontier, compute_op); }
+    template <typename ComputeOperation, typename GraphContainer, typename FrontierContainer>
+    void compute_on_csr_pointers(GraphContainer &_graph, FrontierContainer &_frontier, ComputeOperation &&compute_op)
+    {
+        LOAD_FRONTIER_DATA(_frontier);
+        const int vertices_count = _graph.get_vertices_count();
+        vertex_pass(vertices_count, _graph.get_vertex_pointers(), _frontier.get_sparsity_type(), frontier_flags, frontier_ids, frontier_size, 0, vertices_count, compute_op);
+        finish();
+    }
+
+    // reduce inner implementation
+    template <typename _T, typename ReduceOperation, typename GraphContainer, typename FrontierContainer>
+    void reduce_worker(GraphContainer &_graph, FrontierContainer &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result);
+    template <typename _T, typename ReduceOperation>
+    void reduce_worker(CSRGraph &_graph, FrontierCSR &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
+    { reduce_on_csr_pointers(_graph, _frontier, reduce_op, _reduce_type, _result); }
+    template <typename _T, typename ReduceOperation>
+    void reduce_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
+    { reduce_on_csr_pointers(_graph, _frontier, reduce_op, _reduce_type, _result); }
+    template <typename _T, typename ReduceOperation, typename GraphContainer, typename FrontierContainer>
+    void reduce_on_csr_pointers(GraphContainer &_graph, FrontierContainer &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
+    {
+        if (_reduce_type != REDUCE_SUM && _reduce_type != REDUCE_MAX) throw "Error in GraphAbstractionsHIP::reduce_worker: unsupported reduce type";   // multicore/reduce.hpp:144-150
+        using R = typename std::decay<ReduceOperation>::type;
+        LOAD_FRONTIER_DATA(_frontier);
+        const long long *vertex_pointers = _graph.get_vertex_pointers();
+        const FrontierSparsityType t = _frontier.get_sparsity_type();
+        const int n = t == SPARSE_FRONTIER ? frontier_size : _graph.get_vertices_count();
+        _result = 0;
+        if (n <= 0) return;
+        const int nb = (int)std::min<long long>(1024, ((long long)n + VGL_BLOCK - 1) / VGL_BLOCK);
+        const bool mx = _reduce_type == REDUCE_MAX;
+#define VGL_BIND_REDUCE(MODE)                                                                                                                                     \
+        do {                                                                                                                                                      \
+            if (mx) hipLaunchKernelGGL((vgl_k_reduce_partials<MODE, true, R>), dim3(nb), dim3(VGL_BLOCK), 0, stream, n, vertex_pointers, frontier_flags, frontier_ids, reduce_op, reduce_partials); \
+            else hipLaunchKernelGGL((vgl_k_reduce_partials<MODE, false, R>), dim3(nb), dim3(VGL_BLOCK), 0, stream, n, vertex_pointers, frontier_flags, frontier_ids, reduce_op, reduce_partials); \
+        } while (0)
+        if (t == ALL_ACTIVE_FRONTIER) VGL_BIND_REDUCE(0);
+        else if (t == DENSE_FRONTIER) VGL_BIND_REDUCE(1);
+        else VGL_BIND_REDUCE(2);
+#undef VGL_BIND_REDUCE
+        VGL_HIP_BIND_RT(hipGetLastError());
+        double r = 0.0;
+        if (mx) {
+            hipLaunchKernelGGL(vgl_k_max_fold, dim3(1), dim3(VGL_BLOCK), 0, stream, nb, (const double *)reduce_partials, reduce_partials + 1024);
+            VGL_HIP_BIND_RT(hipGetLastError());
+            VGL_HIP_BIND_CALL(vgl_hip_memcpy_d2h(ctx, &r, reduce_partials + 1024, sizeof(double)));
+        } else
+            VGL_HIP_BIND_CALL(vgl_hip_reduce_sum_f64_buffer(ctx, nb, reduce_partials, &r));      // fixed-order fold of the partials
+        _result = (_T)r;
+    }
+
+    // advance inner implementation
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+              typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+    void advance_worker(CSRGraph &_graph, FrontierCSR &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                        VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                        CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op,
+                        CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op, bool _inner_mpi_processing);
+
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+              typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+    void advance_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                        VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                        CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op,
+                        CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op, bool _inner_mpi_processing);
+
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+              typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation, typename GraphContainer, typename FrontierContainer>
+    void advance_worker(GraphContainer &_graph, FrontierContainer &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                        VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                        CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op,
+                        CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op, bool _inner_mpi_processing)
+    { throw "Error in GraphAbstractionsHIP::advance : this graph container is not served by the HIP backend (CSR_GRAPH and VECTOR_CSR_GRAPH are)"; }
+
+public:
+    // attaches graph-processing API to the specific graph
+    GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection _initial_traversal = SCATTER);
+    ~GraphAbstractionsHIP();
+
+    // generate new frontier implementation (public: it instantiates kernels on device lambdas, as in graph_abstractions_gpu.h:110-131)
+    template <typename FilterCondition>
+    void generate_new_frontier_worker(CSRGraph &_graph, FrontierCSR &_frontier, FilterCondition &&filter_cond);
+    template <typename FilterCondition>
+    void generate_new_frontier_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, FilterCondition &&filter_cond);
+    template <typename FilterCondition, typename GraphContainer, typename FrontierContainer>
+    void generate_new_frontier_worker(GraphContainer &_graph, FrontierContainer &_frontier, FilterCondition &&filter_cond)
+    { throw "Error in GraphAbstractionsHIP::generate_new_frontier : this graph container is not served by the HIP backend"; }
+
+    // performs user-defined "edge_op" operation over all OUTGOING edges, neighbouring specified frontier
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+              typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+    void scatter(VGL_Graph &_graph, VGL_Frontier &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                 VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                 CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op, CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op)
+    {
+        this->common_scatter(_graph, _frontier, edge_op, vertex_preprocess_op, vertex_postprocess_op, collective_edge_op, collective_vertex_preprocess_op,
+                             collective_vertex_postprocess_op, this);
+    }
+    template <typename EdgeOperation>
+    void scatter(VGL_Graph &_graph, VGL_Frontier &_frontier, EdgeOperation &&edge_op)
+    { scatter(_graph, _frontier, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP); }
+
+    // performs user-defined "edge_op" operation over all INCOMING edges, neighbouring specified frontier
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+              typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+    void gather(VGL_Graph &_graph, VGL_Frontier &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op, CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op)
+    {
+        this->common_gather(_graph, _frontier, edge_op, vertex_preprocess_op, vertex_postprocess_op, collective_edge_op, collective_vertex_preprocess_op,
+                            collective_vertex_postprocess_op, this);
+    }
+    template <typename EdgeOperation>
+    void gather(VGL_Graph &_graph, VGL_Frontier &_frontier, EdgeOperation &&edge_op)
+    { gather(_graph, _frontier, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP); }
+
+    // performs user-defined "compute_op" operation for each element in the given frontier
+    template <typename ComputeOperation>
+    void compute(VGL_Graph &_graph, VGL_Frontier &_frontier, ComputeOperation &&compute_op) { this->common_compute(_graph, _frontier, compute_op, this); }
+
+    // performs reduction using user-defined "reduce_op" operation for each element in the given frontier
+    template <typename _T, typename ReduceOperation>
+    _T reduce(VGL_Graph &_graph, VGL_Frontier &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type)
+    {
+        _T result = 0;
+        this->common_reduce(_graph, _frontier, reduce_op, _reduce_type, result, this);
+        return result;
+    }
+
+    // creates new frontier, which satisfy user-defined "cond" condition
+    template <typename FilterCondition>
+    void generate_new_frontier(VGL_Graph &_graph, VGL_Frontier &_frontier, FilterCondition &&filter_cond)
+    { this->common_generate_new_frontier(_graph, _frontier, filter_cond, this); }
+
+    friend class GraphAbstractions;
+};
+
+// one library context per process (the reference's runtime has no handle to keep it in)
+inline vgl_hip_ctx *vgl_hip_binding_context()
+{
+    static vgl_hip_ctx *c = nullptr;
+    if (!c) VGL_HIP_BIND_CALL(vgl_hip_ctx_create(0, nullptr, &c));
+    return c;
+}
+
+GraphAbstractionsHIP::GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection _initial_traversal)
+{
+    processed_graph_ptr = &_graph;
+    current_traversal_direction = _initial_traversal;
+    ctx = vgl_hip_binding_context();
+    stream = (hipStream_t)vgl_hip_ctx_stream(ctx);
+    VGL_HIP_BIND_RT(hipMalloc((void **)&reduce_partials, sizeof(double) * (1024 + 8)));
+    VGL_HIP_BIND_RT(hipMallocManaged((void **)&part_counters, sizeof(unsigned long long) * 8));
+}
+
+GraphAbstractionsHIP::~GraphAbstractionsHIP()
+{
+    hipStreamSynchronize(stream);
+    for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);
+    for (auto &kv : graph_handles) vgl_hip_graph_destroy(ctx, kv.second);
+    hipFree(reduce_partials);
+    hipFree(part_counters);
+}
+
+template <typename ComputeOperation, typename GraphContainer, typename FrontierContainer>
+void GraphAbstractionsHIP::compute_worker(GraphContainer &_graph, FrontierContainer &_frontier, ComputeOperation &&compute_op)
+{ throw "Error in GraphAbstractionsHIP::compute : this graph container is not served by the HIP backend"; }
+
+template <typename _T, typename ReduceOperation, typename GraphContainer, typename FrontierContainer>
+void GraphAbstractionsHIP::reduce_worker(GraphContainer &_graph, FrontierContainer &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
+{ throw "Error in GraphAbstractionsHIP::reduce : this graph container is not served by the HIP backend"; }
+
+// CSR_GRAPH: pre -> every edge of the active vertices -> post; the collective set is never called (advance_worker.hpp:62-149)
+template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+          typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+void GraphAbstractionsHIP::advance_worker(CSRGraph &_graph, FrontierCSR &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                                          VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                                          CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op,
+                                          CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op, bool _inner_mpi_processing)
+{
+    Timer tm;
+    tm.start();
+    LOAD_CSR_GRAPH_DATA(_graph);
+    LOAD_FRONTIER_DATA(_frontier);
+    const long long process_shift = compute_process_shift(current_traversal_direction, CSR_STORAGE);
+    const FrontierSparsityType t = _frontier.get_sparsity_type();
+    if (!is_empty_op<VertexPreprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, vertex_preprocess_op);
+    edge_pass(_graph, _frontier, process_shift, 0, vertices_count, edge_op);
+    if (!is_empty_op<VertexPostprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, vertex_postprocess_op);
+    finish();
+    tm.end();
+    const long long work = t == ALL_ACTIVE_FRONTIER ? edges_count : frontier_neighbours_count;
+    performance_stats.update_advance_stats(tm.get_time(), work * INT_ELEMENTS_PER_EDGE * sizeof(int), work);
+}
+
+// VECTOR_CSR_GRAPH (advance_worker.hpp:204-319)
+template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+          typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+void GraphAbstractionsHIP::advance_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                                          VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                                          CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op,
+                                          CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op, bool _inner_mpi_processing)
+{
+    static_assert(VECTOR_LENGTH == 64, "the vector-extension kernel maps one segment to one 64-lane wavefront");
+    using E = typename std::decay<EdgeOperation>::type; using CE = typename std::decay<CollectiveEdgeOperation>::type;
+    using P = typename std::decay<VertexPreprocessOperation>::type; using CP = typename std::decay<CollectiveVertexPreprocessOperation>::type;
+    using Q = typename std::decay<VertexPostprocessOperation>::type; using CQ = typename std::decay<CollectiveVertexPostprocessOperation>::type;
+    Timer tm;
+    tm.start();
+    LOAD_VECTOR_CSR_GRAPH_DATA(_graph);
+    LOAD_FRONTIER_DATA(_frontier);
+    const int collective_start = _graph.get_vector_core_threshold_vertex();       // [0, collective_start): vector engine + vector core ranges
+    const long long csr_shift = compute_process_shift(current_traversal_direction, CSR_STORAGE);
+    const long long ve_shift = compute_process_shift(current_traversal_direction, VE_STORAGE);
+    const FrontierSparsityType t = _frontier.get_sparsity_type();
+    long long work = 0;
+    if (t == SPARSE_FRONTIER) {
+        // every part of a sparse frontier reads the CSR storage (advance_sparse.hpp:24,90,150)
+        const vgl_range_vertex_op<P, CP> pre{vertex_preprocess_op, collective_vertex_preprocess_op, collective_start};
+        const vgl_range_vertex_op<Q, CQ> post{vertex_postprocess_op, collective_vertex_postprocess_op, collective_start};
+        const vgl_range_edge_op<E, CE> both{edge_op, collective_edge_op, collective_start};
+        const bool no_pre = is_empty_op<VertexPreprocessOperation>() && is_empty_op<CollectiveVertexPreprocessOperation>();
+        const bool no_post = is_empty_op<VertexPostprocessOperation>() && is_empty_op<CollectiveVertexPostprocessOperation>();
+        if (!no_pre) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, pre);
+        edge_pass(_graph, _frontier, csr_shift, 0, vertices_count, both);
+        if (!no_post) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, post);
+        work = frontier_neighbours_count;
+    } else {
+        if (collective_start > 0) {
+            if (!is_empty_op<VertexPreprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, collective_start, vertex_preprocess_op);
+            edge_pass(_graph, _frontier, csr_shift, 0, collective_start, edge_op);
+            if (!is_empty_op<VertexPostprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, collective_start, vertex_postprocess_op);
+        }
+        if (ve_vector_segments_count > 0) {
+            const unsigned blocks = (unsigned)(((long long)ve_vector_segments_count * 64 + VGL_BLOCK - 1) / VGL_BLOCK);
+            if (t == DENSE_FRONTIER)
+                hipLaunchKernelGGL((vgl_k_advance_vector_extension<true, CE, CP, CQ>), dim3(blocks), dim3(VGL_BLOCK), 0, stream, ve_vector_segments_count, ve_starting_vertex, vertices_count,
+                                   vertex_pointers, ve_vector_group_ptrs, ve_vector_group_sizes, ve_adjacent_ids, frontier_flags, ve_shift, collective_edge_op,
+                                   collective_vertex_preprocess_op, collective_vertex_postprocess_op);
+            else
+                hipLaunchKernelGGL((vgl_k_advance_vector_extension<false, CE, CP, CQ>), dim3(blocks), dim3(VGL_BLOCK), 0, stream, ve_vector_segments_count, ve_starting_vertex, vertices_count,
+                                   vertex_pointers, ve_vector_group_ptrs, ve_vector_group_sizes, ve_adjacent_ids, frontier_flags, ve_shift, collective_edge_op,
+                                   collective_vertex_preprocess_op, collective_vertex_postprocess_op);
+        }
+        work = t == ALL_ACTIVE_FRONTIER ? edges_count : frontier_neighbours_count;
+    }
+    finish();
+    tm.end();
+    performance_stats.update_advance_stats(tm.get_time(), work * INT_ELEMENTS_PER_EDGE * sizeof(int), work);
+}
+
+// CSR_GRAPH frontiers: ALL_ACTIVE when every vertex passes, else SPARSE with ascending ids (generate_new_frontier.hpp:113-164)
+template <typename FilterCondition>
+void GraphAbstractionsHIP::generate_new_frontier_worker(CSRGraph &_graph, FrontierCSR &_frontier, FilterCondition &&filter_cond)
+{
+    using C = typename std::decay<FilterCondition>::type;
+    Timer tm;
+    tm.start();
+    _frontier.set_direction(current_traversal_direction);
+    const int vertices_count = _graph.get_vertices_count();
+    vgl_hip_graph *gh = handle_of(_graph);
+    vgl_hip_frontier *fh = handle_of(_frontier, gh);
+    vgl_hip_gnf_buffers b;
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 0, &b));
+    const vgl_pred_user<C> pred{filter_cond, _graph.get_vertex_pointers()};
+    hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
+                       (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
+    VGL_HIP_BIND_RT(hipGetLastError());
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.0, 0, b.seq));
+    int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
+    VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
+    finish();
+    _frontier.size = size;
+    _frontier.neighbours_count = neighbours;
+    _frontier.sparsity_type = sparsity == VGL_HIP_FRONTIER_ALL_ACTIVE ? ALL_ACTIVE_FRONTIER : SPARSE_FRONTIER;
+    tm.end();
+    performance_stats.update_gnf_time(tm);
+    performance_stats.update_bytes_requested((long long)vertices_count * 4.0 * sizeof(int));
+}
+
+// VECTOR_CSR_GRAPH frontiers: ALL_ACTIVE, DENSE (flags only) above 0.7 of the vertices, else SPARSE; sizes and degree sums per degree range
+// (generate_new_frontier.hpp:29-111)
+template <typename FilterCondition>
+void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, FilterCondition &&filter_cond)
+{
+    using C = typename std::decay<FilterCondition>::type;
+    Timer tm;
+    tm.start();
+    const int vertices_count = _graph.get_vertices_count();
+    vgl_hip_graph *gh = handle_of(_graph);
+    vgl_hip_frontier *fh = handle_of(_frontier, gh);
+    vgl_hip_gnf_buffers b;
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 0, &b));
+    const vgl_pred_user<C> pred{filter_cond, _graph.get_vertex_pointers()};
+    hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
+                       (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
+    VGL_HIP_BIND_RT(hipGetLastError());
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.7, 0, b.seq));
+    VGL_HIP_BIND_RT(hipMemsetAsync(part_counters, 0, sizeof(unsigned long long) * 8, stream));
+    hipLaunchKernelGGL(vgl_k_frontier_parts, dim3(grid_for(vertices_count)), dim3(VGL_BLOCK), 0, stream, vertices_count, (const int *)_frontier.flags,
+                       (const long long *)_graph.get_vertex_pointers(), _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
+    int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
+    VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
+    finish();
+    _frontier.vector_engine_part_size = (int)part_counters[0]; _frontier.vector_engine_part_neighbours_count = (long long)part_counters[3];
+    _frontier.vector_core_part_size = (int)part_counters[1]; _frontier.vector_core_part_neighbours_count = (long long)part_counters[4];
+    _frontier.collective_part_size = (int)part_counters[2]; _frontier.collective_part_neighbours_count = (long long)part_counters[5];
+    _frontier.size = size;
+    _frontier.neighbours_count = neighbours;
+    if (sparsity == VGL_HIP_FRONTIER_ALL_ACTIVE) _frontier.sparsity_type = ALL_ACTIVE_FRONTIER;
+    else {
+        const FrontierSparsityType t = sparsity == VGL_HIP_FRONTIER_DENSE ? DENSE_FRONTIER : SPARSE_FRONTIER;
+        _frontier.sparsity_type = t; _frontier.vector_engine_part_type = t; _frontier.vector_core_part_type = t; _frontier.collective_part_type = t;
+    }
+    tm.end();
+    performance_stats.update_gnf_time(tm);
+    performance_stats.update_bytes_requested((long long)vertices_count * 2.0 * sizeof(int));
+}

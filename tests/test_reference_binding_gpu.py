@@ -1,0 +1,52 @@
+"""The reference's OWN applications on the reference's OWN containers, run on the MI355X through the bound-in HIP backend class
+(oracle/_ref/vgl_hip_{bfs,sswp,hits,scc}: apps/<app>/<app>.cpp of the reference, compiled in the CPU container by `make -C oracle binding` with
+-D __USE_HIP__ after integration/apply_hip_binding.py; tests/test_reference_binding.py is the build half).  Each run uses the reference's own
+-check: its sequential implementation (BFS::seq_top_down, SSWP::seq_dijkstra, HITS::seq_hits, SCC::seq_tarjan) recomputes the result on the host
+from the same containers and verify_results / verify_ranking_results / equal_components compare.  CSR_GRAPH exercises advance_worker(CSRGraph&,
+FrontierCSR&); VECTOR_CSR_GRAPH exercises the three degree ranges with the vector-extension kernel and, for SSWP, weights addressed by VE-space
+global_edge_pos in the collective range (EdgesArray_VectorCSR)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(app, *args):
+    exe = os.path.join(ROOT, "oracle", "_ref", "vgl_hip_" + app)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/vgl_hip_* are built where /root/reference exists (make -C oracle binding)")
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert "rror in" not in text and "NOT equal" not in text, text[-3000:]
+    return text
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 14, 16), ("ru", 13, 8)])
+def test_reference_bfs_app(kind, scale, edges, fmt):
+    text = run("bfs", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, "-check", "-it", "4")
+    assert len(re.findall(r"error count: 0\b", text)) == 4, text[-3000:]          # one verify_results per round (apps/bfs/bfs.cpp:39-49)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 13, 16), ("ru", 12, 8)])
+def test_reference_sswp_app(kind, scale, edges, fmt):
+    text = run("sswp", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, "-check", "-it", "2")
+    assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+def test_reference_hits_app(fmt):
+    text = run("hits", "-s", "12", "-e", "16", "-type", "rmat", "-format", fmt, "-check", "-it", "5")
+    assert len(re.findall(r"error count: 0\b", text)) == 2, text[-3000:]          # authorities and hubs (apps/hits/hits.cpp:43-51)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+def test_reference_scc_app(fmt):
+    text = run("scc", "-s", "12", "-e", "8", "-type", "rmat", "-format", fmt, "-check")
+    assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]

@@ -377,11 +377,33 @@ int vgl_hip_frontier_create(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *
     *out = f;
     return vgl_hip_frontier_set_all_active(c, f);   // VGL frontiers start all-active (base_frontier.h ctor)
 }
+// a frontier handle over arrays the CALLER owns (a backend bound to another library's frontier container, whose flags / ids arrays host code of
+// that library reads and writes: FrontierCSR / FrontierVectorCSR, base_frontier.h:5-62).  Nothing is initialised: vgl_hip_frontier_set_state says
+// what the arrays hold before every use.
+int vgl_hip_frontier_create_on(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_flags, int32_t *d_ids, vgl_hip_frontier **out)
+{
+    if (!c || !g || !d_flags || !d_ids || !out) VGL_FAIL("frontier_create_on: null argument");
+    vgl_hip_frontier *f = new vgl_hip_frontier();
+    f->g = g; f->flags = d_flags; f->ids = d_ids; f->borrowed = true;
+    f->size = 0; f->neighbours = 0; f->sparsity = VGL_HIP_FRONTIER_SPARSE; f->plan_dir = -1;
+    *out = f;
+    return 0;
+}
+// the caller changed the frontier behind the handle (host-side add_vertex / clear / set_all_active of the owning container, or a traversal
+// direction switch to the other direction's graph handle): take its description as given and forget the advance plan
+int vgl_hip_frontier_set_state(vgl_hip_ctx *c, vgl_hip_frontier *f, vgl_hip_graph *g, int32_t size, int64_t neighbours, int sparsity)
+{
+    if (!c || !f || !g) VGL_FAIL("frontier_set_state: null argument");
+    if (g->V != f->g->V) VGL_FAIL("frontier_set_state: the graph handle has another vertex count");
+    if (size < 0 || size > g->V || sparsity < VGL_HIP_FRONTIER_DENSE || sparsity > VGL_HIP_FRONTIER_ALL_ACTIVE) VGL_FAIL("frontier_set_state: bad description");
+    f->g = g; f->size = size; f->neighbours = neighbours; f->sparsity = sparsity; f->plan_dir = -1;
+    return 0;
+}
 int vgl_hip_frontier_destroy(vgl_hip_ctx *c, vgl_hip_frontier *f)
 {
     if (!f) return 0;
     if (c) hipStreamSynchronize(c->stream);
-    hipFree(f->flags); hipFree(f->ids);
+    if (!f->borrowed) { hipFree(f->flags); hipFree(f->ids); }
     if (f->offs) { hipFree(f->offs); hipFree(f->tile_first); hipFree(f->blk_sum); hipFree(f->blk_off); }
     delete f;
     return 0;

@@ -136,6 +136,7 @@ struct vgl_hip_frontier {
     int64_t *offs = nullptr;         // V+1 exclusive edge offsets of ids[] in the planned direction
     int32_t *tile_first = nullptr;   // ceil(E/VGL_TILE)+2
     int64_t *blk_sum = nullptr, *blk_off = nullptr;   // per 2048-id block degree sums / offsets
+    bool borrowed = false;           // flags / ids belong to the caller (vgl_hip_frontier_create_on)
     int plan_dir = -1;               // direction whose edge offsets `offs` describe the current ids (-1: none; set by vgl_hip_gnf_complete)
 };
 

@@ -35,6 +35,22 @@
 
 // ------------------------------------------------------------------------------------------------------------------
 // architecture macros (architecture_independent_api.h:19-43, GPU flavour)
+// ------------------------------------------------------------------------------------------------------------------
+#define __USE_HIP__
+#define __VGL_COMPUTE_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_SCATTER_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
+#define __VGL_GATHER_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
+#define __VGL_ADVANCE_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
+#define __VGL_ADVANCE_PREPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_ADVANCE_POSTPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_GNF_ARGS__ __device__ (int src_id, int connections_count)->int
+#define __VGL_COPY_IF_INDEXES_ARGS__ __device__ (long long idx)->int
+#define __VGL_REDUCE_ANY_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
+#define __VGL_REDUCE_INT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->int
+#define __VGL_REDUCE_FLT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->float
+#define __VGL_REDUCE_DBL_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->double
+#define VGL_GRAPH_ABSTRACTIONS GraphAbstractionsHIP
+#define VGL_FRONTIER VGL_Frontier
 #include "vgl_hip_kernels.hpp"
 #define VGL_SRC_ID_ADD(a, b) (vgl_src_id_add((a), (b)))
 #define VGL_INC(a) (atomicAdd(&(a), 1))

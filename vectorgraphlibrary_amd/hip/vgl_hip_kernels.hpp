@@ -12,22 +12,6 @@
 #include "../csrc/vgl_hip_internal.h"
 #include "../csrc/vgl_gnf.h"
 
-// ------------------------------------------------------------------------------------------------------------------
-#define __USE_HIP__
-#define __VGL_COMPUTE_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
-#define __VGL_SCATTER_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
-#define __VGL_GATHER_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
-#define __VGL_ADVANCE_ARGS__ __device__ (int src_id, int dst_id, int local_edge_pos, long long int global_edge_pos, int vector_index)
-#define __VGL_ADVANCE_PREPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
-#define __VGL_ADVANCE_POSTPROCESS_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
-#define __VGL_GNF_ARGS__ __device__ (int src_id, int connections_count)->int
-#define __VGL_COPY_IF_INDEXES_ARGS__ __device__ (long long idx)->int
-#define __VGL_REDUCE_ANY_ARGS__ __device__ (int src_id, int connections_count, int vector_index)
-#define __VGL_REDUCE_INT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->int
-#define __VGL_REDUCE_FLT_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->float
-#define __VGL_REDUCE_DBL_ARGS__ __device__ (int src_id, int connections_count, int vector_index)->double
-#define VGL_GRAPH_ABSTRACTIONS GraphAbstractionsHIP
-#define VGL_FRONTIER VGL_Frontier
 // VGL_SRC_ID_ADD (architecture_independent_api.h:48): "+= into the source vertex's slot" from an edge operator.  The edges of a row
 // sit in consecutive lanes, so when a wavefront walks a hub every lane adds to the SAME address and plain atomics serialise (~12 ns
 // each: 0.7 ms per PageRank iteration for one 60 K-edge hub).  When all active lanes agree on the address the wavefront sums its

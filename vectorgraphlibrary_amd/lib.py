@@ -76,6 +76,8 @@ _SIGNATURES = {
     "vgl_hip_graph_destroy": [_p, _p],
     "vgl_hip_frontier_create": [_p, _p, _pp],
     "vgl_hip_frontier_destroy": [_p, _p],
+    "vgl_hip_frontier_create_on": [_p, _p, _p, _p, _pp],
+    "vgl_hip_frontier_set_state": [_p, _p, _p, _i32, _i64, _int],
     "vgl_hip_frontier_set_all_active": [_p, _p],
     "vgl_hip_frontier_clear": [_p, _p],
     "vgl_hip_frontier_add_vertex": [_p, _p, _i32],
