@@ -28,7 +28,7 @@ APP_ARGS = {
     "cc": [["-cv"], ["-fused"]],
     "sswp": [["-push"], ["-fused"]],
     "hits": [[], ["-fused"]],
-    "scc": [[]],
+    "scc": [[], ["-fused"]],
     "coloring": [[]],
     "rw": [["-it", "100", "-wv", "20"]],
     "tc": [["-bfs-based", "-it", "500"], ["-purdoms", "-it", "500"]],

@@ -11,8 +11,9 @@ int main(int argc, char **argv)
         VGL_Graph graph(parser.format);
         prepare_graph(graph, parser, DIRECTED_GRAPH);
         VerticesArray<int> components(graph, SCATTER);
-        SCC::vgl_forward_backward(graph, components);            // heat run
-        report_performance(SCC::vgl_forward_backward(graph, components));
+        auto run = [&]() { return parser.fused ? SCC::hip_fused(graph, components) : SCC::vgl_forward_backward(graph, components); };
+        run();                                                   // heat run
+        report_performance(run());
         if (parser.get_check_flag()) {
             HostCSR h(graph);
             equal_components(components.to_host(), seq_tarjan(h));

@@ -1,5 +1,5 @@
 // dropin_driver.cpp -- RUNNABLE drop-in proof (test infrastructure; the driver is written here, the algorithm code is the reference's).
-// The reference's own algorithm headers -- algorithms/bfs/bfs.hpp, algorithms/sswp/widest_paths.h, algorithms/hits/hits.h -- are
+// The reference's own algorithm headers -- algorithms/bfs/bfs.hpp, algorithms/sswp/widest_paths.h, algorithms/hits/hits.h, algorithms/scc/scc.h -- are
 // included UNCHANGED from where they lie (-I /root/reference), instantiated on this repository's operator class (VGL_GRAPH_ABSTRACTIONS =
 // GraphAbstractionsHIP, vectorgraphlibrary_amd/hip/vgl_hip.hpp) and executed on the GPU.  Built by `make -C oracle dropin` into
 // oracle/_ref/dropin_hip (git-ignored; travels to the GPU box like the other built files); tests/test_dropin_run_gpu.py runs it and
@@ -22,6 +22,7 @@ public:
 #include "algorithms/bfs/bfs.hpp"
 #include "algorithms/sswp/widest_paths.h"
 #include "algorithms/hits/hits.h"
+#include "algorithms/scc/scc.h"
 
 template <class T> static void dump(const char *path, const std::vector<T> &a, bool append = false)
 {
@@ -31,11 +32,11 @@ template <class T> static void dump(const char *path, const std::vector<T> &a, b
     fclose(f);
 }
 
-// usage: dropin_hip <bfs|sswp|hits> <rmat|ru> <scale> <edge factor> <seed> <source (original id) | steps> <csr|vcsr> <dump file>
+// usage: dropin_hip <bfs|sswp|hits|scc> <rmat|ru> <scale> <edge factor> <seed> <source (original id) | steps> <csr|vcsr> <dump file>
 int main(int argc, char **argv)
 {
     try {
-        if (argc != 9) throw "usage: dropin_hip <bfs|sswp|hits> <rmat|ru> <scale> <ef> <seed> <source|steps> <csr|vcsr> <dump>";
+        if (argc != 9) throw "usage: dropin_hip <bfs|sswp|hits|scc> <rmat|ru> <scale> <ef> <seed> <source|steps> <csr|vcsr> <dump>";
         const std::string algo = argv[1], kind = argv[2], fmt = argv[7];
         const int scale = atoi(argv[3]), ef = atoi(argv[4]), arg = atoi(argv[6]);
         VGL_RUNTIME::init_library(argc, argv);
@@ -73,6 +74,12 @@ int main(int argc, char **argv)
             dump(argv[8], auth.to_host());
             dump(argv[8], hub.to_host(), true);
             std::cout << "DROPIN hits" << std::endl;
+        } else if (algo == "scc") {
+            VerticesArray<int> components(graph, SCATTER);
+            SCC::vgl_forward_backward(graph, components);       // the reference's trim + forward-backward (algorithms/scc/scc.hpp:268-300); labels are its tree ids
+            components.reorder(ORIGINAL);
+            dump(argv[8], components.to_host());
+            std::cout << "DROPIN scc" << std::endl;
         } else throw "unknown algorithm";
         VGL_RUNTIME::finalize_library();
     } catch (std::string error) { std::cout << error << std::endl; return 1; }

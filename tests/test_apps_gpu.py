@@ -86,12 +86,14 @@ def test_hits_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
     assert np.max(np.abs(got[V:] - hub) / np.maximum(np.abs(hub), 1e-300)) <= tol
 
 
+@pytest.mark.parametrize("mode", [[], ["-fused"]], ids=["operator_api", "fused"])
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES + [("ru", 12, 1, 8)])
-def test_scc_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
-    """SCC app (f1 widening): canonical labels equal the oracle's Tarjan partition; the app's own -check (partition equality) agrees"""
+def test_scc_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
+    """SCC app (f1 widening): canonical labels equal the oracle's Tarjan partition; the app's own -check (partition equality) agrees.
+    operator_api = trim + colour forward-backward through scatter / compute / generate_new_frontier (apps/algorithms/scc.hpp), fused = vgl_hip_scc_run"""
     O = oracle
     src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
-    out, dump = run_app("scc", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-check"], tmp_path)
+    out, dump = run_app("scc", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-check"] + mode, tmp_path)
     assert "error count: 0" in out
     assert (np.fromfile(dump, np.int32) == O.scc_tarjan(rowptr, adj)).all()
 
@@ -165,8 +167,6 @@ def test_apps_vector_csr_format(app, mode, tmp_path, oracle, ctx):
     dumped in ORIGINAL numbering must equal what the plain CSR run / the oracle give; the apps' -check runs in the stored numbering"""
     O = oracle
     kind, scale, ef, seed = "rmat", 12, 16, 3
-    if app == "scc" and not mode:
-        pytest.skip("the scc app has the fused path only")
     src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed, symmetric=(app == "cc"))
     w = O.gen_weights(len(perm), seed)[perm] if app != "cc" else None
     source = O.pick_source(rowptr, seed)
@@ -314,7 +314,7 @@ def test_run_tests_harness(tmp_path, ctx):
     rows = res["rows"]
     assert {r["app"] for r in rows} == {"bfs", "sssp", "pr", "cc", "sswp", "hits", "scc", "coloring", "rw", "tc", "mf"}
     assert all(r["errors"] == 0 and isinstance(r["perf"], float) and r["perf"] > 0 for r in rows), [r for r in rows if r["errors"] != 0]
-    assert os.path.exists(os.path.join(BIN, "harness_smoke.csv")) and "VERIFIED 19 TESTS" in out.stdout
+    assert os.path.exists(os.path.join(BIN, "harness_smoke.csv")) and "VERIFIED 20 TESTS" in out.stdout
 
 
 def test_api_performance_stats(tmp_path, ctx):

@@ -67,3 +67,22 @@ def test_reference_hits_header_runs_on_the_backend(kind, scale, ef, seed, fmt, t
     # differ from its sequential checker in the last bits too
     assert np.max(np.abs(got[:V] - auth) / np.maximum(np.abs(auth), 1e-300)) <= 1e-9
     assert np.max(np.abs(got[V:] - hub) / np.maximum(np.abs(hub), 1e-300)) <= 1e-9
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,ef,seed", CASES)
+def test_reference_scc_header_runs_on_the_backend(kind, scale, ef, seed, fmt, tmp_path, oracle, ctx):
+    O = oracle
+    src, rowptr, adj, perm = graph(O, kind, scale, ef, seed)
+    dump = run(tmp_path, "scc", kind, scale, ef, seed, 0, fmt)
+    got = np.fromfile(dump, np.int32)                                  # SCC::vgl_forward_backward: tree ids, one per component
+    # the partition must be Tarjan's: relabel every class by its smallest member, as the oracle does
+    order = np.argsort(got, kind="stable")
+    first = np.ones(len(got), bool)
+    first[1:] = got[order][1:] != got[order][:-1]
+    canon = np.empty(len(got), np.int64)
+    starts = np.flatnonzero(first)
+    ends = np.append(starts[1:], len(got))
+    mins = np.minimum.reduceat(order, starts)
+    canon[order] = np.repeat(mins, ends - starts)
+    assert (canon == O.scc_tarjan(rowptr, adj)).all()
