@@ -11,6 +11,7 @@
 //   vgl_k_bu_probe / vgl_k_bu_heavy    : per unvisited vertex 16 B row offsets + up to 8 adjacency probes (thread-serial),
 //                                        remaining long rows strip-mined 64-wide by one wavefront per vertex
 #include "vgl_hip_internal.h"
+#include <chrono>
 #include "vgl_gnf.h"
 #include "vgl_blocked.h"
 
@@ -269,6 +270,51 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_bfs_blk_accumulate(const v
     }
 }
 
+// Degrees of the rows behind a wavefront's 64 bitmap words, LANE = BIT: a frontier of a degree-sorted graph sits in runs of consecutive ids (the
+// hubs of an early level, the short rows of a late one), i.e. in a few FULL words -- with one thread walking the bits of its own word, 300
+// threads did the row-offset reads of a 6 800-vertex level one after the other (82 us for the write pass) and a 5 M-vertex level took 198 us.
+// Here the wavefront takes its non-empty words in turn (four at a time, so that their loads are in flight together): lane b reads the row
+// offsets of bit b -- consecutive rows, two coalesced 512-byte reads per word -- and `visit(j, set, deg)` sees word j's bit of this lane.
+template <class Visit>
+__device__ __forceinline__ void vgl_wave_words_degrees(uint64_t w, int64_t first_row_of_wave, const int64_t *rowptr, Visit &&visit)
+{
+    const int lane = vgl_lane();
+    unsigned long long nonempty = __ballot(w != 0);
+    while (nonempty) {
+        int j[4];
+        uint64_t wj[4];
+        int64_t lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            j[k] = nonempty ? __ffsll((long long)nonempty) - 1 : -1;
+            if (nonempty) nonempty &= nonempty - 1;
+            wj[k] = j[k] >= 0 ? __shfl(w, j[k]) : 0ULL;
+            lo[k] = hi[k] = 0;
+            if ((wj[k] >> lane) & 1) {
+                const int64_t r = first_row_of_wave + ((int64_t)j[k] << 6) + lane;
+                lo[k] = rowptr[r]; hi[k] = rowptr[r + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (j[k] >= 0) visit(j[k], (bool)((wj[k] >> lane) & 1), hi[k] - lo[k]);
+    }
+}
+// lane = bit pays when the wavefront's words are well filled; a sparse bitmap (a bit or two per non-empty word) is better served by every thread
+// walking its own word, all words at once
+__device__ __forceinline__ bool vgl_wave_words_dense(uint64_t w)
+{
+    const int words = __popcll(__ballot(w != 0));
+    int bits = __popcll(w);
+    for (int o = 32; o > 0; o >>= 1) bits += __shfl_xor(bits, o);
+    return bits >= 8 * words && words > 0;
+}
+__device__ __forceinline__ int64_t vgl_wave_sum_i64(int64_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 // ---- frontier generation from the frontier BITMAP (small frontiers): one 64-bit word per thread, 256 words per workgroup ----
 // The last workgroup to finish also does what used to be two more launches: the exclusive scan of the per-workgroup counts
 // (<= a few thousand entries) and the hand-over of F and M to the host (counters + pinned mirror + sequence number).
@@ -303,6 +349,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
     }
     int cnt = 0;
     int64_t deg = 0;
+    uint64_t wbits = 0;
     if (wi < nwords) {
         uint64_t w;
         if (ADVANCE) {
@@ -311,13 +358,16 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_count(int64_t nwords, 
             if (w) { visited[word0 + wi] |= w; next[word0 + wi] = 0; }
         } else w = front[word0 + wi];
         cnt = __popcll(w);
-        while (w) {
-            const int b = __ffsll((long long)w) - 1;
-            w &= w - 1;
-            const int64_t r = ((word0 + wi) << 6) + b - row_base;
+        wbits = w;
+    }
+    // (a partial sum per lane: lane b adds the degrees of bit b of every word of its wavefront; the block total is what counts)
+    if (vgl_wave_words_dense(wbits))
+        vgl_wave_words_degrees(wbits, ((word0 + wi - vgl_lane()) << 6) - row_base, rowptr, [&](int, bool set, int64_t d) { if (set) deg += d; });
+    else
+        for (uint64_t t = wbits; t; t &= t - 1) {
+            const int64_t r = ((word0 + wi) << 6) + (__ffsll((long long)t) - 1) - row_base;
             deg += rowptr[r + 1] - rowptr[r];
         }
-    }
     const int tc = vgl_block_reduce_add(cnt, s32);
     const int64_t td = vgl_block_reduce_add(deg, s64);
     uint32_t dep = 0;
@@ -392,33 +442,54 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bm_gnf_write(int64_t nwords, 
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
     const int64_t wi = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x;
-    uint64_t w = 0;
-    int64_t deg = 0;
-    if (wi < nwords) {
-        w = front[word0 + wi];
-        uint64_t t = w;
-        while (t) {
-            const int b = __ffsll((long long)t) - 1;
-            t &= t - 1;
-            const int64_t r = ((word0 + wi) << 6) + b - row_base;
-            deg += rowptr[r + 1] - rowptr[r];
+    const int lane = vgl_lane();
+    const uint64_t w = wi < nwords ? front[word0 + wi] : 0ULL;
+    const int64_t first_row = ((word0 + wi - lane) << 6) - row_base;           // row of bit 0 of the wavefront's first word
+    // degree sum of every word (lane j ends up with the sum of word j), then the exclusive offsets of the words in bitmap order
+    int64_t word_deg = 0;
+    const bool dense = vgl_wave_words_dense(w);
+    if (dense)
+        vgl_wave_words_degrees(w, first_row, rowptr, [&](int j, bool set, int64_t d) {
+            const int64_t sum = vgl_wave_sum_i64(set ? d : 0);
+            if (lane == j) word_deg = sum;
+        });
+    else
+        for (uint64_t t = w; t; t &= t - 1) {
+            const int64_t r = first_row + ((int64_t)lane << 6) + (__ffsll((long long)t) - 1);
+            word_deg += rowptr[r + 1] - rowptr[r];
         }
-    }
     int ctot; int64_t dtot;
-    int pos = vt_cnt_off[blockIdx.x] + vgl_block_excl_add((int)__popcll(w), s32, &ctot);
-    int64_t eoff = vt_deg_off[blockIdx.x] + vgl_block_excl_add(deg, s64, &dtot);
-    while (w) {
-        const int b = __ffsll((long long)w) - 1;
-        w &= w - 1;
-        const int32_t v = (int32_t)(((word0 + wi) << 6) + b);
-        const int64_t r = v - row_base;
-        ids[pos] = v; offs[pos] = eoff;
-        const int64_t eend = eoff + (rowptr[r + 1] - rowptr[r]);
+    const int word_pos = vt_cnt_off[blockIdx.x] + vgl_block_excl_add((int)__popcll(w), s32, &ctot);
+    const int64_t word_eoff = vt_deg_off[blockIdx.x] + vgl_block_excl_add(word_deg, s64, &dtot);
+    if (!dense) {                            // every thread emits the vertices of its own word
+        int pos = word_pos;
+        int64_t eoff = word_eoff;
+        for (uint64_t t = w; t; t &= t - 1) {
+            const int64_t r = first_row + ((int64_t)lane << 6) + (__ffsll((long long)t) - 1);
+            ids[pos] = (int32_t)(r + row_base); offs[pos] = eoff;
+            const int64_t eend = eoff + (rowptr[r + 1] - rowptr[r]);
+            for (int64_t q = (eoff + VGL_TILE - 1) / VGL_TILE; q < (eend + VGL_TILE - 1) / VGL_TILE; q++) tile_first[q] = pos;
+            if (eoff < eend && eend == M) tile_first[(M + VGL_TILE - 1) / VGL_TILE] = pos;
+            eoff = eend;
+            pos++;
+        }
+        return;
+    }
+    // second walk (the row offsets now come from the cache): lane b of word j writes frontier position word_pos[j] + (set bits below b)
+    vgl_wave_words_degrees(w, first_row, rowptr, [&](int j, bool set, int64_t d) {
+        const uint64_t wj = __shfl(w, j);
+        const int base_pos = __shfl(word_pos, j);
+        const int64_t base_eoff = __shfl(word_eoff, j);
+        const int64_t mine = set ? d : 0;
+        const int64_t eoff = base_eoff + vgl_wave_incl_add(mine) - mine;
+        if (!set) return;
+        const int pos = base_pos + __popcll(wj & ((1ULL << lane) - 1ULL));
+        ids[pos] = (int32_t)(first_row + row_base + ((int64_t)j << 6) + lane);
+        offs[pos] = eoff;
+        const int64_t eend = eoff + d;
         for (int64_t t = (eoff + VGL_TILE - 1) / VGL_TILE; t < (eend + VGL_TILE - 1) / VGL_TILE; t++) tile_first[t] = pos;
         if (eoff < eend && eend == M) tile_first[(M + VGL_TILE - 1) / VGL_TILE] = pos;
-        eoff = eend;
-        pos++;
-    }
+    });
 }
 
 // ---- small frontiers: several top-down levels in ONE workgroup ----
@@ -1322,6 +1393,17 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     if (const char *e = getenv("VGL_TD_EMIT_EDGES")) VGL_TD_EMIT_EDGES = atoll(e);
     double td_filter_share = 0.125;
     if (const char *e = getenv("VGL_TD_FILTER_SHARE")) td_filter_share = atof(e);
+    // Late levels: once all but a few of the vertices that CAN be discovered (rows with incoming edges; known when the incoming CSR is stored)
+    // are visited, an emitting level is cheap whatever its edge count -- its visited-bitmap probe turns almost every edge away before the
+    // atomic -- and it leaves the next frontier as a bitmap (2 MiB to count) instead of only in `levels` (64 MiB to scan).  VGL_TD_LATE_SHARE:
+    // "few" as a share of V (0 = rule off).
+    double td_late_share = 1.0 / 64;
+    if (const char *e = getenv("VGL_TD_LATE_SHARE")) td_late_share = atof(e);
+    auto late = [&]() -> bool {          // evaluated when visited_total already holds the frontier about to be expanded
+        if (g->in_nz_rows <= 0 || td_late_share <= 0.0) return false;
+        const int64_t remain = std::max<int64_t>(0, (int64_t)g->in_nz_rows + 1 - visited_total);      // (+1: the source may have no incoming edge)
+        return (double)remain <= td_late_share * (double)V;
+    };
     int bu_in_a_row = 0;                                 // bottom-up levels since the last top-down one
     int later_heavy_blocks = 256;                        // RMAT-24 traversal: 0.376 ms with 2048, 0.368-0.370 with 512 / 256 / 128
     if (const char *e = getenv("VGL_BU_LATER_HEAVY_BLOCKS")) later_heavy_blocks = std::max(1, std::min(VGL_BU_BLOCKS, atoi(e)));
@@ -1379,6 +1461,15 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     if (const char *e = getenv("VGL_BFS_SMALL_M")) small_m = std::min<int64_t>(atoll(e), 1 << 20);     // (the kernel scans 32-bit degree sums)
     if (mode == VGL_HIP_BFS_DIRECTION_OPT) small_m = std::min<int64_t>(small_m, (int64_t)V / VGL_DO_ALPHA - 1);
     if (small_m < 64) small_m = 0;                       // not worth a launch of its own
+    // VGL_BFS_TRACE=1: one line per dispatch (level, frontier, edges, path taken, milliseconds since the start; every line synchronises)
+    const bool trace_on = getenv("VGL_BFS_TRACE") && getenv("VGL_BFS_TRACE")[0] == '1';
+    const auto trace_t0 = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what) {
+        if (!trace_on) return;
+        hipStreamSynchronize(c->stream);
+        fprintf(stderr, "[bfs trace] %7.3f ms  level %d  F %lld  M %lld  visited %lld  %s\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - trace_t0).count(), (int)cur, (long long)F, (long long)M, (long long)visited_total, what);
+    };
     bool finished = false;
     bool precounted = false;         // F, M, ids, offs, tile_first of level cur were left by vgl_k_bfs_small_levels: no count, no write pass
     // runs the kernel on the list g->ids[0..F) of level `cur` (or on {source}); returns through C_* what it did
@@ -1432,7 +1523,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         counted = false;
         const bool ids_ready = precounted;
         if (precounted) { counted = true; counted_from_bitmap = true; precounted = false; }
-        else if (!bottom_up) VGL_TRY(count_frontier());      // after a bottom-up step F is already known (M is not needed to stay bottom-up)
+        else if (!bottom_up) { trace("-> count"); VGL_TRY(count_frontier()); trace(counted_from_bitmap ? "count done (bitmap)" : "count done (levels scan)"); }      // after a bottom-up step F is already known (M is not needed to stay bottom-up)
         if (F == 0) break;
         visited_total += F;
         st.levels++; st.frontier_total += F;
@@ -1460,12 +1551,31 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                 VGL_TRY(count_frontier());              // ids / offsets of level cur are needed again (bm_front is valid: cheap)
             }
         }
+        if (!bottom_up && !ids_ready && counted && counted_from_bitmap && small_m > 0 && F <= bm_expand_f && late()) {
+            // the tail of a traversal whose frontier came as a bitmap (top-down mode, or a direction-optimising one that never went bottom-up):
+            // expand it from the bitmap and let the list kernel run whatever follows -- the treatment the switch back from bottom-up gets above
+            trace("counted -> bitmap expand + list kernel");
+            VGL_TRY(small_levels(0, -1, true));
+            trace("bitmap expand + list kernel done");
+            const int64_t m_level = c->h_counters[C_CHANGED], n_next = c->h_counters[C_BU_FOUND];
+            st.td_steps++; st.edges_examined += m_level; st.td_edges += m_level; st.td_frontier += F;
+            prevF = F;
+            cur++;
+            if (n_next == 0) break;
+            if (c->h_counters[C_TMP0] > 0) {
+                visited_total += n_next; st.levels++; st.frontier_total += n_next; prevF = n_next;
+                account_small(n_next);
+            } else { advance_pending = true; front_valid = true; }
+            continue;
+        }
         prevF = F;
         if (skipped && !bottom_up) VGL_FAIL("bfs_run: internal error (the count launch and the host disagree on the direction rule)");
         if (!bottom_up && g->blk_bfs && front_valid && (double)M >= blocked_share * (double)E) {
             // a level that holds a large share of the edges: the blocked pass (bitmaps in, bitmap + levels out: the state afterwards is
             // that after an emitting top-down level)
+            trace("counted -> blocked level");
             VGL_TRY(vgl_bfs_blocked_level(c, g, d_levels, cur + 1));
+            trace("blocked level done");
             advance_pending = true;
             st.td_steps++; st.edges_examined += M; st.td_edges += M; st.td_frontier += F;
             cur++;
@@ -1481,16 +1591,22 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                 hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_equal_i32>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred,
                                    g->nrows, g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
             }
+            trace("ids written");
             if (small_m > 0 && counted_from_bitmap && F <= VGL_SMALL_F && M <= small_m) {
+                trace("counted + ids -> list kernel");
                 VGL_TRY(small_levels((int32_t)F, -1));
+                trace("list kernel done");
                 account_small(F);
                 continue;
             }
-            const bool emit = M <= VGL_TD_EMIT_EDGES;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
+            const bool is_late = late();
+            const bool emit = M <= VGL_TD_EMIT_EDGES || is_late;        // bm_next is all zero here (init / vgl_k_bm_advance leave it so)
             const bool td_counts = emit && use_hints && vgl_ceil_div(M, VGL_TILE) <= VGL_TD_COUNT_TILES;
             // the visited-bitmap probe pays once a good part of the vertices is visited (VGL_TD_FILTER_SHARE of V; 0 = always, 2 = never)
-            const bool filter = (double)visited_total >= td_filter_share * (double)V;
+            const bool filter = is_late || (double)visited_total >= td_filter_share * (double)V;
+            trace(emit ? "counted + ids -> top-down (emitting)" : "counted + ids -> top-down (levels only)");
             VGL_TRY(vgl_bfs_td_launch(c, g, (int32_t)F, M, d_levels, cur + 1, emit, counted_from_bitmap, td_counts, filter));
+            trace("top-down done");
             hint_ready = td_counts && F > 0 && M > 0;     // (a level without edges launches nothing: C_NEXT_* would be another traversal's)
             advance_pending = emit;          // a top-down level is always followed by count_frontier (or the loop ends below)
             front_valid = emit;
@@ -1498,6 +1614,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
         } else {
             if (!front_valid) VGL_FAIL("bfs_run: internal error (bitmaps missing)");
             int64_t seq = 0;
+            trace("-> bottom-up");
             VGL_TRY(vgl_bfs_bu_launch(c, g, d_levels, cur + 1, g->bm_visited, g->bm_front, g->bm_next, &seq, bu_in_a_row > 0 ? later_heavy_blocks : VGL_BU_BLOCKS));
             bu_in_a_row++;
             hipLaunchKernelGGL(vgl_k_bm_advance, dim3(vgl_grid(words)), dim3(VGL_BLOCK), 0, c->stream, words, g->bm_visited,
