@@ -797,11 +797,12 @@ def main():
         # ... and of its launches every 4th (a traversal has ~3 of them: the stride walks through the levels evenly): 5 us of event records per
         # bracketed launch were 5 % of a traversal
         ctx.timing(True, only=dom, stride=4)
+        stats = []
+        lv_do = ctx.empty(g.V, torch.int32)               # one levels array for all rounds, as apps/bfs/bfs.cpp:31,36-40 reuses its VerticesArray
         barrier()
         t0 = time.perf_counter()
-        stats = []
         for s in sources[args.warmup:]:
-            lv_do, st_one = api.bfs(g, s, api.BFS_DIRECTION_OPT, raw=True)
+            st_one = api.bfs(g, s, api.BFS_DIRECTION_OPT, levels=lv_do, raw=True)[1]
             stats.append(st_one)
         barrier()
         dt = time.perf_counter() - t0
