@@ -402,6 +402,8 @@ int vgl_hip_comm_create_hosted(vgl_hip_ctx *ctx, int rank, int world, const char
  * handshake only; window_bytes: capacity of one of the two halves of a window (larger payloads go in pieces).  Fails -- on every rank alike --
  * when a window cannot be mapped by a peer: fall back to vgl_hip_comm_create (RCCL). */
 int vgl_hip_comm_create_peer(vgl_hip_ctx *ctx, int rank, int world, const char *name, size_t window_bytes, vgl_hip_comm **out);
+/* tells the other ranks of a hosted / peer communicator that this rank gives up: their next barrier fails at once instead of after its timeout */
+int vgl_hip_comm_abort(vgl_hip_comm *comm);
 int vgl_hip_comm_destroy(vgl_hip_comm *comm);
 int vgl_hip_comm_info(vgl_hip_comm *comm, int *rank, int *world, int *transport);
 int vgl_hip_comm_barrier(vgl_hip_comm *comm);            /* drains the stream, meets the other ranks */

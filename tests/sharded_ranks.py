@@ -100,7 +100,17 @@ def main():
             assert time.time() - t0 < 120, "rank 0's RCCL id did not appear"
             time.sleep(0.05)
         comm = vs.Comm.rccl(ctx, rank, world, open(token, "rb").read())
+    try:
+        run(ctx, comm, transport, rank, world)
+    except BaseException:
+        comm.abort()                    # the other ranks' next barrier fails at once (hosted / peer), not after its timeout
+        raise
+
+
+def run(ctx, comm, transport, rank, world):
     check_exchanges(ctx, comm)
+    if os.environ.get("VGL_TEST_FAIL_RANK") == str(rank):
+        raise RuntimeError("rank %d fails on purpose (VGL_TEST_FAIL_RANK)" % rank)
 
     scale, ef, seed = 13, 16, 11
     V, E = 1 << scale, (1 << scale) * ef

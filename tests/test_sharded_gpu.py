@@ -39,6 +39,27 @@ def _run_ranks(transport, world, env_extra=None, timeout=900):
         assert p.returncode == 0 and "SHARDED_RANK_OK" in o, "rank %d failed:\n%s\n%s" % (r, o[-3000:], e[-3000:])
 
 
+def test_a_failing_rank_takes_the_others_down_at_once():
+    """a rank that raises between two exchanges sets the abort word of the shared header (Comm.abort -> vgl_hip_comm_abort); the rank waiting at
+    the next barrier fails with that message instead of spinning for VGL_HOSTED_TIMEOUT (180 s)"""
+    import time
+    token = "/vgl_t_%s" % uuid.uuid4().hex[:12]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VGL_TEST_FAIL_RANK="1")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, HELPER, "hosted", str(r), "2", token], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=150) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert procs[0].returncode != 0 and procs[1].returncode != 0
+    assert "fails on purpose" in outs[1][1]
+    assert "another rank gave up" in outs[0][1], outs[0][1][-2000:]
+    assert time.time() - t0 < 120
+
+
 def test_sharded_loops_world_of_one_equal_fused(ctx):
     from vectorgraphlibrary_amd import api
     from vectorgraphlibrary_amd import sharded as vs

@@ -4,6 +4,8 @@
 // (exchange_data_cycle_mode :78-150, exchange_data_recently_changed_and_all :156-187, in_group_exchange :222-247).
 // Every rank is one process with one GPU (or a share of one, HOSTED); all collectives are issued in the same order on every rank.
 #include "vgl_comm.h"
+#include <signal.h>
+#include <errno.h>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -31,7 +33,9 @@ struct vgl_hosted_header {
     uint32_t world;
     uint64_t slot_bytes;
     std::atomic<uint32_t> turn;          // VGL_HOSTED_SERIALIZE=1: ranks that have finished the phase after the last barrier
-    char pad[256 - 28];
+    std::atomic<uint32_t> aborted;       // a rank gave up (vgl_hip_comm_abort, or its own timeout): everybody waiting at a barrier fails at once
+    int32_t creator_pid;                 // rank 0's process: a segment whose creator is gone is a leftover of a crashed run, not this run's
+    char pad[256 - 36];
 };
 static_assert(sizeof(vgl_hosted_header) == 256, "hosted header is one 256-byte block");
 constexpr uint32_t VGL_HOSTED_MAGIC = 0x56474C48u;      // "VGLH"
@@ -50,8 +54,11 @@ int vgl_hosted_barrier(vgl_hip_comm *m)
     auto timed_out = [&](long spin) {
         if ((spin & 0xFFFF) != 0xFFFF) return false;
         usleep(50);
-        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > VGL_HOSTED_TIMEOUT_S;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() <= VGL_HOSTED_TIMEOUT_S) return false;
+        h->aborted.store(1, std::memory_order_release);      // the others need not wait out their own timeouts
+        return true;
     };
+    if (h->aborted.load(std::memory_order_acquire)) VGL_FAIL("hosted transport: another rank gave up (see its error)");
     const uint32_t gen = h->generation.load(std::memory_order_acquire);
     if (serialize) h->turn.fetch_add(1, std::memory_order_acq_rel);         // my phase is over: the next rank may start its own
     if (h->arrived.fetch_add(1, std::memory_order_acq_rel) == (uint32_t)m->world - 1) {
@@ -60,6 +67,7 @@ int vgl_hosted_barrier(vgl_hip_comm *m)
         h->generation.fetch_add(1, std::memory_order_release);
     } else {
         for (long spin = 0; h->generation.load(std::memory_order_acquire) == gen; spin++) {
+            if ((spin & 0x3FF) == 0x3FF && h->aborted.load(std::memory_order_acquire)) VGL_FAIL("hosted transport: another rank gave up (see its error)");
             if (timed_out(spin)) VGL_FAIL("hosted transport: a rank did not reach the barrier (timeout)");
             __builtin_ia32_pause();
         }
@@ -430,7 +438,19 @@ static int vgl_shm_attach(vgl_hip_ctx *c, int rank, int world, const char *name,
             fd = shm_open(name, O_RDWR, 0600);
             if (fd >= 0) {
                 struct stat st;
-                if (fstat(fd, &st) == 0 && (size_t)st.st_size == total) break;
+                if (fstat(fd, &st) == 0 && (size_t)st.st_size == total) {
+                    // an object of this name and size may be what a crashed run left behind (rank 0 unlinks the name only once everybody is
+                    // attached): it is this run's if its creator is alive -- or has not written its pid yet
+                    void *q = mmap(nullptr, sizeof(vgl_hosted_header), PROT_READ, MAP_SHARED, fd, 0);
+                    bool stale = false;
+                    if (q != MAP_FAILED) {
+                        const vgl_hosted_header *hh = reinterpret_cast<const vgl_hosted_header *>(q);
+                        const int32_t pid = hh->magic.load(std::memory_order_acquire) == VGL_HOSTED_MAGIC ? hh->creator_pid : 0;
+                        stale = pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH;
+                        munmap(q, sizeof(vgl_hosted_header));
+                    }
+                    if (!stale) break;
+                }
                 close(fd); fd = -1;
             }
             if (waited() > VGL_HOSTED_TIMEOUT_S) VGL_FAIL("comm_create: rank 0's segment did not appear (timeout)");
@@ -444,7 +464,8 @@ static int vgl_shm_attach(vgl_hip_ctx *c, int rank, int world, const char *name,
     m->ctx = c; m->rank = rank; m->world = world; m->transport = transport;
     m->shm = reinterpret_cast<vgl_hosted_header *>(p); m->shm_bytes = total; m->shm_name = name;
     if (rank == 0) {
-        m->shm->arrived.store(0); m->shm->generation.store(0); m->shm->turn.store(0);
+        m->shm->arrived.store(0); m->shm->generation.store(0); m->shm->turn.store(0); m->shm->aborted.store(0);
+        m->shm->creator_pid = (int32_t)getpid();
         m->shm->world = (uint32_t)world; m->shm->slot_bytes = check;
         memset(m->shm->pad, 0, sizeof(m->shm->pad));
         m->shm->magic.store(VGL_HOSTED_MAGIC, std::memory_order_release);
@@ -483,6 +504,14 @@ int vgl_hip_comm_create_peer(vgl_hip_ctx *c, int rank, int world, const char *na
     return 0;
 }
 
+// a rank that cannot go on (an error anywhere between two exchanges) tells the others, who would otherwise wait at the next barrier until
+// their timeout: hosted / peer transports only (RCCL has its own abort); safe to call more than once
+int vgl_hip_comm_abort(vgl_hip_comm *m)
+{
+    if (!m) return 0;
+    if (m->shm) m->shm->aborted.store(1, std::memory_order_release);
+    return 0;
+}
 int vgl_hip_comm_destroy(vgl_hip_comm *m)
 {
     if (!m) return 0;

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "vgl_hip_comm_create": [_p, _int, _int, _p, _pp],
     "vgl_hip_comm_create_hosted": [_p, _int, _int, C.c_char_p, C.c_size_t, _pp],
     "vgl_hip_comm_create_peer": [_p, _int, _int, C.c_char_p, C.c_size_t, _pp],
+    "vgl_hip_comm_abort": [_p],
     "vgl_hip_comm_destroy": [_p],
     "vgl_hip_comm_info": [_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
     "vgl_hip_comm_barrier": [_p],

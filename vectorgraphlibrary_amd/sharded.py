@@ -68,6 +68,11 @@ class Comm:
         _l.check(self.ctx.L.vgl_hip_comm_stats(self.h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
+    def abort(self):
+        """this rank gives up: ranks of a hosted / peer communicator waiting at a barrier fail at once instead of after their timeout"""
+        if self.h:
+            self.ctx.L.vgl_hip_comm_abort(self.h)
+
     def close(self):
         if self.h:
             self.ctx.L.vgl_hip_comm_destroy(self.h)
