@@ -163,6 +163,32 @@ def peer_comm_or_none(ctx, vs, dist, rank, world):
         recv = torch.empty(n * world, device=dev, dtype=torch.int32)
         comm.allgather(mine, recv)
         ok &= int(torch.equal(recv, want.flatten()))
+        # ... and the other exchange forms of the drivers: owned slices of unequal size, the bitmap OR (all-to-all + all-gather of the owned words,
+        # a word count the ranks do not divide), the changed-entries exchange in its list form
+        bounds = [0] + [int(n * (r + 1) ** 2 / world ** 2) for r in range(world)]
+        arr = torch.full((n,), -1, device=dev, dtype=torch.int32)
+        arr[bounds[rank]:bounds[rank + 1]] = rank
+        comm.allgather_slices(arr, bounds)
+        ok &= int(torch.equal(arr, torch.cat([torch.full((bounds[r + 1] - bounds[r],), r, device=dev, dtype=torch.int32) for r in range(world)])))
+        words = 4097 * world + 1
+        gen = torch.Generator(device="cpu").manual_seed(4321)
+        allb = torch.randint(-2 ** 62, 2 ** 62, (world, words), generator=gen, dtype=torch.int64) & torch.randint(-2 ** 62, 2 ** 62, (world, words), generator=gen, dtype=torch.int64)
+        bits = allb[rank].to(dev)
+        comm.bitmap_or(bits)
+        ref = allb[0]
+        for r in range(1, world):
+            ref = ref | allb[r]
+        ok &= int(torch.equal(bits.cpu(), ref))
+        before = torch.full((n,), 1000000, device=dev, dtype=torch.int32)
+        copies = []
+        for r in range(world):
+            v = before.clone()
+            idx = (torch.arange(5000, device=dev, dtype=torch.int64) * (7 + 2 * r) + r * 31) % n
+            v[idx] = ((idx * (r + 3)) % 999 + 1).to(torch.int32)
+            copies.append(v)
+        got = copies[rank].clone()
+        comm.exchange_changed(before, got, take_min=True)
+        ok &= int(torch.equal(got, torch.stack(copies).min(0).values))
         comm.barrier()                                   # (reads the error word of the window: a spin that ran out fails here)
     except VglHipError:
         ok = 0
