@@ -38,6 +38,7 @@ constexpr int VGL_DS_BLOCKS = 2048;       // persistent grid of the relax kernel
 
 struct vgl_hip_sssp_plan {
     float delta = 0.0f;
+    hipStream_t stream = nullptr;        // the stream whose pool owns the part arrays
     // the edges split into two CSRs over the same rows, both in original relative order: [0] light (w < delta), [1] heavy.
     // Own row offsets / adjacency / weights / tile table each, so a step can either walk a compacted frontier's segments or
     // sweep the whole part as static tiles.
@@ -725,6 +726,7 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     hipStream_t st = c->stream;
     vgl_hip_sssp_plan *p = new vgl_hip_sssp_plan();
     p->delta = delta;
+    p->stream = st;
     VGL_HIP_TRY(hipMalloc((void **)&p->state, (size_t)g->V + 8));
     VGL_HIP_TRY(hipMalloc((void **)&p->active, (size_t)g->V + 8));
     VGL_HIP_TRY(hipMemsetAsync(p->active, 0, (size_t)g->V + 8, st));
@@ -736,19 +738,21 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     uint32_t *flags = nullptr, *S = nullptr;
     void *temp = nullptr;
     size_t need = 0;
-    VGL_HIP_TRY(hipMalloc((void **)&flags, sizeof(uint32_t) * ((size_t)E + 1)));
-    VGL_HIP_TRY(hipMalloc((void **)&S, sizeof(uint32_t) * ((size_t)E + 1)));
+    // (the multi-gigabyte temporaries and part arrays come from the library's stream-ordered pool: fresh hipMalloc / hipFree calls of that size
+    // stalled for hundreds of milliseconds in the bench, where another plan had just been released -- 357 ms for a 42 ms build)
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&flags, sizeof(uint32_t) * ((size_t)E + 1)));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&S, sizeof(uint32_t) * ((size_t)E + 1)));
     hipLaunchKernelGGL(vgl_k_ds_light_flags, dim3(vgl_ds_grid(std::max<int64_t>(E, 1), 16384)), dim3(VGL_BLOCK), 0, st, E, d_weights, delta, flags);
     VGL_HIP_TRY(rocprim::exclusive_scan(nullptr, need, flags, S, 0u, (size_t)E + 1, rocprim::plus<uint32_t>(), st));
-    VGL_HIP_TRY(hipMalloc(&temp, need ? need : 16));
+    VGL_HIP_TRY(vgl_pool_alloc(st, &temp, need ? need : 16));
     VGL_HIP_TRY(rocprim::exclusive_scan(temp, need, flags, S, 0u, (size_t)E + 1, rocprim::plus<uint32_t>(), st));
     uint32_t n_light = 0;                                   // S[E] = number of light edges: sizes of the two parts
     VGL_TRY(vgl_hip_memcpy_d2h(c, &n_light, S + E, sizeof(uint32_t)));
     const int64_t part_edges[2] = {(int64_t)n_light, E - (int64_t)n_light};
     for (int k = 0; k < 2; k++) {
-        VGL_HIP_TRY(hipMalloc((void **)&p->prow[k], sizeof(int64_t) * ((size_t)g->nrows + 1)));
-        VGL_HIP_TRY(hipMalloc((void **)&p->padj[k], sizeof(int32_t) * (size_t)std::max<int64_t>(part_edges[k], 1)));
-        VGL_HIP_TRY(hipMalloc((void **)&p->pw[k], sizeof(float) * (size_t)std::max<int64_t>(part_edges[k], 1)));
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->prow[k], sizeof(int64_t) * ((size_t)g->nrows + 1)));
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->padj[k], sizeof(int32_t) * (size_t)std::max<int64_t>(part_edges[k], 1)));
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->pw[k], sizeof(float) * (size_t)std::max<int64_t>(part_edges[k], 1)));
     }
     if (E > 0)
         hipLaunchKernelGGL(vgl_k_ds_partition, dim3(vgl_ds_grid(E, 16384)), dim3(VGL_BLOCK), 0, st, E, g->out.adj, d_weights, S, delta, p->padj[0],
@@ -766,7 +770,7 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     VGL_TRY(vgl_hip_memcpy_d2h(c, p->rows_nonempty, p->partials, 2 * sizeof(int64_t)));
     VGL_HIP_TRY(hipMemsetAsync(p->partials, 0, 2 * sizeof(int64_t), st));
     VGL_HIP_TRY(hipStreamSynchronize(st));
-    hipFree(temp); hipFree(flags); hipFree(S);
+    vgl_pool_free(st, temp); vgl_pool_free(st, flags); vgl_pool_free(st, S);
     // blocked layout of the HEAVY part for its dense steps (VGL_DS_BLOCKED: 0 never, 1 the heavy part, 2 both parts; default: the heavy part
     // from 2^25 edges -- the build costs about four static sweeps of the part, once per plan).  The light part keeps the static sweep: a
     // blocked pass streams the WHOLE part and sees the distances of the step's start (Jacobi), so the light rounds of the first bucket took
@@ -794,7 +798,7 @@ int vgl_hip_sssp_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_plan *p)
 {
     if (!p) return 0;
     if (c) hipStreamSynchronize(c->stream);
-    for (int k = 0; k < 2; k++) { hipFree(p->prow[k]); hipFree(p->padj[k]); hipFree(p->pw[k]); hipFree(p->part[k].tile_row); }
+    for (int k = 0; k < 2; k++) { vgl_pool_free(p->stream, p->prow[k]); vgl_pool_free(p->stream, p->padj[k]); vgl_pool_free(p->stream, p->pw[k]); hipFree(p->part[k].tile_row); }
     hipFree(p->state); hipFree(p->active); hipFree(p->vt_aux); hipFree(p->partials); hipFree(p->tickets);
     for (int k = 0; k < 2; k++) if (p->blk[k]) vgl_blocked_plan_destroy(p->blk[k]);
     delete p;
