@@ -273,19 +273,23 @@ __global__ __launch_bounds__(VGL_BTHREADS) void vgl_k_bfs_blk_accumulate(const v
 // Degrees of the rows behind a wavefront's 64 bitmap words, LANE = BIT: a frontier of a degree-sorted graph sits in runs of consecutive ids (the
 // hubs of an early level, the short rows of a late one), i.e. in a few FULL words -- with one thread walking the bits of its own word, 300
 // threads did the row-offset reads of a 6 800-vertex level one after the other (82 us for the write pass) and a 5 M-vertex level took 198 us.
-// Here the wavefront takes its non-empty words in turn (four at a time, so that their loads are in flight together): lane b reads the row
+// Here the wavefront takes its non-empty words in turn (VGL_WW_BATCH at a time, so that their loads are in flight together): lane b reads the row
 // offsets of bit b -- consecutive rows, two coalesced 512-byte reads per word -- and `visit(j, set, deg)` sees word j's bit of this lane.
+#ifndef VGL_WW_BATCH_VALUE
+#define VGL_WW_BATCH_VALUE 8
+#endif
+constexpr int VGL_WW_BATCH = VGL_WW_BATCH_VALUE;      // non-empty words whose row-offset loads are in flight together
 template <class Visit>
 __device__ __forceinline__ void vgl_wave_words_degrees(uint64_t w, int64_t first_row_of_wave, const int64_t *rowptr, Visit &&visit)
 {
     const int lane = vgl_lane();
     unsigned long long nonempty = __ballot(w != 0);
     while (nonempty) {
-        int j[4];
-        uint64_t wj[4];
-        int64_t lo[4], hi[4];
+        int j[VGL_WW_BATCH];
+        uint64_t wj[VGL_WW_BATCH];
+        int64_t lo[VGL_WW_BATCH], hi[VGL_WW_BATCH];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < VGL_WW_BATCH; k++) {
             j[k] = nonempty ? __ffsll((long long)nonempty) - 1 : -1;
             if (nonempty) nonempty &= nonempty - 1;
             wj[k] = j[k] >= 0 ? __shfl(w, j[k]) : 0ULL;
@@ -296,7 +300,7 @@ __device__ __forceinline__ void vgl_wave_words_degrees(uint64_t w, int64_t first
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < VGL_WW_BATCH; k++)
             if (j[k] >= 0) visit(j[k], (bool)((wj[k] >> lane) & 1), hi[k] - lo[k]);
     }
 }
