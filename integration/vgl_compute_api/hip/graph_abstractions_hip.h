@@ -97,7 +97,8 @@ private:
     hipStream_t stream;
     double *reduce_partials;                        // 1024 partials + the folded maximum
     unsigned long long *part_counters;              // managed: vgl_k_frontier_parts
-    std::map<void *, vgl_hip_graph *> graph_handles;        // one per direction container (its vertex_pointers / adjacent_ids are borrowed)
+    struct graph_binding { vgl_hip_graph *handle; const void *vertex_pointers, *adjacent_ids; long long edges_count; };
+    std::map<void *, graph_binding> graph_handles;           // one per direction container (its vertex_pointers / adjacent_ids are borrowed)
     std::map<void *, vgl_hip_frontier *> frontier_handles;  // one per frontier container (its flags / ids are borrowed)
 
     static int grid_for(long long n) { return (int)std::min<long long>(4096, std::max<long long>(1, (n + VGL_BLOCK - 1) / VGL_BLOCK)); }
@@ -108,12 +109,22 @@ private:
     template <typename GraphContainer>
     vgl_hip_graph *handle_of(GraphContainer &_graph)
     {
+        // a container that was resized / re-imported since the handle was made (other arrays behind the same object) gets a new handle
         auto it = graph_handles.find((void *)&_graph);
-        if (it != graph_handles.end()) return it->second;
+        if (it != graph_handles.end()) {
+            const graph_binding &b = it->second;
+            if (b.vertex_pointers == (const void *)_graph.get_vertex_pointers() && b.adjacent_ids == (const void *)_graph.get_adjacent_ids() &&
+                b.edges_count == (long long)_graph.get_edges_count())
+                return b.handle;
+            for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);      // (they refer to the old handle)
+            frontier_handles.clear();
+            vgl_hip_graph_destroy(ctx, b.handle);
+            graph_handles.erase(it);
+        }
         vgl_hip_graph *h = nullptr;
         VGL_HIP_BIND_CALL(vgl_hip_graph_create(ctx, _graph.get_vertices_count(), 0, _graph.get_vertices_count(), (const int64_t *)_graph.get_vertex_pointers(),
                                                _graph.get_adjacent_ids(), _graph.get_edges_count(), nullptr, nullptr, 0, &h));
-        graph_handles[(void *)&_graph] = h;
+        graph_handles[(void *)&_graph] = graph_binding{h, (const void *)_graph.get_vertex_pointers(), (const void *)_graph.get_adjacent_ids(), (long long)_graph.get_edges_count()};
         return h;
     }
     // the frontier container may have been changed by host code since the last primitive (add_vertex, clear, set_all_active write its fields and
@@ -123,6 +134,11 @@ private:
     {
         vgl_hip_frontier *h = nullptr;
         auto it = frontier_handles.find((void *)&_frontier);
+        if (it != frontier_handles.end() && vgl_hip_frontier_flags(it->second) != _frontier.flags) {     // another frontier object at a recycled address
+            vgl_hip_frontier_destroy(ctx, it->second);
+            frontier_handles.erase(it);
+            it = frontier_handles.end();
+        }
         if (it != frontier_handles.end()) h = it->second;
         else {
             VGL_HIP_BIND_CALL(vgl_hip_frontier_create_on(ctx, _graph_handle, _frontier.flags, _frontier.ids, &h));
@@ -351,7 +367,7 @@ GraphAbstractionsHIP::~GraphAbstractionsHIP()
 {
     hipStreamSynchronize(stream);
     for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);
-    for (auto &kv : graph_handles) vgl_hip_graph_destroy(ctx, kv.second);
+    for (auto &kv : graph_handles) vgl_hip_graph_destroy(ctx, kv.second.handle);
     hipFree(reduce_partials);
     hipFree(part_counters);
 }
