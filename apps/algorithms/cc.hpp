@@ -3,8 +3,10 @@
 #pragma once
 
 struct ConnectedComponents {
+    // declared = true: the hook is handed over as a DECLARED operator (VGL_MIN_LABEL_OVER_EDGES, an extension of the API: the backend runs it
+    // as its blocked pass) instead of the lambda with atomicMin; the pointer jumps stay lambdas.  Same labels.
     template <typename _T>
-    static double vgl_shiloach_vishkin(VGL_Graph &graph, VerticesArray<_T> &components)
+    static double vgl_shiloach_vishkin(VGL_Graph &graph, VerticesArray<_T> &components, bool declared = false)
     {
         VGL_GRAPH_ABSTRACTIONS api(graph);
         VGL_FRONTIER all(graph);
@@ -24,8 +26,9 @@ struct ConnectedComponents {
                 const int label = components[src_id];
                 if (label < components[dst_id]) { atomicMin(&components[dst_id], label); hooked[0] = 1; }
             };
-            api.scatter(graph, all, hook);
-            const int any_hook = flags.fetch(0);
+            int any_hook;
+            if (declared) any_hook = api.scatter(graph, all, VGL_MIN_LABEL_OVER_EDGES(components)) ? 1 : 0;
+            else { api.scatter(graph, all, hook); any_hook = flags.fetch(0); }
             int any_jump;
             do {
                 flags.clear();
@@ -40,7 +43,7 @@ struct ConnectedComponents {
             if (!any_hook) break;
         } while (true);
         tm.end();
-        performance_stats.print_algorithm_performance_stats("CC (Shiloach-Vishkin, operator API)", tm.get_time(), graph.get_edges_count());
+        performance_stats.print_algorithm_performance_stats(declared ? "CC (Shiloach-Vishkin, operator API, declared hook)" : "CC (Shiloach-Vishkin, operator API)", tm.get_time(), graph.get_edges_count());
         return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
     }
 

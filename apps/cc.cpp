@@ -13,7 +13,7 @@ int main(int argc, char **argv)
         VerticesArray<int> components(graph, SCATTER);
         const bool symmetric = parser.compute_mode == Parser::GENERATE_NEW_GRAPH;      // generated UNDIRECTED_GRAPH inputs hold both directions of every edge
         auto run = [&]() { return parser.fused ? ConnectedComponents::hip_fused(graph, components, symmetric)
-                                               : ConnectedComponents::vgl_shiloach_vishkin(graph, components); };
+                                               : ConnectedComponents::vgl_shiloach_vishkin(graph, components, parser.declared); };
         run();                                   // heat run
         report_performance(run());
         if (parser.get_check_flag()) {

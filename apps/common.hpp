@@ -13,7 +13,7 @@
 
 struct Parser {
     int scale = 10, avg_degree = 5, rounds = 1, source = -1, sink = -1, walk_vertices_percent = 1;
-    bool rmat = true, check = false, direction_optimising = false, fused = false, undirected = false, bfs_based = false, blocked = false, deterministic = false;
+    bool rmat = true, check = false, direction_optimising = false, fused = false, undirected = false, bfs_based = false, blocked = false, deterministic = false, declared = false;
     enum Traversal { PUSH_TRAVERSAL, PULL_TRAVERSAL } traversal = PUSH_TRAVERSAL;                   // cmd_parser.hpp (-push / -pull)
     enum FrontierKind { ALL_ACTIVE_KIND, PARTIAL_ACTIVE_KIND } frontier_kind = ALL_ACTIVE_KIND;     // (-all-active / -partial-active)
     GraphStorageFormat format = CSR_GRAPH;      // -format csr | vcsr (VECTOR_CSR_GRAPH: degree-renumbered, the reference's default)
@@ -42,6 +42,7 @@ struct Parser {
             else if (a == "-do") direction_optimising = true;
             else if (a == "-td") direction_optimising = false;
             else if (a == "-fused") fused = true;
+            else if (a == "-declared") declared = true;                     // cc: the hook as a declared operator (VGL_MIN_LABEL_OVER_EDGES, API extension)
             else if (a == "-deterministic") deterministic = true;           // pr: sums in adjacency order, one lane per vertex (no float atomics)
             else if (a == "-blocked") blocked = true;                       // bfs -fused: prepare the graph for blocked top-down levels (once, not timed)
             else if (a == "-format") {

@@ -518,7 +518,10 @@ def leg_operator_api(scale, ef, extra):
     # neighbours' contributions in adjacency order between the pre and post operators, the multicore recipe: 1e-6 of the oracle, bit-identical
     # from run to run; no load balancing, so for graphs without hubs like this uniform one) is what `operator_api` quotes; the float-atomics
     # form (gpu_pr.hpp's shape, 2e-5, any graph) rides along as operator_api_atomics_mteps
-    variants = {"pagerank_5_iterations": [("operator_api", ["-deterministic"]), ("operator_api_atomics", [])]}
+    # Shiloach-Vishkin: `operator_api` is the lambda form (atomicMin per edge); operator_api_declared hands the hook over as a DECLARED operator
+    # (VGL_MIN_LABEL_OVER_EDGES, an extension of the API: the backend may then run it as its blocked pass), pointer jumps stay lambdas
+    variants = {"pagerank_5_iterations": [("operator_api", ["-deterministic"]), ("operator_api_atomics", [])],
+                "cc_shiloach_vishkin": [("operator_api", []), ("operator_api_declared", ["-declared"])]}
     for name, (app, argv, fused) in runs.items():
         exe = os.path.join(root, "apps", "bin", app)
         if not os.path.exists(exe):
@@ -547,6 +550,8 @@ def leg_operator_api(scale, ef, extra):
             pass
         if row.get("operator_api_mteps") and row.get("fused_mteps"):
             row["operator_api_over_fused"] = round(row["operator_api_mteps"] / row["fused_mteps"], 3)
+        if row.get("operator_api_declared_mteps") and row.get("fused_mteps"):
+            row["operator_api_declared_over_fused"] = round(row["operator_api_declared_mteps"] / row["fused_mteps"], 3)
         out[name] = row
     # ... and the reference's OWN algorithms/bfs/bfs.hpp, unchanged, on the operator class (oracle/_ref/dropin_hip: built where /root/reference
     # exists from oracle/dropin_driver.cpp; the prebuilt binary travels)

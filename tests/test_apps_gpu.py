@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "apps", "bin")
 
 
-def run_app(app, args, tmp_path):
+def run_app(app, args, tmp_path, env=None):
     dump = str(tmp_path / (app + ".bin"))
     cmd = [os.path.join(BIN, app + "_hip")] + [str(a) for a in args] + ["-dump", dump]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     return out.stdout, dump
 
@@ -127,11 +127,17 @@ def test_pr_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
 
 
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)
-@pytest.mark.parametrize("mode", [[], ["-fused"]])
+@pytest.mark.parametrize("mode", [[], ["-fused"], ["-declared"], ["-declared", "-blocked-hook"]], ids=["operator_api", "fused", "declared", "declared_blocked"])
 def test_cc_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
+    """-declared: the hook as a DECLARED operator (VGL_MIN_LABEL_OVER_EDGES, an extension of the operator API): the backend runs it as a library
+    pass -- the atomic kernel on a graph this small, the blocked LDS-window pass when forced (VGL_CC_BLOCKED=1) -- same labels"""
     O = oracle
     src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed, symmetric=True)
-    out, dump = run_app("cc", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-check"] + mode, tmp_path)
+    env = None
+    if "-blocked-hook" in mode:
+        mode = [m for m in mode if m != "-blocked-hook"]
+        env = dict(os.environ, VGL_CC_BLOCKED="1")
+    out, dump = run_app("cc", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-check"] + mode, tmp_path, env=env)
     assert "error count: 0" in out
     assert (np.fromfile(dump, np.int32) == O.cc_sv(rowptr, adj)[0]).all()
 

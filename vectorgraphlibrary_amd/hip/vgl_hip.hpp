@@ -909,6 +909,16 @@ static const vgl_empty_edge_op EMPTY_EDGE_OP;
 // ------------------------------------------------------------------------------------------------------------------
 // GraphAbstractionsHIP: public member list of graph_abstractions_template.h:44-104
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// DECLARED operators -- an extension, not part of the reference API.  A lambda is opaque: the backend must run it per edge in CSR order with
+// whatever gathers and atomics it contains.  When the caller STATES the algebra of an all-active advance instead, the backend may pick the
+// layout: VGL_MIN_LABEL_OVER_EDGES(labels) says "labels[dst] = min(labels[dst], labels[src]) for every edge" (the Shiloach-Vishkin hook,
+// shiloach_vishkin.hpp:37-50) and scatter() runs it as the library's blocked pass (vgl_blocked.h: both label windows in LDS, 4 - 12 B per
+// edge streamed, no atomic per edge) -- the same fixed point as the lambda form, reached in passes that see the labels of the pass start.
+// ------------------------------------------------------------------------------------------------------------------
+struct vgl_declared_min_label { int *labels; };
+inline vgl_declared_min_label VGL_MIN_LABEL_OVER_EDGES(VerticesArray<int> &labels) { return vgl_declared_min_label{labels.get_ptr()}; }
+
 class GraphAbstractionsHIP {
     VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
     double *reduce_partials = nullptr;          // one per workgroup of a reduce (+ the folded maximum)
@@ -1048,6 +1058,18 @@ public:
     {
         if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";
         advance_worker(g, f, SCATTER, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP);
+    }
+    // a declared operator over an ALL_ACTIVE frontier (see VGL_MIN_LABEL_OVER_EDGES): returns whether any label changed (host value: the call synchronises)
+    bool scatter(VGL_Graph &g, VGL_Frontier &f, vgl_declared_min_label op)
+    {
+        if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";
+        if (f.get_sparsity_type() != ALL_ACTIVE_FRONTIER) throw "VGL ERROR: a declared operator needs an all-active frontier";
+        const vgl_stopwatch watch;
+        int changed = 0;
+        VGL_HIP_CALL(vgl_hip_cc_hook_owned(VGL_RUNTIME::ctx(), g.get_handle(), op.labels, &changed));
+        const long long work = g.get_direction_view(SCATTER).edges;
+        performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, false);
+        return changed != 0;
     }
     template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation,
               typename CollectiveEdgeOperation, typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
