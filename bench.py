@@ -518,10 +518,11 @@ def leg_operator_api(scale, ef, extra):
     # neighbours' contributions in adjacency order between the pre and post operators, the multicore recipe: 1e-6 of the oracle, bit-identical
     # from run to run; no load balancing, so for graphs without hubs like this uniform one) is what `operator_api` quotes; the float-atomics
     # form (gpu_pr.hpp's shape, 2e-5, any graph) rides along as operator_api_atomics_mteps
-    # Shiloach-Vishkin: `operator_api` is the lambda form (atomicMin per edge); operator_api_declared hands the hook over as a DECLARED operator
-    # (VGL_MIN_LABEL_OVER_EDGES, an extension of the API: the backend may then run it as its blocked pass), pointer jumps stay lambdas
+    # Shiloach-Vishkin / Bellman-Ford: `operator_api` is the lambda form (atomicMin per edge); operator_api_declared hands the hook / the relax over as a
+    # DECLARED operator (VGL_MIN_LABEL_OVER_EDGES / VGL_RELAX_OVER_EDGES, an extension of the API: the backend may then run it as its blocked pass)
     variants = {"pagerank_5_iterations": [("operator_api", ["-deterministic"]), ("operator_api_atomics", [])],
-                "cc_shiloach_vishkin": [("operator_api", []), ("operator_api_declared", ["-declared"])]}
+                "cc_shiloach_vishkin": [("operator_api", []), ("operator_api_declared", ["-declared"])],
+                "sssp_bellman_ford_all_active_push": [("operator_api", []), ("operator_api_declared", ["-declared"])]}
     for name, (app, argv, fused) in runs.items():
         exe = os.path.join(root, "apps", "bin", app)
         if not os.path.exists(exe):

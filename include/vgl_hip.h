@@ -226,6 +226,9 @@ int vgl_hip_sssp_pull_plan_destroy(vgl_hip_ctx *ctx, vgl_hip_sssp_pull_plan *pla
 /* edges laid out, how many of them as fused tiles (dense pairs of 16384-id blocks: both windows in LDS, 8 bytes per edge streamed instead of
  * 16), bytes one pull pass streams (pad entries included) and bytes the plan keeps resident */
 int vgl_hip_sssp_pull_plan_info(vgl_hip_sssp_pull_plan *plan, int64_t *edges, int64_t *fused_edges, int64_t *streamed_bytes_per_pass, int64_t *plan_bytes);
+/* one all-edges relaxation through the plan (values of the pass start; the relax of shortest_paths.hpp:123-133 over every edge);
+ * *changed = 1 when a distance decreased.  Synchronises. */
+int vgl_hip_sssp_pull_pass(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_sssp_pull_plan *plan, float *d_dist, int *changed);
 int vgl_hip_sssp_run_pull(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan *plan, int32_t source,
                           int mode, float *d_dist, vgl_hip_sssp_stats *stats);
 int vgl_hip_sswp_run_pull(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_capacities, vgl_hip_sssp_pull_plan *plan, int32_t source,

@@ -45,8 +45,9 @@ def test_bfs_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
 
 
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)
-@pytest.mark.parametrize("mode", [[], ["-fused"], ["-pull"], ["-push", "-all-active"], ["-fused", "-pull"], ["-fused", "-do"], ["-pull", "-format", "vcsr"]],
-                         ids=["push", "fused", "pull", "push_all_active", "fused_pull", "fused_do", "pull_vcsr"])
+@pytest.mark.parametrize("mode", [[], ["-fused"], ["-pull"], ["-push", "-all-active"], ["-fused", "-pull"], ["-fused", "-do"], ["-pull", "-format", "vcsr"],
+                                  ["-declared"], ["-declared", "-format", "vcsr"]],
+                         ids=["push", "fused", "pull", "push_all_active", "fused_pull", "fused_do", "pull_vcsr", "declared", "declared_vcsr"])
 def test_sssp_app(kind, scale, ef, seed, mode, tmp_path, oracle, ctx):
     O = oracle
     src, dst, rowptr, adj, perm = graph(O, kind, scale, ef, seed)

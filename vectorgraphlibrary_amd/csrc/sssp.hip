@@ -459,6 +459,21 @@ int vgl_hip_sssp_pull_plan_destroy(vgl_hip_ctx *c, vgl_hip_sssp_pull_plan *p)
     delete p;
     return 0;
 }
+// ONE all-edges relaxation as a blocked pass over the plan (dist[dst] = min(dist[dst], dist[src] + w) for every edge, the values of the pass
+// start): the step behind the operator class's declared relax.  *changed = 1 when a distance decreased.  Synchronises.
+int vgl_hip_sssp_pull_pass(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_pull_plan *plan, float *d_dist, int *changed)
+{
+    if (!c || !g || !plan || !plan->blk || !d_dist) VGL_FAIL("sssp_pull_pass: null argument");
+    if (plan->g != g || plan->g_uid != g->uid) VGL_FAIL("sssp_pull_pass: the pull plan was built for another graph");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("sssp_pull_pass: graph handle must own all rows");
+    const int64_t words = vgl_ceil_div(g->V, 64);
+    VGL_TRY(vgl_zero_words(c, g->bm_next, words));
+    const vgl_path_blk_op<vgl_path_shortest> op{d_dist, g->bm_next, g->row_begin};
+    VGL_TRY((vgl_blocked_pass<vgl_path_blk_op<vgl_path_shortest>, true, false>(c, plan->blk, op, "sssp_pull_gather", "sssp_pull_accumulate", false, "sssp_pull_fused")));
+    VGL_TRY(vgl_bfs_bm_gnf(c, g, g->bm_next, true, false));          // (the improved vertices were marked in the bitmap: its size says whether any were)
+    if (changed) *changed = c->h_counters[C_FRONT] != 0;
+    return 0;
+}
 int vgl_hip_sssp_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan *plan, int32_t source, int mode,
                           float *d_dist, vgl_hip_sssp_stats *stats)
 {

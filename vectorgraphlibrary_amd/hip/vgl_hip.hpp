@@ -534,14 +534,31 @@ class VGL_Graph {
     int64_t *out_rowptr = nullptr, *in_rowptr = nullptr, *out_perm = nullptr, *in_perm = nullptr;
     int32_t *out_adj = nullptr, *in_adj = nullptr;
     vgl_hip_graph *handle = nullptr;
+    // layout behind the declared relax (VGL_RELAX_OVER_EDGES): built on first use, kept while the weights array stays the same
+    vgl_hip_sssp_pull_plan *relax_plan = nullptr;
+    const float *relax_plan_weights = nullptr;
+    unsigned long long relax_plan_version = 0;
     std::vector<long long> host_out_rowptr;
 public:
     explicit VGL_Graph(GraphStorageFormat f = CSR_GRAPH) : format(f) {}
     ~VGL_Graph() { release(); }
     VGL_Graph(const VGL_Graph &) = delete;
+    // (version: EdgesArray::version(), bumped when the array's contents are rewritten -- the plan holds a reordered copy of the weights)
+    vgl_hip_sssp_pull_plan *get_relax_plan(const float *weights, unsigned long long version = 0)
+    {
+        if (!relax_plan || relax_plan_weights != weights || relax_plan_version != version) {
+            if (relax_plan) VGL_HIP_CALL(vgl_hip_sssp_pull_plan_destroy(VGL_RUNTIME::ctx(), relax_plan));
+            relax_plan = nullptr;
+            VGL_HIP_CALL(vgl_hip_sssp_pull_plan_create(VGL_RUNTIME::ctx(), handle, weights, &relax_plan));
+            relax_plan_weights = weights; relax_plan_version = version;
+        }
+        return relax_plan;
+    }
 private:
     void release()
     {
+        if (relax_plan) vgl_hip_sssp_pull_plan_destroy(VGL_RUNTIME::ctx(), relax_plan);
+        relax_plan = nullptr; relax_plan_weights = nullptr;
         if (handle) vgl_hip_graph_destroy(VGL_RUNTIME::ctx(), handle);
         for (void *p : {(void *)out_rowptr, (void *)in_rowptr, (void *)out_perm, (void *)in_perm, (void *)out_adj, (void *)in_adj, (void *)d_fwd,
                         (void *)d_bwd})
@@ -918,6 +935,11 @@ static const vgl_empty_edge_op EMPTY_EDGE_OP;
 // ------------------------------------------------------------------------------------------------------------------
 struct vgl_declared_min_label { int *labels; };
 inline vgl_declared_min_label VGL_MIN_LABEL_OVER_EDGES(VerticesArray<int> &labels) { return vgl_declared_min_label{labels.get_ptr()}; }
+// VGL_RELAX_OVER_EDGES(distances, weights): "distances[dst] = min(distances[dst], distances[src] + weights[edge]) for every edge" (the Bellman-Ford
+// relax, shortest_paths.hpp:123-133).  The graph object keeps a blocked layout of (adjacency, weights) for the weight array last used (built on first use).
+struct vgl_declared_relax { float *distances; const float *weights; unsigned long long weights_version; };
+inline vgl_declared_relax VGL_RELAX_OVER_EDGES(VerticesArray<float> &distances, EdgesArray<float> &weights)
+{ return vgl_declared_relax{distances.get_ptr(), weights.get_ptr(), weights.version()}; }
 
 class GraphAbstractionsHIP {
     VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
@@ -1060,6 +1082,19 @@ public:
         advance_worker(g, f, SCATTER, edge_op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP);
     }
     // a declared operator over an ALL_ACTIVE frontier (see VGL_MIN_LABEL_OVER_EDGES): returns whether any label changed (host value: the call synchronises)
+    bool scatter(VGL_Graph &g, VGL_Frontier &f, vgl_declared_relax op)
+    {
+        if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";
+        if (f.get_sparsity_type() != ALL_ACTIVE_FRONTIER) throw "VGL ERROR: a declared operator needs an all-active frontier";
+        vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+        vgl_hip_sssp_pull_plan *plan = g.get_relax_plan(op.weights, op.weights_version);       // (kept by the graph: the next call with the same weights pays nothing)
+        const vgl_stopwatch watch;
+        int changed = 0;
+        VGL_HIP_CALL(vgl_hip_sssp_pull_pass(c, g.get_handle(), plan, op.distances, &changed));
+        const long long work = g.get_direction_view(SCATTER).edges;
+        performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, false);
+        return changed != 0;
+    }
     bool scatter(VGL_Graph &g, VGL_Frontier &f, vgl_declared_min_label op)
     {
         if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";

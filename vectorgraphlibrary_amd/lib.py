@@ -99,6 +99,7 @@ _SIGNATURES = {
     "vgl_hip_sssp_run_delta": [_p, _p, _p, _i32, C.c_float, _p, C.POINTER(SsspStats)],
     "vgl_hip_sssp_pull_plan_create": [_p, _p, _p, _pp],
     "vgl_hip_sssp_pull_plan_destroy": [_p, _p],
+    "vgl_hip_sssp_pull_pass": [_p, _p, _p, _p, C.POINTER(_int)],
     "vgl_hip_sssp_pull_plan_info": [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "vgl_hip_sssp_run_pull": [_p, _p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
     "vgl_hip_sswp_run_pull": [_p, _p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
