@@ -1,10 +1,12 @@
 """single-GPU rehearsal of the N-rank weak-scaling bench: build all P shards of RMAT scale S with the streaming builder,
-drive them in lock-step (exchange = concatenated bitmaps) with the same direction rule as distributed.bfs_sharded, and
+drive them in lock-step (exchange = concatenated bitmaps) with the same direction rule as protocol_model.bfs_sharded, and
 compare direction-optimising vs top-down levels."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from vectorgraphlibrary_amd import api, distributed as vd
+from vectorgraphlibrary_amd import api
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+import protocol_model as vd  # the Python protocol model (tests/protocol_model.py)
 
 S, P = int(sys.argv[1]), int(sys.argv[2])
 PLACEMENT = sys.argv[3] if len(sys.argv) > 3 else "dealt"

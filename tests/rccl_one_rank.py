@@ -11,7 +11,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vectorgraphlibrary_amd import api  # noqa: E402
-from vectorgraphlibrary_amd import distributed as vd  # noqa: E402
+import protocol_model as vd  # noqa: E402  (tests/protocol_model.py: the Python model + the package's shard builder)
 
 
 def main():

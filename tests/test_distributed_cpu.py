@@ -1,4 +1,4 @@
-"""CPU test (gloo, world_size 2) of the multi-GPU super-step drivers in vectorgraphlibrary_amd/distributed.py: the
+"""CPU test (gloo, world_size 2) of the multi-GPU super-step drivers of the Python protocol model (tests/protocol_model.py; the shipped loops are C++): the
 edge-cut partition, the per-step exchange (bitmap all-gather / min all-reduce / owned-slice sum) and the termination
 logic.  The per-shard kernels are replaced by a numpy test double defined HERE (no GPU code can run in this container);
 the HIP kernels behind the same `ops` interface are covered by tests/test_gpu_parity.py::test_sharded_super_steps_single_process."""
@@ -229,7 +229,7 @@ def _worker(rank, world, port, results):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
-    from vectorgraphlibrary_amd import distributed as vd
+    import protocol_model as vd
     scale, ef, seed = 9, 8, 13
     V = 1 << scale
     src, dst = O.gen_rmat(scale, ef, seed)
@@ -305,7 +305,7 @@ def test_sharded_drivers_gloo_world2():
 
 def test_single_process_driver_without_process_group(oracle):
     O = oracle
-    from vectorgraphlibrary_amd import distributed as vd
+    import protocol_model as vd
     V = 256
     src, dst = O.gen_uniform(8, 4, 3)
     rowptr, adj, perm = O.coo_to_csr(V, src, dst)

@@ -234,7 +234,7 @@ def test_sharded_super_steps_single_process(ctx, oracle):
     single-GPU results (the multi-process version of the same protocol is covered with gloo in test_distributed_cpu)."""
     import torch
     from vectorgraphlibrary_amd import api
-    from vectorgraphlibrary_amd.distributed import HipShardOps
+    from protocol_model import HipShardOps
     O = oracle
     g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, "rmat", 12, 16, 21)
     w = ctx.gather_u32(g.perm, ctx.gen_weights(len(hs), 21))
@@ -272,7 +272,7 @@ def test_sharded_super_steps_single_process(ctx, oracle):
         assert (r.cpu().numpy() == ref).all()
 
     # the driver itself (world size 1, one shard = whole graph): top-down and direction-optimising must agree with the oracle
-    from vectorgraphlibrary_amd import distributed as vd
+    import protocol_model as vd
     whole = HipShardOps(g, w)
     degrees = (g.out_rowptr[1:] - g.out_rowptr[:-1]).to(torch.int32)
     assert (vd.bfs_sharded(whole, source)[0].cpu().numpy() == ref).all()
@@ -520,7 +520,7 @@ def test_generated_shards_match_whole_graph_build(kind, renumber, placement, ctx
     direction-optimising BFS over them reproduces the oracle's levels."""
     import torch
     from vectorgraphlibrary_amd import api
-    from vectorgraphlibrary_amd import distributed as vd
+    import protocol_model as vd
     O = oracle
     scale, ef, seed = 13, 16, 77
     P = 4 if placement == "dealt" else 3
@@ -779,9 +779,10 @@ def test_scc_larger_graphs_match_oracle(kind, scale, ef, ctx, oracle):
 
 @pytest.mark.gpu
 def test_bitmap_or_parts(ctx):
-    """the merge step of the two-phase top-down exchange (distributed.bfs_sharded): out = OR of the received slices"""
+    """the merge step of the two-phase top-down exchange (protocol_model.bfs_sharded): out = OR of the received slices"""
     import torch
-    from vectorgraphlibrary_amd import api, distributed as vd
+    from vectorgraphlibrary_amd import api
+    import protocol_model as vd
     V = 64 * 1000
     src = torch.zeros(1, dtype=torch.int32, device=ctx.device)
     g = api.Graph.from_coo(ctx, V, src, src)
@@ -930,7 +931,7 @@ def test_sparse_exchange_primitives(ctx):
     """vgl_hip_bitmap_to_ids / vgl_hip_bfs_apply_ids (id-list exchange of tiny multi-GPU levels) against numpy: counts beyond the
     cap are reported, lists are a subset of the set bits, duplicates across parts and visited vertices are taken once / not at all"""
     import torch
-    from vectorgraphlibrary_amd import distributed as vd
+    import protocol_model as vd
 
     class G:                                        # the two calls only need V and the context
         pass
@@ -997,7 +998,7 @@ def test_edgeless_graph_with_renumbering(renumber, ctx):
 def test_apply_bitmaps_owned(ctx):
     """vgl_hip_bfs_apply_bitmaps_owned: bitmaps updated for every vertex, levels / counts / degree sums for the owned range only"""
     import torch
-    from vectorgraphlibrary_amd import distributed as vd
+    import protocol_model as vd
 
     class G:
         pass
@@ -1148,7 +1149,7 @@ def test_cc_blocked_hook(kind, scale, ef, symmetric, ctx, oracle):
     import os
     import torch
     from vectorgraphlibrary_amd import api
-    from vectorgraphlibrary_amd import distributed as vd
+    import protocol_model as vd
     O = oracle
     g, V, hs, hd, rowptr, adj, perm = build_case(ctx, O, kind, scale, ef, 17, symmetric=symmetric)
     ref, _ = O.cc_sv(rowptr, adj)
