@@ -27,14 +27,14 @@ def run(app, *args):
 
 
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
-@pytest.mark.parametrize("kind,scale,edges", [("rmat", 14, 16), ("ru", 13, 8)])
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 14, 16), ("ru", 13, 8), ("rmat", 6, 4), ("ru", 9, 1)])      # the last two: a few vector segments; mostly isolated vertices
 def test_reference_bfs_app(kind, scale, edges, fmt):
     text = run("bfs", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, "-check", "-it", "4")
     assert len(re.findall(r"error count: 0\b", text)) == 4, text[-3000:]          # one verify_results per round (apps/bfs/bfs.cpp:39-49)
 
 
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
-@pytest.mark.parametrize("kind,scale,edges", [("rmat", 13, 16), ("ru", 12, 8)])
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 13, 16), ("ru", 12, 8), ("rmat", 7, 3)])
 def test_reference_sswp_app(kind, scale, edges, fmt):
     text = run("sswp", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, "-check", "-it", "2")
     assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
