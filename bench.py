@@ -833,9 +833,9 @@ def main():
         lv_do = ctx.empty(g.V, torch.int32)               # one levels array for all rounds, as apps/bfs/bfs.cpp:31,36-40 reuses its VerticesArray
         barrier()
         t0 = time.perf_counter()
-        for s in sources[args.warmup:]:
-            st_one = api.bfs(g, s, api.BFS_DIRECTION_OPT, levels=lv_do, raw=True)[1]
-            stats.append(st_one)
+        # the K timed traversals behind ONE call of the C ABI (vgl_hip_bfs_run_batch: the rounds loop of apps/bfs/bfs.cpp:36-50 in C, so that the
+        # ~10 us a Python -> ctypes round trip costs per traversal is not in the metric); per-traversal statistics come back as an array
+        _, stats = api.bfs_batch(g, sources[args.warmup:], api.BFS_DIRECTION_OPT, levels=lv_do)
         barrier()
         dt = time.perf_counter() - t0
         # ---- roofline of the dominant kernel, from the HIP events recorded inside the timed region ----

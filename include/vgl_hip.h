@@ -183,6 +183,10 @@ typedef struct {
 #define VGL_HIP_BFS_DIRECTION_OPT 1      /* + bottom-up steps; switch rule change_state.hpp:100-141 (ALPHA 15, BETA 18) */
 int vgl_hip_bfs_run(vgl_hip_ctx *ctx, vgl_hip_graph *g, int32_t source, int mode,
                     int32_t *d_levels, vgl_hip_bfs_stats *stats);
+/* `count` traversals from HOST source ids one after the other behind one call (the rounds loop of apps/bfs/bfs.cpp:36-50): d_levels is reused
+ * and holds the levels of the last source afterwards; stats (optional) has `count` entries.  Stops at the first failing traversal. */
+int vgl_hip_bfs_run_batch(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *sources, int32_t count, int mode, int32_t *d_levels,
+                          vgl_hip_bfs_stats *stats);
 /* Optional graph preparation for repeated top-down traversals (the counterpart of the reference's offline graph import,
  * vgl_graph.hpp:57-68): lays the outgoing edges out for the blocked advance (4 bytes per edge kept, a radix sort of the edges once).
  * Afterwards vgl_hip_bfs_run expands the levels that hold at least a tenth of the edges (VGL_BFS_BLOCKED_SHARE) as a blocked pass --

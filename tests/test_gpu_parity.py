@@ -851,6 +851,27 @@ def test_random_graphs_all_algorithms(seed, ctx, oracle):
         gs.close()
 
 
+def test_bfs_batch_equals_single_runs(oracle, ctx):
+    """vgl_hip_bfs_run_batch (the bench's timed region: the rounds loop behind one call of the C ABI): per-traversal statistics equal those of
+    single calls, the levels buffer holds the last source's levels, an out-of-range source fails the call"""
+    import torch
+    from vectorgraphlibrary_amd import api
+    from vectorgraphlibrary_amd.lib import VglHipError
+    O = oracle
+    src, dst = O.gen_rmat(12, 16, 7)
+    rowptr, adj, _ = O.coo_to_csr(1 << 12, src, dst)
+    g = api.Graph.from_coo(ctx, 1 << 12, torch.from_numpy(src).to(ctx.device), torch.from_numpy(dst).to(ctx.device), with_incoming=True)
+    sources = [int(np.argmax(np.diff(rowptr))), 5, 77, 1234]
+    for mode in (api.BFS_DIRECTION_OPT, api.BFS_TOP_DOWN):
+        levels, stats = api.bfs_batch(g, sources, mode)
+        assert (levels.cpu().numpy() == O.bfs_top_down(rowptr, adj, sources[-1])[0]).all()
+        for s, st in zip(sources, stats):
+            one = api.bfs(g, s, mode, raw=True)[1]
+            assert st["levels"] == one["levels"] and st["discovered"] == one["discovered"] and st["frontier_total"] == one["frontier_total"]
+    with pytest.raises(VglHipError):
+        api.bfs_batch(g, [0, 1 << 12], api.BFS_TOP_DOWN)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,scale,ef", [("rmat", 15, 8), ("rmat", 18, 16), ("ru", 16, 8), ("ru", 14, 2), ("ru", 13, 1), ("rmat", 10, 4)])
 def test_bfs_small_level_kernel_paths(kind, scale, ef, ctx, oracle):

@@ -292,6 +292,18 @@ def bfs(graph, source, mode=BFS_DIRECTION_OPT, levels=None, raw=False):
     return (levels if raw else graph.to_original(levels)), _stats(st)
 
 
+def bfs_batch(graph, sources, mode=BFS_DIRECTION_OPT, levels=None):
+    """vgl_hip_bfs_run_batch: the traversals from `sources` (the graph's own numbering) one after the other behind ONE call of the C ABI -- the rounds
+    loop of the reference's bfs app; returns (levels of the last source, list of per-traversal stats)."""
+    ctx = graph.ctx
+    levels = ctx.empty(graph.V, torch.int32) if levels is None else levels
+    n = len(sources)
+    src = (C.c_int32 * n)(*[int(s) for s in sources])
+    st = (_l.BfsStats * n)()
+    _l.check(ctx.L.vgl_hip_bfs_run_batch(ctx.h, graph.h, src, n, mode, _ptr(levels), st))
+    return levels, [_stats(st[i]) for i in range(n)]
+
+
 class SsspPlan:
     """light/heavy partitioned copy of (adjacency, weights) for the bucketed SSSP schedule; reusable across sources."""
 

@@ -1639,6 +1639,15 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     return 0;
 }
 
+// `count` traversals one after the other (the rounds loop of apps/bfs/bfs.cpp:36-50 behind one call): d_levels is reused and holds the levels
+// of the last source afterwards, stats[i] (optional) those of traversal i.  Stops at the first failing traversal.
+int vgl_hip_bfs_run_batch(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *sources, int32_t count, int mode, int32_t *d_levels, vgl_hip_bfs_stats *stats)
+{
+    if (!sources || count < 0) VGL_FAIL("bfs_run_batch: null argument");
+    for (int32_t i = 0; i < count; i++) VGL_TRY(vgl_hip_bfs_run(c, g, sources[i], mode, d_levels, stats ? stats + i : nullptr));
+    return 0;
+}
+
 int vgl_hip_bfs_step_top_down(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_levels, int32_t level, const uint64_t *d_visited_bits,
                               int64_t *local_frontier, int64_t *local_edges)
 {

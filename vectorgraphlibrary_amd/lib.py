@@ -93,6 +93,7 @@ _SIGNATURES = {
     "vgl_hip_reduce_sum_f32": [_p, _p, _p, C.POINTER(_dbl)],
     "vgl_hip_count_not_equal_u32": [_p, _i32, _p, _p, C.POINTER(_i64)],
     "vgl_hip_bfs_run": [_p, _p, _i32, _int, _p, C.POINTER(BfsStats)],
+    "vgl_hip_bfs_run_batch": [_p, _p, C.POINTER(_i32), _i32, _int, _p, C.POINTER(BfsStats)],
     "vgl_hip_bfs_prepare_blocked": [_p, _p],
     "vgl_hip_sssp_run": [_p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
     "vgl_hip_sswp_run": [_p, _p, _p, _i32, _int, _p, C.POINTER(SsspStats)],
