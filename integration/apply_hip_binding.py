@@ -51,6 +51,29 @@ RULES = [
     ("vgl_runtime/helpers/memory_API/memory_API.hpp", "before", r"^\s*#elif defined\(__USE_KNL__\)$",
      "        #elif defined(__USE_HIP__)\n        hipFree((void*)_ptr);\n", 2, 1),
     ("vgl_runtime/helpers/memory_API/memory_API.h", "before", r"^class MemoryAPI", "#ifdef __USE_HIP__\n#include <hip/hip_runtime.h>\n#endif\n\n"),
+    # ---- move_to_device / move_to_host of every container and user array: the CUDA flavour's declarations, definitions and call sites
+    #      (algorithms/bfs/bfs.hpp:70-74, hits/hits.hpp:12-17, the gpu_*.hpp variants) exist under __USE_HIP__ too; they do NOTHING there: the
+    #      managed pages of a pool without XNACK migrate back on every host touch, and the prefetch hints made the bfs app slower ----
+    ("*", "sub_tree", r"#ifdef __USE_GPU__(?=\n(?:\s*template <typename _T>\n)?[^\n]*move_(?:array_)?to_(?:device|host))", GPU_OR_HIP, 43,
+     ("vgl_runtime/helpers/memory_API/memory_API.hpp",)),
+    ("vgl_runtime/helpers/memory_API/memory_API.hpp", "after", r"\A",
+     "// HIP flavour: the prefetch hints of the CUDA flavour are accepted and ignored (see integration/apply_hip_binding.py)\n"
+     "#ifdef __USE_HIP__\n"
+     "template <typename _T>\nvoid MemoryAPI::move_array_to_device(_T *_ptr, size_t _size) {}\n\n"
+     "template <typename _T>\nvoid MemoryAPI::move_array_to_host(_T *_ptr, size_t _size) {}\n#endif\n\n"),
+    # ---- the reference's own GPU variants of PageRank, SSSP and Shiloach-Vishkin (operators written for device lambdas; three CUDA runtime
+    #      calls by name get a HIP branch) ----
+    ("algorithms/pr/pr.h", "sub", r"^(\s*)#ifdef __USE_GPU__$", r"\1" + GPU_OR_HIP, 1),
+    ("algorithms/pr/gpu_pr.hpp", "sub", r"^#ifdef __USE_GPU__$", GPU_OR_HIP, 1),
+    ("algorithms/sssp/shortest_paths.h", "sub", r"^(\s*)#ifdef __USE_GPU__$", r"\1" + GPU_OR_HIP, 3),
+    ("algorithms/sssp/gpu_shortest_paths.hpp", "sub", r"^#ifdef __USE_GPU__$", GPU_OR_HIP, 4),
+    ("algorithms/cc/cc.h", "sub", r"^(\s*)#ifdef __USE_GPU__$", r"\1" + GPU_OR_HIP, 1),
+    ("algorithms/cc/gpu_shiloach_vishkin.hpp", "sub", r"^#ifdef __USE_GPU__$", GPU_OR_HIP, 1),
+    ("algorithms/sssp/gpu_shortest_paths.hpp", "sub", r"\bGraphAbstractionsGPU\b", "VGL_GRAPH_ABSTRACTIONS", 3),      # (the file names the CUDA class instead of the macro)
+    ("algorithms/sssp/gpu_shortest_paths.hpp", "sub", r"^(\s*)cudaMemset\((.*)\);$",
+     r"\1#ifdef __USE_HIP__\n\1(void)hipMemset(\2);\n\1#else\n\1cudaMemset(\2);\n\1#endif", 1),
+    ("algorithms/cc/gpu_shiloach_vishkin.hpp", "sub", r"^(\s*)cudaMallocManaged\((.*)\);$",
+     r"\1#ifdef __USE_HIP__\n\1(void)hipMallocManaged(\2);\n\1#else\n\1cudaMallocManaged(\2);\n\1#endif", 2),
     # ---- user data and containers readable from device code ----
     ("vgl_datastructures/vertices_array/vertices_array.h", "sub", r"#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)", GPU_OR_HIP),
     ("vgl_datastructures/edges_array/edges_array.h", "sub", r"#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)", GPU_OR_HIP),

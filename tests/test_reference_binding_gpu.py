@@ -1,8 +1,10 @@
 """The reference's OWN applications on the reference's OWN containers, run on the MI355X through the bound-in HIP backend class
-(oracle/_ref/vgl_hip_{bfs,sswp,hits,scc}: apps/<app>/<app>.cpp of the reference, compiled in the CPU container by `make -C oracle binding` with
+(oracle/_ref/vgl_hip_{bfs,sswp,hits,scc,pr,sssp,cc}: apps/<app>/<app>.cpp of the reference, compiled in the CPU container by `make -C oracle binding` with
 -D __USE_HIP__ after integration/apply_hip_binding.py; tests/test_reference_binding.py is the build half).  Each run uses the reference's own
 -check: its sequential implementation (BFS::seq_top_down, SSWP::seq_dijkstra, HITS::seq_hits, SCC::seq_tarjan) recomputes the result on the host
-from the same containers and verify_results / verify_ranking_results / equal_components compare.  CSR_GRAPH exercises advance_worker(CSRGraph&,
+from the same containers and verify_results / verify_ranking_results / equal_components compare.  pr, sssp and cc run the reference's own GPU
+variants of the algorithms (algorithms/pr/gpu_pr.hpp, sssp/gpu_shortest_paths.hpp, cc/gpu_shiloach_vishkin.hpp: device lambdas with atomics, written for
+its CUDA backend), enabled for __USE_HIP__ by the binding's edits.  CSR_GRAPH exercises advance_worker(CSRGraph&,
 FrontierCSR&); VECTOR_CSR_GRAPH exercises the three degree ranges with the vector-extension kernel and, for SSWP, weights addressed by VE-space
 global_edge_pos in the collective range (EdgesArray_VectorCSR)."""
 import os
@@ -49,4 +51,27 @@ def test_reference_hits_app(fmt):
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
 def test_reference_scc_app(fmt):
     text = run("scc", "-s", "12", "-e", "8", "-type", "rmat", "-format", fmt, "-check")
+    assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind", ["rmat", "ru"])
+def test_reference_pr_app(kind, fmt):
+    text = run("pr", "-s", "12", "-e", "16", "-type", kind, "-format", fmt, "-check", "-it", "5")      # PageRank::vgl_page_rank of gpu_pr.hpp (float atomics)
+    assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
+
+
+@pytest.mark.parametrize("mode", [[], ["-all-active"], ["-pull"], ["-all-active", "-pull"]], ids=["partial_active_push", "all_active_push", "partial_active_pull", "all_active_pull"])
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+def test_reference_sssp_app(fmt, mode):
+    """ShortestPaths::vgl_dijkstra of gpu_shortest_paths.hpp in its frontier / traversal variants: weights through global_edge_pos -- on vcsr both
+    the CSR and the vector-extension index space of EdgesArray_VectorCSR"""
+    text = run("sssp", "-s", "12", "-e", "16", "-type", "rmat", "-format", fmt, "-check", "-it", "2", *mode)
+    assert len(re.findall(r"error count: 0\b", text)) == 2, text[-3000:]
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind", ["rmat", "ru"])
+def test_reference_cc_app(kind, fmt):
+    text = run("cc", "-s", "12", "-e", "16", "-type", kind, "-format", fmt, "-check")                  # ConnectedComponents::vgl_shiloach_vishkin of gpu_shiloach_vishkin.hpp
     assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
