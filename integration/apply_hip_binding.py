@@ -13,9 +13,13 @@ context; the anchors below are the shortest strings that locate each edit):
   * MemoryAPI                       : hipMallocManaged / hipFree
   * VerticesArray / EdgesArray / container accessors : callable from device code
   * frontier containers             : friend class GraphAbstractionsHIP
-  * apps/Makefile                   : a hip stanza
+  * move_to_device / move_to_host   : the CUDA flavour's family exists (and does nothing: no prefetch hints on a pool without XNACK)
+  * algorithms/{pr,sssp,cc}         : the reference's GPU variants (gpu_pr.hpp, gpu_shortest_paths.hpp, gpu_shiloach_vishkin.hpp) compile for __USE_HIP__;
+                                      three CUDA runtime calls by name get a HIP branch
+  * graph_library.h                 : coloring.h and tc.h left out (host helpers called from device lambdas)
+(the hipcc command line is in oracle/Makefile, target `binding`)
 Every rule must apply (an anchor that is not found is an error): the script is also the test that the reference still has the shape the
-binding was written against.  tests/test_reference_binding.py applies it to a copy in /tmp and compiles apps/bfs/bfs.cpp with hipcc."""
+binding was written against.  tests/test_reference_binding.py applies it to a copy in /tmp and compiles seven of the reference's apps with hipcc."""
 import os
 import re
 import shutil
