@@ -2,7 +2,7 @@
 `make -C oracle binding` copies /root/reference to a scratch directory in /tmp, applies integration/apply_hip_binding.py (the edits of INTEGRATION.md
 section 2: -D __USE_HIP__ selects GraphAbstractionsHIP, a class derived from GraphAbstractions in vgl_compute_api/hip/graph_abstractions_hip.h that
 works on CSRGraph / VectorCSRGraph / FrontierCSR / FrontierVectorCSR through friend access) and compiles the reference's applications
-apps/{bfs,sswp,hits,scc,pr,sssp,cc}/*.cpp -- main() unchanged, algorithms unchanged but for three CUDA runtime calls by name in the GPU variants -- with hipcc for gfx950 against libvgl_hip.so.  Nothing of the reference
+apps/{bfs,sswp,hits,scc,pr,sssp,cc,mf}/*.cpp -- main() unchanged, algorithms unchanged but for three CUDA runtime calls by name in the GPU variants -- with hipcc for gfx950 against libvgl_hip.so.  Nothing of the reference
 enters the repository; the binaries go to oracle/_ref (git-ignored, they travel to the GPU box, where tests/test_reference_binding_gpu.py runs
 them with the reference's own -check)."""
 import os
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF) or not os.path.exists(HIPCC), reason="needs /root/reference and hipcc (CPU container)")
-APPS = ("bfs", "sswp", "hits", "scc", "pr", "sssp", "cc")
+APPS = ("bfs", "sswp", "hits", "scc", "pr", "sssp", "cc", "mf")
 
 
 @pytest.fixture(scope="module")

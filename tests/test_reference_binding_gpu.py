@@ -1,5 +1,5 @@
 """The reference's OWN applications on the reference's OWN containers, run on the MI355X through the bound-in HIP backend class
-(oracle/_ref/vgl_hip_{bfs,sswp,hits,scc,pr,sssp,cc}: apps/<app>/<app>.cpp of the reference, compiled in the CPU container by `make -C oracle binding` with
+(oracle/_ref/vgl_hip_{bfs,sswp,hits,scc,pr,sssp,cc,mf}: apps/<app>/<app>.cpp of the reference, compiled in the CPU container by `make -C oracle binding` with
 -D __USE_HIP__ after integration/apply_hip_binding.py; tests/test_reference_binding.py is the build half).  Each run uses the reference's own
 -check: its sequential implementation (BFS::seq_top_down, SSWP::seq_dijkstra, HITS::seq_hits, SCC::seq_tarjan) recomputes the result on the host
 from the same containers and verify_results / verify_ranking_results / equal_components compare.  pr, sssp and cc run the reference's own GPU
@@ -75,3 +75,12 @@ def test_reference_sssp_app(fmt, mode):
 def test_reference_cc_app(kind, fmt):
     text = run("cc", "-s", "12", "-e", "16", "-type", kind, "-format", fmt, "-check")                  # ConnectedComponents::vgl_shiloach_vishkin of gpu_shiloach_vishkin.hpp
     assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
+
+
+def test_reference_mf_app():
+    """MF::vgl_ford_fulkerson (algorithms/mf/mf.hpp) against MF::seq_ford_fulkerson on a small dense graph, CSR_GRAPH.  (Not on a sparse directed
+    graph: the reference divides by its iteration count, which is zero when the random sink cannot be reached.  Not on VECTOR_CSR_GRAPH: the
+    reference's own multicore build loops for ever there once a frontier turns dense -- the host-side flow updates go to the CSR copy of the
+    edge array and a dense collective advance reads the vector-extension copy; this backend reproduces that.)"""
+    text = run("mf", "-s", "6", "-e", "32", "-type", "ru", "-format", "csr", "-check", "-it", "3")
+    assert len(re.findall(r"Results are equal", text)) == 3, text[-3000:]
