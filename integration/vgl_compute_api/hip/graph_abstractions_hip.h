@@ -7,7 +7,7 @@
 // FrontierCSR / FrontierVectorCSR through friend access, exactly like GraphAbstractionsGPU / GraphAbstractionsMulticore.
 //
 //   kernels   : vectorgraphlibrary_amd/hip/vgl_hip_kernels.hpp (templated on the user's device lambdas; plain pointers only)
-//   library   : libvgl_hip.so through the C ABI include/vgl_hip.h -- graph handles BORROW the containers' vertex_pointers / adjacent_ids,
+//   library   : libvgl_hip.so through the C ABI include/vgl_hip.h -- graph handles work on DEVICE COPIES of the containers' vertex_pointers / adjacent_ids (+ the vector extension),
 //               frontier handles BORROW the containers' flags / ids (vgl_hip_frontier_create_on), so host code of the reference that reads or
 //               writes those arrays (add_vertex, print, the seq_* checkers) sees what the kernels see
 //   memory    : MemoryAPI::allocate_array is hipMallocManaged under __USE_HIP__ (the reference's own __USE_MANAGED_MEMORY__ scheme, settings.h:81)
@@ -97,8 +97,20 @@ private:
     hipStream_t stream;
     double *reduce_partials;                        // 1024 partials + the folded maximum
     unsigned long long *part_counters;              // managed: vgl_k_frontier_parts
-    struct graph_binding { vgl_hip_graph *handle; const void *vertex_pointers, *adjacent_ids; long long edges_count; };
-    std::map<void *, graph_binding> graph_handles;           // one per direction container (its vertex_pointers / adjacent_ids are borrowed)
+    // Per direction container: the library's graph handle and DEVICE copies of the arrays the kernels traverse.  The containers themselves stay in
+    // managed memory (host-resident on a pool without XNACK), where the reference's host code -- import, select_random_nz_vertex, the sequential
+    // checkers -- reads them at full speed; a container that was resized / re-imported (other arrays or another edge count behind the same object)
+    // gets new copies.
+    struct graph_binding {
+        vgl_hip_graph *handle = nullptr;
+        const void *vertex_pointers = nullptr, *adjacent_ids = nullptr;       // the container's arrays the copies were made from
+        long long edges_count = 0;
+        long long *d_vertex_pointers = nullptr;
+        int *d_adjacent_ids = nullptr;
+        long long *d_ve_group_ptrs = nullptr;                                   // VECTOR_CSR_GRAPH: the vector extension
+        int *d_ve_group_sizes = nullptr, *d_ve_adjacent_ids = nullptr;
+    };
+    std::map<void *, graph_binding> graph_handles;
     std::map<void *, vgl_hip_frontier *> frontier_handles;  // one per frontier container (its flags / ids are borrowed)
 
     static int grid_for(long long n) { return (int)std::min<long long>(4096, std::max<long long>(1, (n + VGL_BLOCK - 1) / VGL_BLOCK)); }
@@ -106,27 +118,55 @@ private:
     { return t == ALL_ACTIVE_FRONTIER ? VGL_HIP_FRONTIER_ALL_ACTIVE : (t == DENSE_FRONTIER ? VGL_HIP_FRONTIER_DENSE : VGL_HIP_FRONTIER_SPARSE); }
     void finish() { VGL_HIP_BIND_RT(hipGetLastError()); VGL_HIP_BIND_RT(hipStreamSynchronize(stream)); }
 
-    template <typename GraphContainer>
-    vgl_hip_graph *handle_of(GraphContainer &_graph)
+    template <typename T>
+    T *device_copy(const T *src, size_t n)
     {
-        // a container that was resized / re-imported since the handle was made (other arrays behind the same object) gets a new handle
+        T *d = nullptr;
+        VGL_HIP_BIND_RT(hipMalloc((void **)&d, sizeof(T) * std::max<size_t>(n, 1)));
+        if (n) VGL_HIP_BIND_RT(hipMemcpyAsync(d, src, sizeof(T) * n, hipMemcpyDefault, stream));
+        return d;
+    }
+    void release(graph_binding &b)
+    {
+        if (b.handle) vgl_hip_graph_destroy(ctx, b.handle);
+        hipFree(b.d_vertex_pointers); hipFree(b.d_adjacent_ids); hipFree(b.d_ve_group_ptrs); hipFree(b.d_ve_group_sizes); hipFree(b.d_ve_adjacent_ids);
+        b = graph_binding();
+    }
+    template <typename GraphContainer>
+    const graph_binding &binding_of(GraphContainer &_graph)
+    {
         auto it = graph_handles.find((void *)&_graph);
         if (it != graph_handles.end()) {
-            const graph_binding &b = it->second;
+            graph_binding &b = it->second;
             if (b.vertex_pointers == (const void *)_graph.get_vertex_pointers() && b.adjacent_ids == (const void *)_graph.get_adjacent_ids() &&
                 b.edges_count == (long long)_graph.get_edges_count())
-                return b.handle;
+                return b;
             for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);      // (they refer to the old handle)
             frontier_handles.clear();
-            vgl_hip_graph_destroy(ctx, b.handle);
+            release(b);
             graph_handles.erase(it);
         }
-        vgl_hip_graph *h = nullptr;
-        VGL_HIP_BIND_CALL(vgl_hip_graph_create(ctx, _graph.get_vertices_count(), 0, _graph.get_vertices_count(), (const int64_t *)_graph.get_vertex_pointers(),
-                                               _graph.get_adjacent_ids(), _graph.get_edges_count(), nullptr, nullptr, 0, &h));
-        graph_handles[(void *)&_graph] = graph_binding{h, (const void *)_graph.get_vertex_pointers(), (const void *)_graph.get_adjacent_ids(), (long long)_graph.get_edges_count()};
-        return h;
+        graph_binding b;
+        const size_t V = (size_t)_graph.get_vertices_count(), E = (size_t)_graph.get_edges_count();
+        b.vertex_pointers = (const void *)_graph.get_vertex_pointers(); b.adjacent_ids = (const void *)_graph.get_adjacent_ids(); b.edges_count = (long long)E;
+        b.d_vertex_pointers = device_copy(_graph.get_vertex_pointers(), V + 1);
+        b.d_adjacent_ids = device_copy(_graph.get_adjacent_ids(), E);
+        copy_vector_extension(_graph, b);
+        VGL_HIP_BIND_CALL(vgl_hip_graph_create(ctx, (int32_t)V, 0, (int32_t)V, (const int64_t *)b.d_vertex_pointers, b.d_adjacent_ids, (int64_t)E, nullptr, nullptr, 0, &b.handle));
+        return graph_handles[(void *)&_graph] = b;
     }
+    void copy_vector_extension(CSRGraph &, graph_binding &) {}
+    void copy_vector_extension(VectorCSRGraph &_graph, graph_binding &b)
+    {
+        VectorExtension *ve = _graph.get_ve_ptr();
+        const size_t segments = (size_t)ve->get_vector_segments_count();
+        b.d_ve_group_ptrs = device_copy(ve->get_vector_group_ptrs(), segments);
+        b.d_ve_group_sizes = device_copy(ve->get_vector_group_sizes(), segments);
+        b.d_ve_adjacent_ids = device_copy(ve->get_adjacent_ids(), (size_t)ve->get_edges_count_in_ve());
+    }
+    template <typename GraphContainer>
+    vgl_hip_graph *handle_of(GraphContainer &_graph) { return binding_of(_graph).handle; }
+
     // the frontier container may have been changed by host code since the last primitive (add_vertex, clear, set_all_active write its fields and
     // arrays directly): its description is taken as it stands before every use
     template <typename FrontierContainer>
@@ -169,10 +209,12 @@ private:
     {
         using E = typename std::decay<EdgeOp>::type;
         LOAD_FRONTIER_DATA(_frontier);
-        long long *vertex_pointers = _graph.get_vertex_pointers();
-        int *adjacent_ids = _graph.get_adjacent_ids();
+        const graph_binding &gb = binding_of(_graph);
+        const long long *host_vertex_pointers = _graph.get_vertex_pointers();      // (read on the host below: the container's own array)
+        const long long *vertex_pointers = gb.d_vertex_pointers;
+        const int *adjacent_ids = gb.d_adjacent_ids;
         const long long edges_count = _graph.get_edges_count();
-        vgl_hip_graph *gh = handle_of(_graph);
+        vgl_hip_graph *gh = gb.handle;
         if (_frontier.get_sparsity_type() == SPARSE_FRONTIER) {
             if (frontier_size == 0) return;
             vgl_hip_frontier *fh = handle_of(_frontier, gh);
@@ -187,8 +229,8 @@ private:
         const int32_t *tile_row; int64_t ntiles;
         VGL_HIP_BIND_CALL(vgl_hip_graph_tile_rows(gh, 0, &tile_row, &ntiles));
         // rows are stored in id order: the tiles past the last edge of row _row_hi - 1 hold nothing of the range
-        const long long last_edge = vertex_pointers[_row_hi];
-        const long long first_edge = vertex_pointers[_row_lo];
+        const long long last_edge = host_vertex_pointers[_row_hi];
+        const long long first_edge = host_vertex_pointers[_row_lo];
         if (last_edge <= first_edge) return;
         const unsigned tiles = (unsigned)std::min<long long>(ntiles, (last_edge + VGL_TILE - 1) / VGL_TILE);
         if (_frontier.get_sparsity_type() == DENSE_FRONTIER)
@@ -213,7 +255,7 @@ private:
     {
         LOAD_FRONTIER_DATA(_frontier);
         const int vertices_count = _graph.get_vertices_count();
-        vertex_pass(vertices_count, _graph.get_vertex_pointers(), _frontier.get_sparsity_type(), frontier_flags, frontier_ids, frontier_size, 0, vertices_count, compute_op);
+        vertex_pass(vertices_count, binding_of(_graph).d_vertex_pointers, _frontier.get_sparsity_type(), frontier_flags, frontier_ids, frontier_size, 0, vertices_count, compute_op);
         finish();
     }
 
@@ -232,7 +274,7 @@ private:
         if (_reduce_type != REDUCE_SUM && _reduce_type != REDUCE_MAX) throw "Error in GraphAbstractionsHIP::reduce_worker: unsupported reduce type";   // multicore/reduce.hpp:144-150
         using R = typename std::decay<ReduceOperation>::type;
         LOAD_FRONTIER_DATA(_frontier);
-        const long long *vertex_pointers = _graph.get_vertex_pointers();
+        const long long *vertex_pointers = binding_of(_graph).d_vertex_pointers;
         const FrontierSparsityType t = _frontier.get_sparsity_type();
         const int n = t == SPARSE_FRONTIER ? frontier_size : _graph.get_vertices_count();
         _result = 0;
@@ -367,7 +409,7 @@ GraphAbstractionsHIP::~GraphAbstractionsHIP()
 {
     hipStreamSynchronize(stream);
     for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);
-    for (auto &kv : graph_handles) vgl_hip_graph_destroy(ctx, kv.second.handle);
+    for (auto &kv : graph_handles) release(kv.second);
     hipFree(reduce_partials);
     hipFree(part_counters);
 }
@@ -390,7 +432,9 @@ void GraphAbstractionsHIP::advance_worker(CSRGraph &_graph, FrontierCSR &_fronti
 {
     Timer tm;
     tm.start();
-    LOAD_CSR_GRAPH_DATA(_graph);
+    const int vertices_count = _graph.get_vertices_count();
+    const long long edges_count = _graph.get_edges_count();
+    const long long *vertex_pointers = binding_of(_graph).d_vertex_pointers;       // the device copy (the kernels' view of the container)
     LOAD_FRONTIER_DATA(_frontier);
     const long long process_shift = compute_process_shift(current_traversal_direction, CSR_STORAGE);
     const FrontierSparsityType t = _frontier.get_sparsity_type();
@@ -417,7 +461,13 @@ void GraphAbstractionsHIP::advance_worker(VectorCSRGraph &_graph, FrontierVector
     using Q = typename std::decay<VertexPostprocessOperation>::type; using CQ = typename std::decay<CollectiveVertexPostprocessOperation>::type;
     Timer tm;
     tm.start();
-    LOAD_VECTOR_CSR_GRAPH_DATA(_graph);
+    const graph_binding &gb = binding_of(_graph);
+    const int vertices_count = _graph.get_vertices_count();
+    const long long edges_count = _graph.get_edges_count();
+    const long long *vertex_pointers = gb.d_vertex_pointers;                        // device copies: CSR part and vector extension
+    const long long *ve_vector_group_ptrs = gb.d_ve_group_ptrs;
+    const int *ve_vector_group_sizes = gb.d_ve_group_sizes, *ve_adjacent_ids = gb.d_ve_adjacent_ids;
+    const int ve_starting_vertex = _graph.get_ve_ptr()->get_starting_vertex(), ve_vector_segments_count = _graph.get_ve_ptr()->get_vector_segments_count();
     LOAD_FRONTIER_DATA(_frontier);
     const int collective_start = _graph.get_vector_core_threshold_vertex();       // [0, collective_start): vector engine + vector core ranges
     const long long csr_shift = compute_process_shift(current_traversal_direction, CSR_STORAGE);
@@ -472,7 +522,7 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(CSRGraph &_graph, Fronti
     vgl_hip_frontier *fh = handle_of(_frontier, gh);
     vgl_hip_gnf_buffers b;
     VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 0, &b));
-    const vgl_pred_user<C> pred{filter_cond, _graph.get_vertex_pointers()};
+    const vgl_pred_user<C> pred{filter_cond, binding_of(_graph).d_vertex_pointers};
     hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
                        (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
     VGL_HIP_BIND_RT(hipGetLastError());
@@ -501,14 +551,14 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
     vgl_hip_frontier *fh = handle_of(_frontier, gh);
     vgl_hip_gnf_buffers b;
     VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 0, &b));
-    const vgl_pred_user<C> pred{filter_cond, _graph.get_vertex_pointers()};
+    const vgl_pred_user<C> pred{filter_cond, binding_of(_graph).d_vertex_pointers};
     hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
                        (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
     VGL_HIP_BIND_RT(hipGetLastError());
     VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.7, 0, b.seq));
     VGL_HIP_BIND_RT(hipMemsetAsync(part_counters, 0, sizeof(unsigned long long) * 8, stream));
     hipLaunchKernelGGL(vgl_k_frontier_parts, dim3(grid_for(vertices_count)), dim3(VGL_BLOCK), 0, stream, vertices_count, (const int *)_frontier.flags,
-                       (const long long *)_graph.get_vertex_pointers(), _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
+                       (const long long *)binding_of(_graph).d_vertex_pointers, _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
     int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
     VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
     finish();

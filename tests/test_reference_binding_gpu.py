@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(app, *args):
+def run(app, *args, env=None):
     exe = os.path.join(ROOT, "oracle", "_ref", "vgl_hip_" + app)
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/vgl_hip_* are built where /root/reference exists (make -C oracle binding)")
-    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=env)
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-3000:]
     assert "rror in" not in text and "NOT equal" not in text, text[-3000:]
@@ -84,3 +84,17 @@ def test_reference_mf_app():
     edge array and a dense collective advance reads the vector-extension copy; this backend reproduces that.)"""
     text = run("mf", "-s", "6", "-e", "32", "-type", "ru", "-format", "csr", "-check", "-it", "3")
     assert len(re.findall(r"Results are equal", text)) == 3, text[-3000:]
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("app,args,checks", [("bfs", ["-s", "10", "-it", "3"], 3), ("pr", ["-s", "12", "-it", "5"], 1), ("sssp", ["-s", "10", "-it", "2"], 2),
+                                             ("cc", ["-s", "10"], 1), ("sswp", ["-s", "10", "-it", "1"], 1)])
+def test_reference_apps_with_device_resident_arrays(app, args, checks, fmt):
+    """VGL_HIP_DEVICE_ARRAYS=1: VerticesArray / EdgesArray / frontier flags and ids are hipMalloc memory (kernels at HBM rates: INTEGRATION 2.0); the
+    reference's host code -- initialisation, change_traversal_direction, the -check -- still dereferences them, through the PCIe BAR (slow loads, so a
+    small graph here)"""
+    env = dict(os.environ, VGL_HIP_DEVICE_ARRAYS="1")
+    # (pr at scale 12 like test_reference_pr_app: verify_ranking_results compares the MEAN ABSOLUTE difference of gpu_pr.hpp and seq_page_rank with 1e-4,
+    # which the two only meet once the ranks themselves are that small)
+    text = run(app, "-e", "16", "-type", "rmat", "-format", fmt, "-check", *args, env=env)
+    assert len(re.findall(r"error count: 0\b", text)) == checks, text[-3000:]
