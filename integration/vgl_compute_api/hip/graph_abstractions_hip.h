@@ -7,10 +7,13 @@
 // FrontierCSR / FrontierVectorCSR through friend access, exactly like GraphAbstractionsGPU / GraphAbstractionsMulticore.
 //
 //   kernels   : vectorgraphlibrary_amd/hip/vgl_hip_kernels.hpp (templated on the user's device lambdas; plain pointers only)
-//   library   : libvgl_hip.so through the C ABI include/vgl_hip.h -- graph handles work on DEVICE COPIES of the containers' vertex_pointers / adjacent_ids (+ the vector extension),
-//               frontier handles BORROW the containers' flags / ids (vgl_hip_frontier_create_on), so host code of the reference that reads or
-//               writes those arrays (add_vertex, print, the seq_* checkers) sees what the kernels see
-//   memory    : MemoryAPI::allocate_array is hipMallocManaged under __USE_HIP__ (the reference's own __USE_MANAGED_MEMORY__ scheme, settings.h:81)
+//   library   : libvgl_hip.so through the C ABI include/vgl_hip.h -- graph handles work on DEVICE COPIES of the containers' vertex_pointers / adjacent_ids
+//               (+ the vector extension), made when a container is first used; frontier handles BORROW the containers' flags / ids
+//               (vgl_hip_frontier_create_on), so host code of the reference that writes those arrays (add_vertex, set_all_active) needs no change
+//   memory    : the containers stay in managed memory (MemoryAPI::allocate_array = hipMallocManaged under __USE_HIP__: host-resident on a pool
+//               without XNACK, where the reference's host code wants them); user arrays and frontier flags / ids come from
+//               MemoryAPI::allocate_compute_array -- managed by default, hipMalloc with VGL_HIP_DEVICE_ARRAYS=1 (host code still reaches them, slowly,
+//               through the PCIe BAR)
 //
 // Containers served: CSR_GRAPH (advance_worker.hpp:62-149, generate_new_frontier.hpp:113-164) and VECTOR_CSR_GRAPH with its three degree
 // ranges and the padded vector extension (advance_worker.hpp:204-319, advance_{all_active,dense,sparse}.hpp, generate_new_frontier.hpp:29-111):
