@@ -99,7 +99,7 @@ private:
     vgl_hip_ctx *ctx;
     hipStream_t stream;
     double *reduce_partials;                        // 1024 partials + the folded maximum
-    unsigned long long *part_counters;              // managed: vgl_k_frontier_parts
+    unsigned long long *part_counters;              // device: vgl_k_frontier_parts (atomics on host-resident memory would cross PCIe one by one)
     // Per direction container: the library's graph handle and DEVICE copies of the arrays the kernels traverse.  The containers themselves stay in
     // managed memory (host-resident on a pool without XNACK), where the reference's host code -- import, select_random_nz_vertex, the sequential
     // checkers -- reads them at full speed; a container that was resized / re-imported (other arrays or another edge count behind the same object)
@@ -113,7 +113,10 @@ private:
         long long *d_ve_group_ptrs = nullptr;                                   // VECTOR_CSR_GRAPH: the vector extension
         int *d_ve_group_sizes = nullptr, *d_ve_adjacent_ids = nullptr;
     };
-    std::map<void *, graph_binding> graph_handles;
+    // The bindings outlive the backend object: the reference's algorithms construct a VGL_GRAPH_ABSTRACTIONS per call (bfs.hpp:58, gpu_pr.hpp:15),
+    // and copying a container's adjacency per call would cost more than the traversal (RMAT-20: 3.7 of 4.4 ms per BFS before this was a
+    // process-wide table).  Entries are replaced when the container's arrays change and released at process exit.
+    static std::map<void *, graph_binding> &graph_bindings() { static std::map<void *, graph_binding> table; return table; }
     std::map<void *, vgl_hip_frontier *> frontier_handles;  // one per frontier container (its flags / ids are borrowed)
 
     static int grid_for(long long n) { return (int)std::min<long long>(4096, std::max<long long>(1, (n + VGL_BLOCK - 1) / VGL_BLOCK)); }
@@ -138,6 +141,7 @@ private:
     template <typename GraphContainer>
     const graph_binding &binding_of(GraphContainer &_graph)
     {
+        std::map<void *, graph_binding> &graph_handles = graph_bindings();
         auto it = graph_handles.find((void *)&_graph);
         if (it != graph_handles.end()) {
             graph_binding &b = it->second;
@@ -405,14 +409,14 @@ GraphAbstractionsHIP::GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection
     ctx = vgl_hip_binding_context();
     stream = (hipStream_t)vgl_hip_ctx_stream(ctx);
     VGL_HIP_BIND_RT(hipMalloc((void **)&reduce_partials, sizeof(double) * (1024 + 8)));
-    VGL_HIP_BIND_RT(hipMallocManaged((void **)&part_counters, sizeof(unsigned long long) * 8));
+    VGL_HIP_BIND_RT(hipMalloc((void **)&part_counters, sizeof(unsigned long long) * 8));
 }
 
 GraphAbstractionsHIP::~GraphAbstractionsHIP()
 {
     hipStreamSynchronize(stream);
     for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);
-    for (auto &kv : graph_handles) release(kv.second);
+    // (the graph bindings stay: see graph_bindings())
     hipFree(reduce_partials);
     hipFree(part_counters);
 }
@@ -564,10 +568,12 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
                        (const long long *)binding_of(_graph).d_vertex_pointers, _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
     int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
     VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
+    unsigned long long parts[6];
+    VGL_HIP_BIND_RT(hipMemcpyAsync(parts, part_counters, sizeof(parts), hipMemcpyDeviceToHost, stream));
     finish();
-    _frontier.vector_engine_part_size = (int)part_counters[0]; _frontier.vector_engine_part_neighbours_count = (long long)part_counters[3];
-    _frontier.vector_core_part_size = (int)part_counters[1]; _frontier.vector_core_part_neighbours_count = (long long)part_counters[4];
-    _frontier.collective_part_size = (int)part_counters[2]; _frontier.collective_part_neighbours_count = (long long)part_counters[5];
+    _frontier.vector_engine_part_size = (int)parts[0]; _frontier.vector_engine_part_neighbours_count = (long long)parts[3];
+    _frontier.vector_core_part_size = (int)parts[1]; _frontier.vector_core_part_neighbours_count = (long long)parts[4];
+    _frontier.collective_part_size = (int)parts[2]; _frontier.collective_part_neighbours_count = (long long)parts[5];
     _frontier.size = size;
     _frontier.neighbours_count = neighbours;
     if (sparsity == VGL_HIP_FRONTIER_ALL_ACTIVE) _frontier.sparsity_type = ALL_ACTIVE_FRONTIER;
