@@ -67,9 +67,18 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_frontier_parts(int vertices_c
             const int part = v < ve_threshold ? 0 : (v < vc_threshold ? 1 : 2);
             n[part] += 1; d[part] += (unsigned long long)(vertex_pointers[v + 1] - vertex_pointers[v]);
         }
+    // one atomic per counter and WORKGROUP: the six counters are single addresses, and one atomic per wavefront (98 000 of them for 2^20 vertices)
+    // queued behind each other for 131 us -- two thirds of a VectorCSR traversal of RMAT-20
+    __shared__ unsigned long long s_part[VGL_BLOCK / 64][6];
     for (int p = 0; p < 3; p++) {
         for (int o = 32; o > 0; o >>= 1) { n[p] += __shfl_xor(n[p], o); d[p] += __shfl_xor(d[p], o); }
-        if ((threadIdx.x & 63) == 0 && (n[p] | d[p])) { atomicAdd(&out[p], n[p]); atomicAdd(&out[3 + p], d[p]); }
+        if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][p] = n[p]; s_part[threadIdx.x >> 6][3 + p] = d[p]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned long long t = 0;
+        for (int w = 0; w < VGL_BLOCK / 64; w++) t += s_part[w][threadIdx.x];
+        if (t) atomicAdd(&out[threadIdx.x], t);
     }
 }
 // SPARSE frontier of a VECTOR_CSR_GRAPH: ids below the vector-core threshold take (edge_op, pre, post), the others the collective set; ids are
@@ -564,7 +573,7 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
     VGL_HIP_BIND_RT(hipGetLastError());
     VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.7, 0, b.seq));
     VGL_HIP_BIND_RT(hipMemsetAsync(part_counters, 0, sizeof(unsigned long long) * 8, stream));
-    hipLaunchKernelGGL(vgl_k_frontier_parts, dim3(grid_for(vertices_count)), dim3(VGL_BLOCK), 0, stream, vertices_count, (const int *)_frontier.flags,
+    hipLaunchKernelGGL(vgl_k_frontier_parts, dim3(std::min(grid_for(vertices_count), 512)), dim3(VGL_BLOCK), 0, stream, vertices_count, (const int *)_frontier.flags,
                        (const long long *)binding_of(_graph).d_vertex_pointers, _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
     int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
     VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
