@@ -124,9 +124,20 @@ private:
     };
     // The bindings outlive the backend object: the reference's algorithms construct a VGL_GRAPH_ABSTRACTIONS per call (bfs.hpp:58, gpu_pr.hpp:15),
     // and copying a container's adjacency per call would cost more than the traversal (RMAT-20: 3.7 of 4.4 ms per BFS before this was a
-    // process-wide table).  Entries are replaced when the container's arrays change and released at process exit.
+    // process-wide table).  Entries are replaced when the container's arrays change (other pointers or another edge count behind the same object)
+    // and released at process exit; host code that REWRITES a container's adjacency in place after the first primitive -- nothing in the reference
+    // does -- calls forget_graph_bindings().
     static std::map<void *, graph_binding> &graph_bindings() { static std::map<void *, graph_binding> table; return table; }
+    // every release of a binding starts a new generation: frontier handles of ANY backend object that were made before it refer to a graph handle
+    // that may be gone and are dropped (unread) at their next use
+    static unsigned long long &bindings_generation() { static unsigned long long generation = 0; return generation; }
+    unsigned long long frontier_generation = 0;
     std::map<void *, vgl_hip_frontier *> frontier_handles;  // one per frontier container (its flags / ids are borrowed)
+    void drop_frontier_handles()
+    {
+        for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);
+        frontier_handles.clear();
+    }
 
     static int grid_for(long long n) { return (int)std::min<long long>(4096, std::max<long long>(1, (n + VGL_BLOCK - 1) / VGL_BLOCK)); }
     static int sparsity_code(FrontierSparsityType t)
@@ -157,10 +168,10 @@ private:
             if (b.vertex_pointers == (const void *)_graph.get_vertex_pointers() && b.adjacent_ids == (const void *)_graph.get_adjacent_ids() &&
                 b.edges_count == (long long)_graph.get_edges_count())
                 return b;
-            for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);      // (they refer to the old handle)
-            frontier_handles.clear();
+            drop_frontier_handles();                                                         // (they refer to the old handle)
             release(b);
             graph_handles.erase(it);
+            frontier_generation = ++bindings_generation();
         }
         graph_binding b;
         const size_t V = (size_t)_graph.get_vertices_count(), E = (size_t)_graph.get_edges_count();
@@ -189,6 +200,7 @@ private:
     vgl_hip_frontier *handle_of(FrontierContainer &_frontier, vgl_hip_graph *_graph_handle)
     {
         vgl_hip_frontier *h = nullptr;
+        if (frontier_generation != bindings_generation()) { drop_frontier_handles(); frontier_generation = bindings_generation(); }
         auto it = frontier_handles.find((void *)&_frontier);
         if (it != frontier_handles.end() && vgl_hip_frontier_flags(it->second) != _frontier.flags) {     // another frontier object at a recycled address
             vgl_hip_frontier_destroy(ctx, it->second);
@@ -344,6 +356,16 @@ public:
     // attaches graph-processing API to the specific graph
     GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection _initial_traversal = SCATTER);
     ~GraphAbstractionsHIP();
+    // the device copies of every container's adjacency are dropped (the next primitive copies again): for host code that rewrote a container's
+    // vertex_pointers / adjacent_ids IN PLACE after a primitive had used it
+    void forget_graph_bindings()
+    {
+        hipStreamSynchronize(stream);
+        drop_frontier_handles();
+        for (auto &kv : graph_bindings()) release(kv.second);
+        graph_bindings().clear();
+        frontier_generation = ++bindings_generation();
+    }
 
     // generate new frontier implementation (public: it instantiates kernels on device lambdas, as in graph_abstractions_gpu.h:110-131)
     template <typename FilterCondition>
@@ -419,12 +441,13 @@ GraphAbstractionsHIP::GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection
     stream = (hipStream_t)vgl_hip_ctx_stream(ctx);
     VGL_HIP_BIND_RT(hipMalloc((void **)&reduce_partials, sizeof(double) * (1024 + 8)));
     VGL_HIP_BIND_RT(hipMalloc((void **)&part_counters, sizeof(unsigned long long) * 8));
+    frontier_generation = bindings_generation();
 }
 
 GraphAbstractionsHIP::~GraphAbstractionsHIP()
 {
     hipStreamSynchronize(stream);
-    for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);
+    drop_frontier_handles();
     // (the graph bindings stay: see graph_bindings())
     hipFree(reduce_partials);
     hipFree(part_counters);

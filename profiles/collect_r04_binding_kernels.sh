@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel trace of the REFERENCE'S OWN apps with the HIP backend bound in (which kernels run, how long): rocprofv3 runs the app binary directly.
-# usage: bash profiles/collect_r04_binding_kernels.sh  (writes gpurun_out/bindprof_<app>_<format>_kernel_stats.csv)
+# usage: bash profiles/collect_r04_binding_kernels.sh [vcsr]  (writes gpurun_out/bindprof_<app>_<format>_kernel_stats.csv)
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp VGL_HIP_DEVICE_ARRAYS=1
 one() { # <tag> <app> <args...>
@@ -12,6 +12,7 @@ one() { # <tag> <app> <args...>
   grep AVG_PERF gpurun_out/bindprof_$tag.log
   rm -rf gpurun_out/bindprof_$tag
 }
+if [ "$1" = "vcsr" ]; then one bfs_vcsr bfs -s 20 -e 32 -type rmat -format vcsr -it 8; exit 0; fi
 one bfs_csr bfs -s 20 -e 32 -type rmat -format csr -it 8
 one bfs_vcsr bfs -s 20 -e 32 -type rmat -format vcsr -it 8
 one sssp_csr sssp -s 20 -e 32 -type rmat -format csr -it 4
