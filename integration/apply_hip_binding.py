@@ -12,7 +12,7 @@ context; the anchors below are the shortest strings that locate each edit):
   * common/graph_abstractions.h     : include the backend header
   * MemoryAPI                       : hipMallocManaged / hipFree
   * VerticesArray / EdgesArray / container accessors : callable from device code
-  * frontier containers             : friend class GraphAbstractionsHIP
+  * frontier containers             : friend class GraphAbstractionsHIP; the plan stamp (hip_plan_token) and its reset in every mutator
   * move_to_device / move_to_host   : the CUDA flavour's family exists (and does nothing: no prefetch hints on a pool without XNACK)
   * algorithms/{pr,sssp,cc}         : the reference's GPU variants (gpu_pr.hpp, gpu_shortest_paths.hpp, gpu_shiloach_vishkin.hpp) compile for __USE_HIP__;
                                       three CUDA runtime calls by name get a HIP branch
@@ -108,6 +108,16 @@ RULES = [
      "defined(__USE_NEC_SX_AURORA__) || defined(__USE_MULTICORE__) || defined(__USE_HIP__)", 2),
     ("vgl_datastructures/graphs/undirected_containers/vect_csr/reorder.hpp", "sub", r"defined\(__USE_NEC_SX_AURORA__\) \|\| defined\(__USE_MULTICORE__\)$",
      "defined(__USE_NEC_SX_AURORA__) || defined(__USE_MULTICORE__) || defined(__USE_HIP__)", 2),
+    # ---- a stamp on the frontier containers: generate_new_frontier of the HIP backend leaves the advance plan of a sparse frontier behind and marks
+    #      the container; every mutator of the container voids the mark ("plan stamp") ----
+    ("vgl_datastructures/frontier/containers/base_frontier.h", "after", r"^\s*FrontierSparsityType sparsity_type;$",
+     "    #ifdef __USE_HIP__\n    unsigned long long hip_plan_token = 0;   // non-zero: ids / flags are as GraphAbstractionsHIP::generate_new_frontier left them\n    #endif\n"),
+    ("vgl_datastructures/frontier/containers/csr/modification.hpp", "sub", r"^(void FrontierCSR::(?:set_all_active|add_vertex|clear)\([^)]*\)\n\{\n)",
+     r"\1    #ifdef __USE_HIP__\n    hip_plan_token = 0;\n    #endif\n", 3),
+    ("vgl_datastructures/frontier/containers/vect_csr/modification.hpp", "sub", r"^(void FrontierVectorCSR::(?:set_all_active|add_vertex|add_group_of_vertices)\([^)]*\)\n\{\n)",
+     r"\1    #ifdef __USE_HIP__\n    hip_plan_token = 0;\n    #endif\n", 3),
+    ("vgl_datastructures/frontier/containers/vect_csr/frontier_vect_csr.h", "sub", r"^(\s*void clear\(\) \{)(sparsity_type = SPARSE_FRONTIER;)",
+     r"\1\n    #ifdef __USE_HIP__\n    hip_plan_token = 0;\n    #endif\n    \2", 1),
     # ---- the backend writes the frontier containers, like the other backends ----
     ("vgl_datastructures/frontier/containers/csr/frontier_csr.h", "after", r"friend class GraphAbstractionsGPU;", "    friend class GraphAbstractionsHIP;\n"),
     ("vgl_datastructures/frontier/containers/vect_csr/frontier_vect_csr.h", "after", r"friend class GraphAbstractionsGPU;", "    friend class GraphAbstractionsHIP;\n"),

@@ -132,13 +132,18 @@ private:
     // that may be gone and are dropped (unread) at their next use
     static unsigned long long &bindings_generation() { static unsigned long long generation = 0; return generation; }
     unsigned long long frontier_generation = 0;
-    std::map<void *, vgl_hip_frontier *> frontier_handles;  // one per frontier container (its flags / ids are borrowed)
+    // one per frontier container (its flags / ids are borrowed).  plan_token / planned_on: generate_new_frontier left the advance plan of the SPARSE
+    // frontier behind (the ids' edge offsets, a by-product of the compaction) and stamped the container (BaseFrontier::hip_plan_token); the container's
+    // mutators -- set_all_active, add_vertex, clear -- zero the stamp, so an equal non-zero stamp says that nothing touched the frontier since and
+    // scatter / gather on the same direction container start from the plan instead of three more launches and a host wait per level
+    struct frontier_binding { vgl_hip_frontier *handle = nullptr; unsigned long long plan_token = 0; vgl_hip_graph *planned_on = nullptr; int planned_size = 0; };
+    std::map<void *, frontier_binding> frontier_handles;
+    static unsigned long long next_plan_token() { static unsigned long long token = 0; return ++token; }
     void drop_frontier_handles()
     {
-        for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second);
+        for (auto &kv : frontier_handles) vgl_hip_frontier_destroy(ctx, kv.second.handle);
         frontier_handles.clear();
     }
-
     static int grid_for(long long n) { return (int)std::min<long long>(4096, std::max<long long>(1, (n + VGL_BLOCK - 1) / VGL_BLOCK)); }
     static int sparsity_code(FrontierSparsityType t)
     { return t == ALL_ACTIVE_FRONTIER ? VGL_HIP_FRONTIER_ALL_ACTIVE : (t == DENSE_FRONTIER ? VGL_HIP_FRONTIER_DENSE : VGL_HIP_FRONTIER_SPARSE); }
@@ -202,18 +207,34 @@ private:
         vgl_hip_frontier *h = nullptr;
         if (frontier_generation != bindings_generation()) { drop_frontier_handles(); frontier_generation = bindings_generation(); }
         auto it = frontier_handles.find((void *)&_frontier);
-        if (it != frontier_handles.end() && vgl_hip_frontier_flags(it->second) != _frontier.flags) {     // another frontier object at a recycled address
-            vgl_hip_frontier_destroy(ctx, it->second);
+        if (it != frontier_handles.end() && vgl_hip_frontier_flags(it->second.handle) != _frontier.flags) {     // another frontier object at a recycled address
+            vgl_hip_frontier_destroy(ctx, it->second.handle);
             frontier_handles.erase(it);
             it = frontier_handles.end();
         }
-        if (it != frontier_handles.end()) h = it->second;
-        else {
+        if (it != frontier_handles.end()) {
+            frontier_binding &fb = it->second;
+            if (fb.plan_token != 0 && fb.plan_token == _frontier.hip_plan_token && fb.planned_on == _graph_handle && fb.planned_size == _frontier.size &&
+                _frontier.sparsity_type == SPARSE_FRONTIER)
+                return fb.handle;                                                   // as generated: description and plan stand
+            fb.plan_token = 0;
+            h = fb.handle;
+        } else {
             VGL_HIP_BIND_CALL(vgl_hip_frontier_create_on(ctx, _graph_handle, _frontier.flags, _frontier.ids, &h));
-            frontier_handles[(void *)&_frontier] = h;
+            frontier_handles[(void *)&_frontier].handle = h;
         }
         VGL_HIP_BIND_CALL(vgl_hip_frontier_set_state(ctx, h, _graph_handle, _frontier.size, _frontier.neighbours_count, sparsity_code(_frontier.sparsity_type)));
         return h;
+    }
+    // generate_new_frontier produced _frontier on _graph_handle: a SPARSE one carries its advance plan from here on
+    template <typename FrontierContainer>
+    void stamp_generated(FrontierContainer &_frontier, vgl_hip_graph *_graph_handle, int _sparsity)
+    {
+        frontier_binding &fb = frontier_handles[(void *)&_frontier];
+        fb.plan_token = _sparsity == VGL_HIP_FRONTIER_SPARSE ? next_plan_token() : 0;
+        fb.planned_on = _graph_handle;
+        fb.planned_size = _frontier.size;
+        _frontier.hip_plan_token = fb.plan_token;
     }
 
     // per-vertex operator over the active vertices of a range of ids
@@ -560,18 +581,19 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(CSRGraph &_graph, Fronti
     vgl_hip_graph *gh = handle_of(_graph);
     vgl_hip_frontier *fh = handle_of(_frontier, gh);
     vgl_hip_gnf_buffers b;
-    VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 0, &b));
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 1, &b));
     const vgl_pred_user<C> pred{filter_cond, binding_of(_graph).d_vertex_pointers};
     hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
                        (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
     VGL_HIP_BIND_RT(hipGetLastError());
-    VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.0, 0, b.seq));
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.0, 1, b.seq));
     int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
     VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
     finish();
     _frontier.size = size;
     _frontier.neighbours_count = neighbours;
     _frontier.sparsity_type = sparsity == VGL_HIP_FRONTIER_ALL_ACTIVE ? ALL_ACTIVE_FRONTIER : SPARSE_FRONTIER;
+    stamp_generated(_frontier, gh, sparsity);
     tm.end();
     performance_stats.update_gnf_time(tm);
     performance_stats.update_bytes_requested((long long)vertices_count * 4.0 * sizeof(int));
@@ -589,12 +611,12 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
     vgl_hip_graph *gh = handle_of(_graph);
     vgl_hip_frontier *fh = handle_of(_frontier, gh);
     vgl_hip_gnf_buffers b;
-    VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 0, &b));
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 1, &b));
     const vgl_pred_user<C> pred{filter_cond, binding_of(_graph).d_vertex_pointers};
     hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
                        (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
     VGL_HIP_BIND_RT(hipGetLastError());
-    VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.7, 0, b.seq));
+    VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.7, 1, b.seq));
     VGL_HIP_BIND_RT(hipMemsetAsync(part_counters, 0, sizeof(unsigned long long) * 8, stream));
     hipLaunchKernelGGL(vgl_k_frontier_parts, dim3(std::min(grid_for(vertices_count), 512)), dim3(VGL_BLOCK), 0, stream, vertices_count, (const int *)_frontier.flags,
                        (const long long *)binding_of(_graph).d_vertex_pointers, _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
@@ -613,6 +635,7 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
         const FrontierSparsityType t = sparsity == VGL_HIP_FRONTIER_DENSE ? DENSE_FRONTIER : SPARSE_FRONTIER;
         _frontier.sparsity_type = t; _frontier.vector_engine_part_type = t; _frontier.vector_core_part_type = t; _frontier.collective_part_type = t;
     }
+    stamp_generated(_frontier, gh, sparsity);
     tm.end();
     performance_stats.update_gnf_time(tm);
     performance_stats.update_bytes_requested((long long)vertices_count * 2.0 * sizeof(int));

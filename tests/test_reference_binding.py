@@ -28,7 +28,7 @@ def built():
 
 
 def test_the_reference_apps_compile_with_the_backend_bound_in(built):
-    for app in APPS:
+    for app in APPS + ("plan_stamp_check",):            # (the last one: integration/tests/plan_stamp_check.cpp, our own program against the patched tree)
         assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "vgl_hip_" + app)), app
 
 

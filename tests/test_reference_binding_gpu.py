@@ -98,3 +98,17 @@ def test_reference_apps_with_device_resident_arrays(app, args, checks, fmt):
     # which the two only meet once the ranks themselves are that small)
     text = run(app, "-e", "16", "-type", "rmat", "-format", fmt, "-check", *args, env=env)
     assert len(re.findall(r"error count: 0\b", text)) == checks, text[-3000:]
+
+
+@pytest.mark.parametrize("device_arrays", ["0", "1"])
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 12, 16), ("ru", 10, 4)])
+def test_host_rewrites_of_a_generated_frontier_void_its_advance_plan(kind, scale, edges, fmt, device_arrays):
+    """integration/tests/plan_stamp_check.cpp (our program against the patched tree): generate_new_frontier leaves the advance plan of a sparse
+    frontier behind and stamps the container; clear / add_vertex / add_group_of_vertices / set_all_active void the stamp.  A scatter on a frontier
+    that was generated and then rewritten by host code -- same size, other degrees -- must reach what it reaches on a frontier the backend never
+    generated."""
+    env = dict(os.environ, VGL_HIP_DEVICE_ARRAYS=device_arrays)
+    text = run("plan_stamp_check", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, env=env)
+    assert "PLAN STAMP CHECK PASSED" in text, text[-3000:]
+    assert len(re.findall(r", 0 differences", text)) == 4, text[-3000:]
