@@ -13,4 +13,7 @@ run 1 bfs -s $S -e 32 -type rmat -format vcsr -it 8
 run 1 pr -s $S -e 32 -type ru -format csr -it 5
 run 1 sssp -s $S -e 32 -type rmat -format csr -it 4
 run 1 cc -s $S -e 16 -type rmat -format vcsr
+run 1 hits -s $S -e 32 -type rmat -format csr -it 3
+run 1 sswp -s $S -e 32 -type rmat -format csr -it 3
+if [ -n "${BIG:-}" ]; then run 1 bfs -s $BIG -e 32 -type rmat -format csr -it 8; fi
 cat "$OUT"
