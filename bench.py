@@ -145,7 +145,6 @@ def peer_comm_or_none(ctx, vs, dist, rank, world):
     The ranks decide together (a MIN over torch.distributed), so that all of them end up on the same transport."""
     import torch
     import uuid
-    from vectorgraphlibrary_amd.lib import VglHipError
     box = ["/vgl_bench_%s" % uuid.uuid4().hex[:12] if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     old = os.environ.get("VGL_PEER_TIMEOUT_MS")
@@ -190,7 +189,7 @@ def peer_comm_or_none(ctx, vs, dist, rank, world):
         comm.exchange_changed(before, got, take_min=True)
         ok &= int(torch.equal(got, torch.stack(copies).min(0).values))
         comm.barrier()                                   # (reads the error word of the window: a spin that ran out fails here)
-    except VglHipError:
+    except Exception:                                    # noqa: BLE001  (VglHipError, or anything else: this rank must still reach the vote below)
         ok = 0
     finally:
         if old is None:
