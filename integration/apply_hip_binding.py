@@ -10,10 +10,11 @@ context; the anchors below are the shortest strings that locate each edit):
   * settings.h                      : VECTOR_LENGTH = 64 (one wavefront), thresholds
   * common dispatch (advance.hpp, compute.hpp) : call the workers directly, not inside an OpenMP parallel region
   * common/graph_abstractions.h     : include the backend header
-  * MemoryAPI                       : hipMallocManaged / hipFree
-  * VerticesArray / EdgesArray / container accessors : callable from device code
+  * MemoryAPI                       : hipMallocManaged / hipFree for containers; user arrays are SHADOWED (pinned host mirror + HBM buffer + owner flag,
+                                      vgl_compute_api/hip/shadow_memory.h); frontier flags / ids in device memory
+  * VerticesArray / EdgesArray      : device code indexes the HBM buffer, host code the mirror (fetched back on demand)
   * frontier containers             : friend class GraphAbstractionsHIP; the plan stamp (hip_plan_token) and its reset in every mutator
-  * move_to_device / move_to_host   : the CUDA flavour's family exists (and does nothing: no prefetch hints on a pool without XNACK)
+  * move_to_device / move_to_host   : the CUDA flavour's family exists; on user arrays they are real copies mirror <-> HBM
   * algorithms/{pr,sssp,cc}         : the reference's GPU variants (gpu_pr.hpp, gpu_shortest_paths.hpp, gpu_shiloach_vishkin.hpp) compile for __USE_HIP__;
                                       three CUDA runtime calls by name get a HIP branch
   * graph_library.h                 : coloring.h and tc.h left out (host helpers called from device lambdas)
@@ -56,15 +57,18 @@ RULES = [
      "        #elif defined(__USE_HIP__)\n        hipFree((void*)_ptr);\n", 2, 1),
     ("vgl_runtime/helpers/memory_API/memory_API.h", "before", r"^class MemoryAPI", "#ifdef __USE_HIP__\n#include <hip/hip_runtime.h>\n#endif\n\n"),
     # ---- move_to_device / move_to_host of every container and user array: the CUDA flavour's declarations, definitions and call sites
-    #      (algorithms/bfs/bfs.hpp:70-74, hits/hits.hpp:12-17, the gpu_*.hpp variants) exist under __USE_HIP__ too; they do NOTHING there: the
-    #      managed pages of a pool without XNACK migrate back on every host touch, and the prefetch hints made the bfs app slower ----
+    #      (algorithms/bfs/bfs.hpp:70-74, hits/hits.hpp:12-17, the gpu_*.hpp variants) exist under __USE_HIP__ too: for a user array they copy the
+    #      pinned host mirror into its HBM buffer / back (shadow_memory.h), for managed graph containers and device-only frontier arrays they do nothing ----
     ("*", "sub_tree", r"#ifdef __USE_GPU__(?=\n(?:\s*template <typename _T>\n)?[^\n]*move_(?:array_)?to_(?:device|host))", GPU_OR_HIP, 43,
      ("vgl_runtime/helpers/memory_API/memory_API.hpp",)),
     ("vgl_runtime/helpers/memory_API/memory_API.hpp", "after", r"\A",
-     "// HIP flavour: the prefetch hints of the CUDA flavour are accepted and ignored (see integration/apply_hip_binding.py)\n"
+     "// HIP flavour: move_array_to_device / _to_host are the ownership transitions of a shadowed user array (vgl_compute_api/hip/shadow_memory.h) made early;\n"
+     "// for anything else (graph containers in managed memory, frontier arrays in device memory) they are accepted and do nothing\n"
      "#ifdef __USE_HIP__\n"
-     "template <typename _T>\nvoid MemoryAPI::move_array_to_device(_T *_ptr, size_t _size) {}\n\n"
-     "template <typename _T>\nvoid MemoryAPI::move_array_to_host(_T *_ptr, size_t _size) {}\n#endif\n\n"),
+     "template <typename _T>\nvoid MemoryAPI::move_array_to_device(_T *_ptr, size_t _size)\n{\n    if(HipShadow *s = hip_shadow_of(_ptr)) hip_shadow_acquire_device(s, 0);\n}\n\n"
+     "template <typename _T>\nvoid MemoryAPI::move_array_to_host(_T *_ptr, size_t _size)\n{\n    if(HipShadow *s = hip_shadow_of(_ptr)) hip_shadow_host_access(s);\n}\n\n"
+     "template <typename _T>\nvoid MemoryAPI::allocate_device_array(_T **_ptr, size_t _size)\n{\n"
+     "    if(hipMalloc((void**)_ptr, (_size > 0 ? _size : 1) * sizeof(_T)) != hipSuccess) throw \"Error in MemoryAPI::allocate_device_array : hipMalloc failed\";\n}\n#endif\n\n"),
     # ---- the reference's own GPU variants of PageRank, SSSP and Shiloach-Vishkin (operators written for device lambdas; three CUDA runtime
     #      calls by name get a HIP branch) ----
     ("algorithms/pr/pr.h", "sub", r"^(\s*)#ifdef __USE_GPU__$", r"\1" + GPU_OR_HIP, 1),
@@ -75,31 +79,86 @@ RULES = [
     ("algorithms/cc/gpu_shiloach_vishkin.hpp", "sub", r"^#ifdef __USE_GPU__$", GPU_OR_HIP, 1),
     ("algorithms/sssp/gpu_shortest_paths.hpp", "sub", r"\bGraphAbstractionsGPU\b", "VGL_GRAPH_ABSTRACTIONS", 3),      # (the file names the CUDA class instead of the macro)
     ("algorithms/sssp/gpu_shortest_paths.hpp", "sub", r"^(\s*)cudaMemset\((.*)\);$",
-     r"\1#ifdef __USE_HIP__\n\1(void)hipMemset(\2);\n\1#else\n\1cudaMemset(\2);\n\1#endif", 1),
+     r"\1#ifdef __USE_HIP__\n\1(void)hipMemset(was_updated.get_device_ptr(), 0, sizeof(char) * _graph.get_vertices_count());\n\1#else\n\1cudaMemset(\2);\n\1#endif", 1),
     ("algorithms/cc/gpu_shiloach_vishkin.hpp", "sub", r"^(\s*)cudaMallocManaged\((.*)\);$",
      r"\1#ifdef __USE_HIP__\n\1(void)hipMallocManaged(\2);\n\1#else\n\1cudaMallocManaged(\2);\n\1#endif", 2),
-    # ---- where the arrays live.  Graph containers stay in managed (on this pool: host-resident) memory, which their host-side import and the
-    #      sequential checkers read at full speed; the backend class keeps device copies of the adjacency it traverses.  The arrays that device
-    #      lambdas gather from and scatter to -- VerticesArray, EdgesArray, frontier flags / ids -- go through MemoryAPI::allocate_compute_array:
-    #      managed memory by default, DEVICE memory (hipMalloc) with VGL_HIP_DEVICE_ARRAYS=1.  Host code still dereferences device memory through
-    #      the PCIe BAR -- stores at ~10 GB/s, loads at 150 ns each -- so everything keeps working, but whatever reads those arrays on the host
-    #      (the -check paths, change_traversal_direction's permutations) crawls: the switch is for runs that measure the kernels ----
+    # ---- where the arrays live (vgl_compute_api/hip/shadow_memory.h).  Graph containers and one-word flags stay in managed (on this pool: host-resident)
+    #      memory, which their host-side import and the sequential checkers read at full speed; the backend class keeps device copies of the adjacency
+    #      it traverses.  VerticesArray / EdgesArray get a pinned host mirror AND a buffer in HBM with an owner flag: device lambdas index the HBM
+    #      buffer, host code the mirror, a host accessor fetches the array back when kernels ran since, every primitive uploads what the host wrote
+    #      since; move_to_device() / move_to_host() are those transitions made early.  Frontier flags / ids are device memory only ----
+    ("vgl_runtime/helpers/memory_API/memory_API.h", "before", r"^class MemoryAPI",
+     "#ifdef __USE_HIP__\n#include \"vgl_compute_api/hip/shadow_memory.h\"\n#define VGL_HOST_ACCESS(obj) hip_shadow_host_access((obj)->shadow)\n#else\n#define VGL_HOST_ACCESS(obj)\n#endif\n\n"),
     ("vgl_runtime/helpers/memory_API/memory_API.h", "after", r"static void resize\(_T \*\*_ptr, size_t _new_size\);",
-     "\n    // arrays that compute kernels gather from and scatter to (VerticesArray, EdgesArray, frontier flags / ids)\n"
-     "    template <typename _T>\n    static void allocate_compute_array(_T **_ptr, size_t _size);\n"),
-    ("vgl_runtime/helpers/memory_API/memory_API.hpp", "after", r"\A",
-     "template <typename _T>\nvoid MemoryAPI::allocate_compute_array(_T **_ptr, size_t _size)\n{\n"
-     "    #ifdef __USE_HIP__\n    static const bool on_device = getenv(\"VGL_HIP_DEVICE_ARRAYS\") != NULL && getenv(\"VGL_HIP_DEVICE_ARRAYS\")[0] == '1';\n"
-     "    if(!on_device) { MemoryAPI::allocate_array(_ptr, _size); return; }\n"
-     "    if(hipMalloc((void**)_ptr, (_size > 0 ? _size : 1) * sizeof(_T)) != hipSuccess) throw \"Error in MemoryAPI::allocate_compute_array : hipMalloc failed\";\n"
-     "    #else\n    MemoryAPI::allocate_array(_ptr, _size);\n    #endif\n}\n\n"),
-    ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"MemoryAPI::allocate_array\(&this->vertices_data,", "MemoryAPI::allocate_compute_array(&this->vertices_data,", 1),
-    ("vgl_datastructures/edges_array/edges_array.hpp", "sub", r"MemoryAPI::allocate_array\(&edges_data,", "MemoryAPI::allocate_compute_array(&edges_data,", 1),
-    ("vgl_datastructures/frontier/containers/csr/frontier_csr.hpp", "sub", r"MemoryAPI::allocate_array\(&(flags|ids),", r"MemoryAPI::allocate_compute_array(&\1,", 2),
-    ("vgl_datastructures/frontier/containers/vect_csr/frontier_vect_csr.hpp", "sub", r"MemoryAPI::allocate_array\(&(flags|ids),", r"MemoryAPI::allocate_compute_array(&\1,", 2),
-    # ---- user data and containers readable from device code ----
-    ("vgl_datastructures/vertices_array/vertices_array.h", "sub", r"#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)", GPU_OR_HIP),
-    ("vgl_datastructures/edges_array/edges_array.h", "sub", r"#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)", GPU_OR_HIP),
+     "\n    #ifdef __USE_HIP__\n    // arrays only kernels (and single host stores) touch: frontier flags / ids\n"
+     "    template <typename _T>\n    static void allocate_device_array(_T **_ptr, size_t _size);\n    #endif\n"),
+    # VerticesArray: members, accessors, constructors / destructor, the host-side member functions
+    ("vgl_datastructures/vertices_array/vertices_array.h", "after", r"^\s*_T \*vertices_data;$",
+     "    #ifdef __USE_HIP__\n    _T *device_data;          // the buffer in HBM (vertices_data is the pinned host mirror)\n    HipShadow *shadow;        // who holds the current values\n    #endif\n"),
+    ("vgl_datastructures/vertices_array/vertices_array.h", "sub", r"^(\s*)#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)",
+     r"\1#if defined(__USE_HIP__)" "\n"
+     r"\1// device code: the HBM buffer; host code: the mirror, fetched back first when kernels ran since" "\n"
+     r"\1__host__ __device__ inline _T &at(int _idx) const" "\n" r"\1{" "\n"
+     r"\1    #if defined(__HIP_DEVICE_COMPILE__)" "\n" r"\1    return device_data[_idx];" "\n"
+     r"\1    #else" "\n" r"\1    hip_shadow_host_access(shadow); return vertices_data[_idx];" "\n" r"\1    #endif" "\n" r"\1}" "\n"
+     r"\1__host__ __device__ inline _T get(int _idx) const { return at(_idx); };" "\n"
+     r"\1__host__ __device__ inline void set(int _idx, _T _val) const { at(_idx) = _val; };" "\n"
+     r"\1__host__ __device__ inline _T& operator[] (int _idx) const { return at(_idx); };" "\n"
+     r"\1#elif defined(__USE_GPU__)"),
+    ("vgl_datastructures/vertices_array/vertices_array.h", "sub", r"^(\s*)(_T \*get_ptr\(\) \{return vertices_data;\};)$",
+     r"\1#ifdef __USE_HIP__" "\n"
+     r"\1_T *get_ptr() { hip_shadow_host_access(shadow); return vertices_data; };                 // host code: the mirror, current" "\n"
+     r"\1_T *get_device_ptr() { hip_shadow_acquire_device(shadow, 0); return device_data; };      // runtime calls on the device buffer (hipMemset)" "\n"
+     r"\1#else" "\n" r"\1\2" "\n" r"\1#endif"),
+    ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"^(\s*)(MemoryAPI::allocate_array\(&this->vertices_data, this->vertices_count\);)$",
+     r"\1#ifdef __USE_HIP__" "\n"
+     r"\1shadow = hip_shadow_allocate(sizeof(_T) * (size_t)this->vertices_count);" "\n"
+     r"\1this->vertices_data = (_T*)shadow->host; this->device_data = (_T*)shadow->device;" "\n"
+     r"\1#else" "\n" r"\1\2" "\n" r"\1#endif"),
+    ("vgl_datastructures/vertices_array/vertices_array.hpp", "after", r"^\s*this->vertices_data = _copy_obj\.vertices_data;$",
+     "    #ifdef __USE_HIP__\n    this->device_data = _copy_obj.device_data;\n    this->shadow = _copy_obj.shadow;\n    #endif\n"),
+    ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"^(\s*)(MemoryAPI::free_array\(this->vertices_data\);)$",
+     r"\1#ifdef __USE_HIP__" "\n" r"\1hip_shadow_free(shadow); shadow = NULL; device_data = NULL;" "\n" r"\1#else" "\n" r"\1\2" "\n" r"\1#endif"),
+    ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"^(void VerticesArray<_T>::(?:set_all_constant|set_all_random|print)\([^)]*\)\n\{\n)",
+     r"\1    VGL_HOST_ACCESS(this);\n", 4),
+    # EdgesArray: the same (its container classes keep pointers into the mirror: attach_pointer)
+    ("vgl_datastructures/edges_array/edges_array.h", "after", r"^\s*_T \*edges_data;$",
+     "    #ifdef __USE_HIP__\n    _T *device_data;          // the buffer in HBM (edges_data is the pinned host mirror)\n    HipShadow *shadow;\n    #endif\n"),
+    ("vgl_datastructures/edges_array/edges_array.h", "sub", r"^(\s*)#ifdef __USE_GPU__$(?=\n\s*__host__ __device__)",
+     r"\1#if defined(__USE_HIP__)" "\n"
+     r"\1__host__ __device__ inline _T &at(long long _global_idx) const" "\n" r"\1{" "\n"
+     r"\1    #if defined(__HIP_DEVICE_COMPILE__)" "\n" r"\1    return device_data[_global_idx];" "\n"
+     r"\1    #else" "\n" r"\1    hip_shadow_host_access(shadow); return edges_data[_global_idx];" "\n" r"\1    #endif" "\n" r"\1}" "\n"
+     r"\1__host__ __device__ inline _T get(long long _global_idx) const { return at(_global_idx); };" "\n"
+     r"\1__host__ __device__ inline void set(long long _global_idx, _T _val) const { at(_global_idx) = _val; };" "\n"
+     r"\1__host__ __device__ inline _T& operator[] (long long _global_idx) const { return at(_global_idx); };" "\n"
+     r"\1#elif defined(__USE_GPU__)"),
+    ("vgl_datastructures/edges_array/edges_array.h", "sub", r"^(\s*)(inline _T \*get_ptr\(\) const \{ return edges_data; \};)$",
+     r"\1#ifdef __USE_HIP__" "\n"
+     r"\1inline _T *get_ptr() const { hip_shadow_host_access(shadow); return edges_data; };" "\n"
+     r"\1inline _T *get_device_ptr() const { hip_shadow_acquire_device(shadow, 0); return device_data; };" "\n"
+     r"\1#else" "\n" r"\1\2" "\n" r"\1#endif"),
+    ("vgl_datastructures/edges_array/edges_array.h", "sub", r"\{ container->(set_all_constant|set_all_random|print)\(", r"{ VGL_HOST_ACCESS(this); container->\1(", 3),
+    ("vgl_datastructures/edges_array/edges_array.hpp", "sub", r"^(\s*)(MemoryAPI::allocate_array\(&edges_data, container->get_total_array_size\(\)\);)$",
+     r"\1#ifdef __USE_HIP__" "\n"
+     r"\1shadow = hip_shadow_allocate(sizeof(_T) * (size_t)container->get_total_array_size());" "\n"
+     r"\1edges_data = (_T*)shadow->host; device_data = (_T*)shadow->device;" "\n"
+     r"\1#else" "\n" r"\1\2" "\n" r"\1#endif"),
+    ("vgl_datastructures/edges_array/edges_array.hpp", "after", r"^\s*this->edges_data = _copy_obj\.edges_data;$",
+     "    #ifdef __USE_HIP__\n    this->device_data = _copy_obj.device_data;\n    this->shadow = _copy_obj.shadow;\n    #endif\n"),
+    ("vgl_datastructures/edges_array/edges_array.hpp", "sub", r"^(\s*)(MemoryAPI::free_array\(edges_data\);)$",
+     r"\1#ifdef __USE_HIP__" "\n" r"\1hip_shadow_free(shadow); shadow = NULL; device_data = NULL;" "\n" r"\1#else" "\n" r"\1\2" "\n" r"\1#endif"),
+    ("vgl_datastructures/edges_array/edges_array.hpp", "sub", r"^(void EdgesArray<_T>::finalize_advance\([^)]*\)\n\{\n)", r"\1    VGL_HOST_ACCESS(this);\n", 1),
+    # frontier flags / ids: device memory
+    ("vgl_datastructures/frontier/containers/csr/frontier_csr.hpp", "sub", r"^(\s*)MemoryAPI::allocate_array\(&(flags|ids), vertices_count\);$",
+     r"\1#ifdef __USE_HIP__" "\n" r"\1MemoryAPI::allocate_device_array(&\2, vertices_count);" "\n" r"\1#else" "\n" r"\1MemoryAPI::allocate_array(&\2, vertices_count);" "\n" r"\1#endif", 2),
+    ("vgl_datastructures/frontier/containers/vect_csr/frontier_vect_csr.hpp", "sub", r"^(\s*)MemoryAPI::allocate_array\(&(flags|ids), max_size\);$",
+     r"\1#ifdef __USE_HIP__" "\n" r"\1MemoryAPI::allocate_device_array(&\2, max_size);" "\n" r"\1#else" "\n" r"\1MemoryAPI::allocate_array(&\2, max_size);" "\n" r"\1#endif", 2),
+    # a graph container that frees its arrays tells the backend (device copies of the adjacency are keyed by the container's address)
+    ("vgl_datastructures/graphs/undirected_containers/csr/csr_graph.hpp", "sub", r"^(void CSRGraph::free\(\)\n\{\n)",
+     r"\1    #ifdef __USE_HIP__\n    hip_container_changed(this);\n    #endif\n", 1),
+    ("vgl_datastructures/graphs/undirected_containers/vect_csr/vect_csr_graph.hpp", "sub", r"^(void VectorCSRGraph::free\(\)\n\{\n)",
+     r"\1    #ifdef __USE_HIP__\n    hip_container_changed(this);\n    #endif\n", 1),
     # ---- host-side container code that exists per architecture: take the plain C++ variant of the CUDA flavour ----
     ("vgl_datastructures/graphs/undirected_containers/edges_list/preprocess_into_segmented.hpp", "sub",
      r"^#ifdef __USE_GPU__$(?=\nvoid EdgesListGraph::preprocess_into_segmented)", GPU_OR_HIP),

@@ -11,9 +11,9 @@
 //               (+ the vector extension), made when a container is first used; frontier handles BORROW the containers' flags / ids
 //               (vgl_hip_frontier_create_on), so host code of the reference that writes those arrays (add_vertex, set_all_active) needs no change
 //   memory    : the containers stay in managed memory (MemoryAPI::allocate_array = hipMallocManaged under __USE_HIP__: host-resident on a pool
-//               without XNACK, where the reference's host code wants them); user arrays and frontier flags / ids come from
-//               MemoryAPI::allocate_compute_array -- managed by default, hipMalloc with VGL_HIP_DEVICE_ARRAYS=1 (host code still reaches them, slowly,
-//               through the PCIe BAR)
+//               without XNACK, where the reference's host code wants them); user arrays (VerticesArray / EdgesArray) are shadowed -- a pinned host
+//               mirror and a buffer in HBM with an owner flag, shadow_memory.h: every primitive starts with hip_shadows_to_device(), which uploads what
+//               host code wrote since the last one; frontier flags / ids are device memory
 //
 // Containers served: CSR_GRAPH (advance_worker.hpp:62-149, generate_new_frontier.hpp:113-164) and VECTOR_CSR_GRAPH with its three degree
 // ranges and the padded vector extension (advance_worker.hpp:204-319, advance_{all_active,dense,sparse}.hpp, generate_new_frontier.hpp:29-111):
@@ -117,6 +117,7 @@ private:
         vgl_hip_graph *handle = nullptr;
         const void *vertex_pointers = nullptr, *adjacent_ids = nullptr;       // the container's arrays the copies were made from
         long long edges_count = 0;
+        unsigned long long version = 0;                                       // hip_container_version() when the copies were made (bumped by the container's free())
         long long *d_vertex_pointers = nullptr;
         int *d_adjacent_ids = nullptr;
         long long *d_ve_group_ptrs = nullptr;                                   // VECTOR_CSR_GRAPH: the vector extension
@@ -171,7 +172,7 @@ private:
         if (it != graph_handles.end()) {
             graph_binding &b = it->second;
             if (b.vertex_pointers == (const void *)_graph.get_vertex_pointers() && b.adjacent_ids == (const void *)_graph.get_adjacent_ids() &&
-                b.edges_count == (long long)_graph.get_edges_count())
+                b.edges_count == (long long)_graph.get_edges_count() && b.version == hip_container_version((const void *)&_graph))
                 return b;
             drop_frontier_handles();                                                         // (they refer to the old handle)
             release(b);
@@ -181,6 +182,7 @@ private:
         graph_binding b;
         const size_t V = (size_t)_graph.get_vertices_count(), E = (size_t)_graph.get_edges_count();
         b.vertex_pointers = (const void *)_graph.get_vertex_pointers(); b.adjacent_ids = (const void *)_graph.get_adjacent_ids(); b.edges_count = (long long)E;
+        b.version = hip_container_version((const void *)&_graph);
         b.d_vertex_pointers = device_copy(_graph.get_vertex_pointers(), V + 1);
         b.d_adjacent_ids = device_copy(_graph.get_adjacent_ids(), E);
         copy_vector_extension(_graph, b);
@@ -303,6 +305,7 @@ private:
     void compute_on_csr_pointers(GraphContainer &_graph, FrontierContainer &_frontier, ComputeOperation &&compute_op)
     {
         LOAD_FRONTIER_DATA(_frontier);
+        hip_shadows_to_device(stream);
         const int vertices_count = _graph.get_vertices_count();
         vertex_pass(vertices_count, binding_of(_graph).d_vertex_pointers, _frontier.get_sparsity_type(), frontier_flags, frontier_ids, frontier_size, 0, vertices_count, compute_op);
         finish();
@@ -323,6 +326,7 @@ private:
         if (_reduce_type != REDUCE_SUM && _reduce_type != REDUCE_MAX) throw "Error in GraphAbstractionsHIP::reduce_worker: unsupported reduce type";   // multicore/reduce.hpp:144-150
         using R = typename std::decay<ReduceOperation>::type;
         LOAD_FRONTIER_DATA(_frontier);
+        hip_shadows_to_device(stream);
         const long long *vertex_pointers = binding_of(_graph).d_vertex_pointers;
         const FrontierSparsityType t = _frontier.get_sparsity_type();
         const int n = t == SPARSE_FRONTIER ? frontier_size : _graph.get_vertices_count();
@@ -463,6 +467,17 @@ GraphAbstractionsHIP::GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection
     VGL_HIP_BIND_RT(hipMalloc((void **)&reduce_partials, sizeof(double) * (1024 + 8)));
     VGL_HIP_BIND_RT(hipMalloc((void **)&part_counters, sizeof(unsigned long long) * 8));
     frontier_generation = bindings_generation();
+    // the device copies of both direction containers are made HERE, before the algorithm starts its timer (the reference's algorithms construct the class
+    // first and call _graph.move_to_device() next, bfs.hpp:58-72): the first primitive does not pay for 2 x (adjacency + vector extension) over PCIe
+    if (_graph.get_container_type() == CSR_GRAPH) {
+        binding_of(*(CSRGraph *)_graph.get_outgoing_data());
+        if (_graph.get_number_of_directions() == BOTH_DIRECTIONS) binding_of(*(CSRGraph *)_graph.get_incoming_data());
+        VGL_HIP_BIND_RT(hipStreamSynchronize(stream));
+    } else if (_graph.get_container_type() == VECTOR_CSR_GRAPH) {
+        binding_of(*(VectorCSRGraph *)_graph.get_outgoing_data());
+        if (_graph.get_number_of_directions() == BOTH_DIRECTIONS) binding_of(*(VectorCSRGraph *)_graph.get_incoming_data());
+        VGL_HIP_BIND_RT(hipStreamSynchronize(stream));
+    }
 }
 
 GraphAbstractionsHIP::~GraphAbstractionsHIP()
@@ -492,6 +507,7 @@ void GraphAbstractionsHIP::advance_worker(CSRGraph &_graph, FrontierCSR &_fronti
 {
     Timer tm;
     tm.start();
+    hip_shadows_to_device(stream);
     const int vertices_count = _graph.get_vertices_count();
     const long long edges_count = _graph.get_edges_count();
     const long long *vertex_pointers = binding_of(_graph).d_vertex_pointers;       // the device copy (the kernels' view of the container)
@@ -521,6 +537,7 @@ void GraphAbstractionsHIP::advance_worker(VectorCSRGraph &_graph, FrontierVector
     using Q = typename std::decay<VertexPostprocessOperation>::type; using CQ = typename std::decay<CollectiveVertexPostprocessOperation>::type;
     Timer tm;
     tm.start();
+    hip_shadows_to_device(stream);
     const graph_binding &gb = binding_of(_graph);
     const int vertices_count = _graph.get_vertices_count();
     const long long edges_count = _graph.get_edges_count();
@@ -576,6 +593,7 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(CSRGraph &_graph, Fronti
     using C = typename std::decay<FilterCondition>::type;
     Timer tm;
     tm.start();
+    hip_shadows_to_device(stream);
     _frontier.set_direction(current_traversal_direction);
     const int vertices_count = _graph.get_vertices_count();
     vgl_hip_graph *gh = handle_of(_graph);
@@ -607,6 +625,7 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
     using C = typename std::decay<FilterCondition>::type;
     Timer tm;
     tm.start();
+    hip_shadows_to_device(stream);
     const int vertices_count = _graph.get_vertices_count();
     vgl_hip_graph *gh = handle_of(_graph);
     vgl_hip_frontier *fh = handle_of(_frontier, gh);

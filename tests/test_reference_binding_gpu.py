@@ -87,28 +87,29 @@ def test_reference_mf_app():
 
 
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
-@pytest.mark.parametrize("app,args,checks", [("bfs", ["-s", "10", "-it", "3"], 3), ("pr", ["-s", "12", "-it", "5"], 1), ("sssp", ["-s", "10", "-it", "2"], 2),
-                                             ("cc", ["-s", "10"], 1), ("sswp", ["-s", "10", "-it", "1"], 1)])
-def test_reference_apps_with_device_resident_arrays(app, args, checks, fmt):
-    """VGL_HIP_DEVICE_ARRAYS=1: VerticesArray / EdgesArray / frontier flags and ids are hipMalloc memory (kernels at HBM rates: INTEGRATION 2.0); the
-    reference's host code -- initialisation, change_traversal_direction, the -check -- still dereferences them, through the PCIe BAR (slow loads, so a
-    small graph here)"""
-    env = dict(os.environ, VGL_HIP_DEVICE_ARRAYS="1")
-    # (pr at scale 12 like test_reference_pr_app: verify_ranking_results compares the MEAN ABSOLUTE difference of gpu_pr.hpp and seq_page_rank with 1e-4,
-    # which the two only meet once the ranks themselves are that small)
-    text = run(app, "-e", "16", "-type", "rmat", "-format", fmt, "-check", *args, env=env)
-    assert len(re.findall(r"error count: 0\b", text)) == checks, text[-3000:]
+def test_user_arrays_live_in_hbm_and_cross_pcie_only_when_the_other_side_touches_them(fmt):
+    """Residency (integration/vgl_compute_api/hip/shadow_memory.h): a VerticesArray is a pinned host mirror + a buffer in HBM with an owner flag.
+    The reference's bfs app with -check, three rounds: `levels` goes up once per round (move_to_device() in bfs.hpp:71, after verify_results read it on
+    the host; the first round uploads nothing: the array is fresh) and comes down once per round (verify_results); `check_levels` is written and read by
+    host code only and never crosses.  Without -check nothing crosses at all."""
+    env = dict(os.environ, VGL_HIP_SHADOW_STATS="1")
+    text = run("bfs", "-s", "12", "-e", "16", "-type", "rmat", "-format", fmt, "-check", "-it", "3", env=env)
+    assert len(re.findall(r"error count: 0\b", text)) == 3, text[-3000:]
+    m = re.search(r"shadowed arrays: (\d+) uploads \(([\d.]+) MB\), (\d+) downloads \(([\d.]+) MB\)", text)
+    assert m, text[-3000:]
+    assert (int(m.group(1)), int(m.group(3))) == (2, 3), m.group(0)
+    text = run("bfs", "-s", "12", "-e", "16", "-type", "rmat", "-format", fmt, "-it", "3", env=env)
+    m = re.search(r"shadowed arrays: (\d+) uploads \(([\d.]+) MB\), (\d+) downloads", text)
+    assert m and (int(m.group(1)), int(m.group(3))) == (0, 0), text[-3000:]
 
 
-@pytest.mark.parametrize("device_arrays", ["0", "1"])
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
 @pytest.mark.parametrize("kind,scale,edges", [("rmat", 12, 16), ("ru", 10, 4)])
-def test_host_rewrites_of_a_generated_frontier_void_its_advance_plan(kind, scale, edges, fmt, device_arrays):
+def test_host_rewrites_of_a_generated_frontier_void_its_advance_plan(kind, scale, edges, fmt):
     """integration/tests/plan_stamp_check.cpp (our program against the patched tree): generate_new_frontier leaves the advance plan of a sparse
     frontier behind and stamps the container; clear / add_vertex / add_group_of_vertices / set_all_active void the stamp.  A scatter on a frontier
     that was generated and then rewritten by host code -- same size, other degrees -- must reach what it reaches on a frontier the backend never
-    generated."""
-    env = dict(os.environ, VGL_HIP_DEVICE_ARRAYS=device_arrays)
-    text = run("plan_stamp_check", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, env=env)
+    generated.  (The program also alternates host writes, kernels and host reads of four VerticesArrays: every case crosses the shadow both ways.)"""
+    text = run("plan_stamp_check", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt)
     assert "PLAN STAMP CHECK PASSED" in text, text[-3000:]
     assert len(re.findall(r", 0 differences", text)) == 4, text[-3000:]
