@@ -9,6 +9,8 @@ struct PageRank {
     // 2 = pull inside compute(): the lane of a vertex sums its neighbours' contributions in a register (adjacency through a vgl_csr_view
     // captured by value, as the reference's random_walk.hpp reads the graph inside compute lambdas).  1 and 2 are the multicore recipe
     // (pr.hpp:105-124): products and sums in f32 in adjacency order -- seq_page_rank's chain, independent of the schedule.
+    // 3 = the pull as a DECLARED operator (VGL_SUM_OVER_EDGES, an API extension): the class runs the library's blocked pass -- exact sums, the same
+    // bits for any schedule, <= 1e-6 of the chain while rows are short (uniform graphs).
     static double vgl_page_rank(VGL_Graph &graph, VerticesArray<_T> &page_ranks, _T, int max_iterations, int deterministic = 0)
     {
         const int vertices_count = graph.get_vertices_count();
@@ -56,7 +58,9 @@ struct PageRank {
             auto vertex_postprocess_op = [page_ranks, k, d, dangling_input] __VGL_ADVANCE_POSTPROCESS_ARGS__ {
                 page_ranks[src_id] = k + d * (page_ranks[src_id] + dangling_input);
             };
-            if (deterministic == 2) {
+            if (deterministic == 3) {
+                graph_API.scatter(graph, frontier, VGL_SUM_OVER_EDGES(page_ranks, contributions), EMPTY_VERTEX_OP, vertex_postprocess_op);
+            } else if (deterministic == 2) {
                 const vgl_csr_view out = graph.get_direction_view(SCATTER);
                 auto pull = [page_ranks, contributions, out, k, d, dangling_input] __VGL_COMPUTE_ARGS__ {
                     _T sum = 0;

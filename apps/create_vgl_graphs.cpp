@@ -47,6 +47,9 @@ int main(int argc, char **argv)
         tm.start();
         if (parser.format == EDGES_CONTAINER) {
             if (!edges_container.save_to_binary_file(full_name)) throw "Error: can not write the edges container file";
+        } else if (parser.format == VECTOR_CSR_GRAPH) {
+            // both per-direction containers of the file on the device (vgl_write_vect_csr_file): the same bytes as import + save_to_binary_file
+            if (!vgl_write_vect_csr_file(edges_container, full_name)) throw "Error: can not write the graph file";
         } else {
             VGL_Graph out_graph(parser.format);
             out_graph.import(edges_container);

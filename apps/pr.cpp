@@ -13,7 +13,7 @@ int main(int argc, char **argv)
         VerticesArray<float> page_ranks(graph);
         const double perf = parser.fused ? PageRank::hip_fused(graph, page_ranks, parser.get_number_of_rounds())
                                          : PageRank::vgl_page_rank(graph, page_ranks, 1.0e-4f, parser.get_number_of_rounds(),
-                                                                   parser.traversal == Parser::PULL_TRAVERSAL ? 2 : parser.deterministic ? 1 : 0);
+                                                                   parser.declared ? 3 : parser.traversal == Parser::PULL_TRAVERSAL ? 2 : parser.deterministic ? 1 : 0);
         report_performance(perf);
         if (parser.get_check_flag()) {
             HostCSR h(graph);

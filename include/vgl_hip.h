@@ -282,6 +282,12 @@ int vgl_hip_pr_run_mode(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_ind
  * vgl_hip_pr_run_mode for the reference's evaluation order at any size. */
 int vgl_hip_pr_prepare(vgl_hip_ctx *ctx, vgl_hip_graph *g, int mode, int *resolved_mode);
 int vgl_hip_cc_prepare(vgl_hip_ctx *ctx, vgl_hip_graph *g);
+/* Graph preparation for the path algorithms (Bellman-Ford / widest paths; counterpart of the reference's import, which derives every edge-array layout
+ * from one permutation, csr_edges_array.hpp:31-40): builds the blocked STRUCTURE of the outgoing CSR once per graph -- one radix sort of the edges by
+ * block pair, the CSR position behind every value slot kept.  Afterwards a pull plan for ANY weights array (vgl_hip_sssp_pull_plan_create) is one
+ * gather pass, and vgl_hip_sssp_run(ALL_ACTIVE) -- the reference's schedule, every edge in every super-step -- runs as blocked passes (same fixed
+ * point, same f32 bits).  Needs a handle that owns all rows. */
+int vgl_hip_sssp_prepare(vgl_hip_ctx *ctx, vgl_hip_graph *g);
 
 typedef struct {
     int32_t hook_passes;
@@ -369,6 +375,13 @@ int vgl_hip_cc_jump(vgl_hip_ctx *ctx, int32_t V, int32_t *d_comp);
 /* PageRank pieces: prepare (contrib = old*rdeg, dangling sum over ALL vertices) and pull over the owned rows only;
  * ranks of owned rows are written, the caller all-gathers owned slices (EXCHANGE_PRIVATE_DATA, pr.hpp:127). */
 int vgl_hip_pr_setup(vgl_hip_ctx *ctx, int32_t V, const int32_t *d_indeg_noloops, float *d_ranks, float *d_rdeg);
+/* The sum-type all-active advance of PR::vgl_page_rank (algorithms/pr/pr.hpp:105-124: `page_ranks[src] += contribution[dst]` over every edge
+ * src -> dst with dst != src) with the caller's own arrays: d_sums[src] = sum over those edges of d_values[dst], for the rows the handle owns.
+ * Runs as the blocked pass (values read from LDS windows, exact 64-bit fixed-point accumulation, rounded to f32 once: the same bits for any
+ * schedule; it differs from an f32 `+=` chain in adjacency order by the chain's own rounding).  d_values must be non-negative and every
+ * per-vertex sum at most sum_bound (the unit of the fixed point is derived from it; PageRank contributions: 1).  The layout is the one
+ * vgl_hip_pr_prepare(BLOCKED) builds (built here on first use).  Asynchronous on the context's stream. */
+int vgl_hip_sum_over_edges_f32(vgl_hip_ctx *ctx, vgl_hip_graph *g, const float *d_values, float sum_bound, float *d_sums);
 int vgl_hip_pr_iteration_owned(vgl_hip_ctx *ctx, vgl_hip_graph *g, const int32_t *d_indeg_noloops, const float *d_rdeg,
                                float *d_ranks, float *d_contrib_scratch);
 /* "Recently changed" exchange of a replicated 4-byte vertex array (EXCHANGE_RECENTLY_CHANGED, common/mpi_exchange.hpp:110-150): instead

@@ -17,7 +17,7 @@ context; the anchors below are the shortest strings that locate each edit):
   * move_to_device / move_to_host   : the CUDA flavour's family exists; on user arrays they are real copies mirror <-> HBM
   * algorithms/{pr,sssp,cc}         : the reference's GPU variants (gpu_pr.hpp, gpu_shortest_paths.hpp, gpu_shiloach_vishkin.hpp) compile for __USE_HIP__;
                                       three CUDA runtime calls by name get a HIP branch
-  * graph_library.h                 : coloring.h and tc.h left out (host helpers called from device lambdas)
+  * algorithms/coloring             : bit helpers callable from device code; graph_library.h leaves tc.h out (EDGES_LIST_GRAPH + host-side copy_if)
 (the hipcc command line is in oracle/Makefile, target `binding`)
 Every rule must apply (an anchor that is not found is an error): the script is also the test that the reference still has the shape the
 binding was written against.  tests/test_reference_binding.py applies it to a copy in /tmp and compiles seven of the reference's apps with hipcc."""
@@ -46,9 +46,13 @@ RULES = [
     ("vgl_compute_api/common/compute.hpp", "sub", r"^(\s*)#ifdef __USE_GPU__$", r"\1" + GPU_OR_HIP, 4),
     ("vgl_compute_api/common/graph_abstractions.h", "before", r"^#if defined\(__USE_MULTICORE__\)$",
      "#ifdef __USE_HIP__\n#include \"vgl_compute_api/hip/graph_abstractions_hip.h\"\n#endif\n\n"),
-    # ---- algorithm headers whose operator lambdas cannot be device code under clang: coloring.hpp calls its host-only helpers (clear_bit,
-    #      smallest_bit_pos) from them, tc.hpp hands a device lambda to the host-side copy_if (nvcc accepts both in never-instantiated templates) ----
-    ("graph_library.h", "sub", r'^(#include "algorithms/coloring/coloring.h")$', r"#ifndef __USE_HIP__\n\1\n#endif"),
+    # ---- coloring.hpp calls its bit helpers (clear_bit, smallest_bit_pos) from operator lambdas: they become callable from device code (clang, unlike
+    #      nvcc, checks this in templates that are never instantiated too).  Its scatter under enable_safe_stores() -- a read-modify-write of per-vertex
+    #      data without atomics -- runs one lane per vertex in the HIP class (GraphAbstractionsHIP::enable_safe_stores).
+    #      tc.hpp stays out: it hands a device lambda to the host-side copy_if and runs its condensed graph as an EDGES_LIST_GRAPH, a container the
+    #      reference's own GPU backend does not serve either (gpu/advance.hpp:37) ----
+    ("algorithms/coloring/coloring.hpp", "sub", r"^inline (size_t|int) (set_bit|clear_bit|get_bit|smallest_bit_pos)\(",
+     r"#if defined(__USE_GPU__) || defined(__USE_HIP__)\n__host__ __device__\n#endif\ninline \1 \2(", 4),
     ("graph_library.h", "sub", r'^(#include "algorithms/tc/tc.h")$', r"#ifndef __USE_HIP__\n\1\n#endif"),
     # ---- memory: managed allocations, as the CUDA flavour (__USE_MANAGED_MEMORY__, settings.h) ----
     ("vgl_runtime/helpers/memory_API/memory_API.hpp", "before", r"^\s*#elif defined\(__USE_KNL__\)$",
@@ -119,8 +123,11 @@ RULES = [
      "    #ifdef __USE_HIP__\n    this->device_data = _copy_obj.device_data;\n    this->shadow = _copy_obj.shadow;\n    #endif\n"),
     ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"^(\s*)(MemoryAPI::free_array\(this->vertices_data\);)$",
      r"\1#ifdef __USE_HIP__" "\n" r"\1hip_shadow_free(shadow); shadow = NULL; device_data = NULL;" "\n" r"\1#else" "\n" r"\1\2" "\n" r"\1#endif"),
-    ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"^(void VerticesArray<_T>::(?:set_all_constant|set_all_random|print)\([^)]*\)\n\{\n)",
-     r"\1    VGL_HOST_ACCESS(this);\n", 4),
+    ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"^(void VerticesArray<_T>::(?:set_all_random|print)\([^)]*\)\n\{\n)",
+     r"\1    VGL_HOST_ACCESS(this);\n", 3),
+    # set_all_constant between primitives (coloring.hpp:90,113 does it every iteration): filled where the array lives
+    ("vgl_datastructures/vertices_array/vertices_array.hpp", "sub", r"^(void VerticesArray<_T>::set_all_constant\([^)]*\)\n\{\n)(\s*)(MemoryAPI::set\(this->vertices_data, _const, this->vertices_count\);)$",
+     r"\1\2#ifdef __USE_HIP__\n\2if(hip_shadow_fill(shadow, this->device_data, _const, (size_t)this->vertices_count)) return;\n\2VGL_HOST_ACCESS(this);\n\2#endif\n\2\3", 1),
     # EdgesArray: the same (its container classes keep pointers into the mirror: attach_pointer)
     ("vgl_datastructures/edges_array/edges_array.h", "after", r"^\s*_T \*edges_data;$",
      "    #ifdef __USE_HIP__\n    _T *device_data;          // the buffer in HBM (edges_data is the pinned host mirror)\n    HipShadow *shadow;\n    #endif\n"),

@@ -133,6 +133,10 @@ private:
     // that may be gone and are dropped (unread) at their next use
     static unsigned long long &bindings_generation() { static unsigned long long generation = 0; return generation; }
     unsigned long long frontier_generation = 0;
+    // enable_safe_stores() (common/graph_abstractions.h:170; coloring.hpp:108-110 brackets a scatter whose operator does a plain read-modify-write of
+    // src-indexed data with it): while on, an advance runs ONE LANE PER ACTIVE VERTEX -- its edges in adjacency order between its pre and post
+    // operators, the execution shape of the reference's vector-core kernels (multicore/advance_worker.hpp:62-149) -- instead of edge tiles
+    bool safe_stores = false;
     // one per frontier container (its flags / ids are borrowed).  plan_token / planned_on: generate_new_frontier left the advance plan of the SPARSE
     // frontier behind (the ids' edge offsets, a by-product of the compaction) and stamped the container (BaseFrontier::hip_plan_token); the container's
     // mutators -- set_all_active, add_vertex, clear -- zero the stamp, so an equal non-zero stamp says that nothing touched the frontier since and
@@ -292,6 +296,27 @@ private:
                                frontier_flags, _row_lo, _row_hi, edge_op);
     }
 
+    // the same, one lane per active vertex (safe stores): pre, the vertex's edges in adjacency order, post
+    template <typename GraphContainer, typename FrontierContainer, typename EdgeOp, typename PreOp, typename PostOp>
+    void rows_pass(GraphContainer &_graph, FrontierContainer &_frontier, long long _process_shift, int _row_lo, int _row_hi, EdgeOp &&edge_op, PreOp &&pre_op, PostOp &&post_op)
+    {
+        using E = typename std::decay<EdgeOp>::type; using P = typename std::decay<PreOp>::type; using Q = typename std::decay<PostOp>::type;
+        LOAD_FRONTIER_DATA(_frontier);
+        const graph_binding &gb = binding_of(_graph);
+        const int vertices_count = _graph.get_vertices_count();
+        const FrontierSparsityType t = _frontier.get_sparsity_type();
+        if (_row_hi <= _row_lo) return;
+        if (t == ALL_ACTIVE_FRONTIER)
+            hipLaunchKernelGGL((vgl_k_advance_rows<0, E, P, Q>), dim3(grid_for(vertices_count)), dim3(VGL_BLOCK), 0, stream, vertices_count, gb.d_vertex_pointers, gb.d_adjacent_ids,
+                               frontier_flags, frontier_ids, _process_shift, _row_lo, _row_hi, edge_op, pre_op, post_op);
+        else if (t == DENSE_FRONTIER)
+            hipLaunchKernelGGL((vgl_k_advance_rows<1, E, P, Q>), dim3(grid_for(vertices_count)), dim3(VGL_BLOCK), 0, stream, vertices_count, gb.d_vertex_pointers, gb.d_adjacent_ids,
+                               frontier_flags, frontier_ids, _process_shift, _row_lo, _row_hi, edge_op, pre_op, post_op);
+        else if (frontier_size > 0)
+            hipLaunchKernelGGL((vgl_k_advance_rows<2, E, P, Q>), dim3(grid_for(frontier_size)), dim3(VGL_BLOCK), 0, stream, frontier_size, gb.d_vertex_pointers, gb.d_adjacent_ids,
+                               frontier_flags, frontier_ids, _process_shift, _row_lo, _row_hi, edge_op, pre_op, post_op);
+    }
+
     // compute inner implementation
     template <typename ComputeOperation, typename GraphContainer, typename FrontierContainer>
     void compute_worker(GraphContainer &_graph, FrontierContainer &_frontier, ComputeOperation &&compute_op);
@@ -381,6 +406,8 @@ public:
     // attaches graph-processing API to the specific graph
     GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection _initial_traversal = SCATTER);
     ~GraphAbstractionsHIP();
+    void enable_safe_stores() { safe_stores = true; }
+    void disable_safe_stores() { safe_stores = false; }
     // the device copies of every container's adjacency are dropped (the next primitive copies again): for host code that rewrote a container's
     // vertex_pointers / adjacent_ids IN PLACE after a primitive had used it
     void forget_graph_bindings()
@@ -514,9 +541,12 @@ void GraphAbstractionsHIP::advance_worker(CSRGraph &_graph, FrontierCSR &_fronti
     LOAD_FRONTIER_DATA(_frontier);
     const long long process_shift = compute_process_shift(current_traversal_direction, CSR_STORAGE);
     const FrontierSparsityType t = _frontier.get_sparsity_type();
-    if (!is_empty_op<VertexPreprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, vertex_preprocess_op);
-    edge_pass(_graph, _frontier, process_shift, 0, vertices_count, edge_op);
-    if (!is_empty_op<VertexPostprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, vertex_postprocess_op);
+    if (safe_stores) rows_pass(_graph, _frontier, process_shift, 0, vertices_count, edge_op, vertex_preprocess_op, vertex_postprocess_op);
+    else {
+        if (!is_empty_op<VertexPreprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, vertex_preprocess_op);
+        edge_pass(_graph, _frontier, process_shift, 0, vertices_count, edge_op);
+        if (!is_empty_op<VertexPostprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, vertex_postprocess_op);
+    }
     finish();
     tm.end();
     const long long work = t == ALL_ACTIVE_FRONTIER ? edges_count : frontier_neighbours_count;
@@ -558,12 +588,16 @@ void GraphAbstractionsHIP::advance_worker(VectorCSRGraph &_graph, FrontierVector
         const vgl_range_edge_op<E, CE> both{edge_op, collective_edge_op, collective_start};
         const bool no_pre = is_empty_op<VertexPreprocessOperation>() && is_empty_op<CollectiveVertexPreprocessOperation>();
         const bool no_post = is_empty_op<VertexPostprocessOperation>() && is_empty_op<CollectiveVertexPostprocessOperation>();
-        if (!no_pre) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, pre);
-        edge_pass(_graph, _frontier, csr_shift, 0, vertices_count, both);
-        if (!no_post) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, post);
+        if (safe_stores) rows_pass(_graph, _frontier, csr_shift, 0, vertices_count, both, pre, post);
+        else {
+            if (!no_pre) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, pre);
+            edge_pass(_graph, _frontier, csr_shift, 0, vertices_count, both);
+            if (!no_post) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, vertices_count, post);
+        }
         work = frontier_neighbours_count;
     } else {
-        if (collective_start > 0) {
+        if (collective_start > 0 && safe_stores) rows_pass(_graph, _frontier, csr_shift, 0, collective_start, edge_op, vertex_preprocess_op, vertex_postprocess_op);
+        else if (collective_start > 0) {
             if (!is_empty_op<VertexPreprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, collective_start, vertex_preprocess_op);
             edge_pass(_graph, _frontier, csr_shift, 0, collective_start, edge_op);
             if (!is_empty_op<VertexPostprocessOperation>()) vertex_pass(vertices_count, vertex_pointers, t, frontier_flags, frontier_ids, frontier_size, 0, collective_start, vertex_postprocess_op);

@@ -61,7 +61,12 @@ inline HipShadow *hip_shadow_allocate(size_t bytes)
     s->bytes = bytes;
     const size_t n = bytes ? bytes : 1;
     HIP_SHADOW_RT(hipHostMalloc(&s->host, n, hipHostMallocDefault));
-    HIP_SHADOW_RT(hipMalloc(&s->device, n));
+    {   // EXPERIMENT (removed once decided): which kind of device memory user arrays get
+        const char *kind = getenv("VGL_HIP_SHADOW_MEM");
+        if (kind && kind[0] == 'f') HIP_SHADOW_RT(hipExtMallocWithFlags(&s->device, n, hipDeviceMallocFinegrained));
+        else if (kind && kind[0] == 'u') HIP_SHADOW_RT(hipExtMallocWithFlags(&s->device, n, hipDeviceMallocUncached));
+        else HIP_SHADOW_RT(hipMalloc(&s->device, n));
+    }
     HipShadowRegistry &r = hip_shadow_registry();
     std::lock_guard<std::recursive_mutex> g(r.lock);
     r.by_host[s->host] = s;
@@ -135,6 +140,31 @@ inline HipShadow *hip_shadow_of(const void *host_pointer)
     std::lock_guard<std::recursive_mutex> g(r.lock);
     auto it = r.by_host.find((void *)host_pointer);
     return it == r.by_host.end() ? nullptr : it->second;
+}
+
+// VerticesArray::set_all_constant while the array lives on the device: a fill kernel instead of fetching the array back, filling the mirror and
+// uploading it again at the next primitive.  Returns false (nothing done) while the host owns the array: the caller fills the mirror as before.
+template <typename T>
+__global__ void hip_shadow_fill_kernel(T *data, T value, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) data[i] = value;
+}
+template <typename T>
+inline bool hip_shadow_fill(HipShadow *s, T *device_data, T value, size_t n)
+{
+    if (s->owner == HIP_SHADOW_HOST) return false;
+    if (n) {
+        const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(hip_shadow_fill_kernel<T>, dim3(blocks), dim3(256), 0, 0, device_data, value, n);
+        HIP_SHADOW_RT(hipGetLastError());
+        HIP_SHADOW_RT(hipStreamSynchronize(0));
+    }
+    if (s->owner == HIP_SHADOW_FRESH) {
+        HipShadowRegistry &r = hip_shadow_registry();
+        std::lock_guard<std::recursive_mutex> g(r.lock);
+        if (s->owner == HIP_SHADOW_FRESH) { s->owner = HIP_SHADOW_DEVICE; r.not_on_device--; }
+    }
+    return true;
 }
 
 // Graph containers that were freed or resized since the backend copied their adjacency to the device (CSRGraph::free / VectorCSRGraph::free call

@@ -125,6 +125,14 @@ def test_pr_app(kind, scale, ef, seed, tmp_path, oracle, ctx):
     out3, dump3 = run_app("pr", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 5, "-check", "-pull"], tmp_path)
     assert "error count: 0" in out3
     assert (np.fromfile(dump3, np.float32).view(np.int32) == got.view(np.int32)).all()
+    # -declared (round 5): the pull as the declared operator VGL_SUM_OVER_EDGES -- the class runs the library's blocked pass (exact sums): within 1e-6
+    # of the chain on uniform graphs (short rows), within the chain's own rounding on RMAT hubs; the same bits from run to run
+    out4, dump4 = run_app("pr", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 5, "-check", "-declared"], tmp_path)
+    assert "error count: 0" in out4
+    got4 = np.fromfile(dump4, np.float32)
+    assert np.max(np.abs(got4 - ref) / ref) <= (1e-6 if kind == "ru" else 2e-5)
+    out5, dump5 = run_app("pr", ["-s", scale, "-e", ef, "-type", kind, "-seed", seed, "-it", 5, "-declared"], tmp_path)
+    assert (np.fromfile(dump5, np.float32).view(np.int32) == got4.view(np.int32)).all()
 
 
 @pytest.mark.parametrize("kind,scale,ef,seed", CASES)

@@ -1111,6 +1111,48 @@ def test_pagerank_blocked_pull(kind, scale, ef, renumber, ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef,bound", [("ru", 16, 8, 1.0), ("rmat", 15, 16, 1.0), ("ru", 17, 4, 1000.0), ("ru", 14, 1, 0.3)])
+def test_sum_over_edges_declared_operator(kind, scale, ef, bound, ctx, oracle):
+    """vgl_hip_sum_over_edges_f32 (the declared operator VGL_SUM_OVER_EDGES; pull of algorithms/pr/pr.hpp:109-123 on the caller's arrays):
+    sums[src] = sum of values[dst] over the edges src -> dst, dst != src, EXACT (f64 accumulation of f32 values is exact here) and rounded to
+    f32 once, for any bound that covers the sums (the unit of the fixed point follows the bound) and for any cut into units."""
+    import os
+    import torch
+    from vectorgraphlibrary_amd import api
+    V, seed = 1 << scale, 77
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst)
+    rowptr, adj = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy()
+    rng = np.random.default_rng(5)
+    rows = np.repeat(np.arange(V, dtype=np.int64), np.diff(rowptr))
+    keep = rows != adj
+    longest = int(np.diff(rowptr).max())
+    values = (rng.random(V, dtype=np.float32) * np.float32(bound / max(longest, 1))).astype(np.float32)     # every sum stays below `bound`
+    values[rng.integers(0, V, V // 16)] = 0.0
+    want = np.bincount(rows[keep], weights=values[adj[keep]].astype(np.float64), minlength=V).astype(np.float32)
+    x = torch.from_numpy(values).to(ctx.device)
+    got = []
+    for unit in ("", "64"):
+        if unit:
+            os.environ["VGL_BLK_GATHER_UNIT"] = os.environ["VGL_BLK_ACCUM_UNIT"] = unit
+        try:
+            g2 = api.Graph(ctx, V, g.out_rowptr, g.out_adj, g.in_rowptr, g.in_adj) if unit else g
+            got.append(api.sum_over_edges(g2, x, bound).cpu().numpy())
+        finally:
+            os.environ.pop("VGL_BLK_GATHER_UNIT", None), os.environ.pop("VGL_BLK_ACCUM_UNIT", None)
+        if unit:
+            g2.close()
+    assert (got[0].view(np.int32) == got[1].view(np.int32)).all(), "the sums depend on the cut into units"
+    nz = want > 0
+    # one f32 rounding of the exact sum; contributions below bound * 2^-62 are dropped by the fixed point (none here)
+    assert np.max(np.abs(got[0][nz] - want[nz]) / want[nz]) <= 1.2e-7, np.max(np.abs(got[0][nz] - want[nz]) / want[nz])
+    assert (got[0][~nz] == 0).all()
+    with pytest.raises(Exception):
+        api.sum_over_edges(g, x, 0.0)
+    g.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,scale,ef,renumber", [("rmat", 17, 16, "total"), ("rmat", 17, 16, None), ("ru", 17, 8, None), ("ru", 16, 2, None)])
 def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, oracle):
     """pull (blocked gather / LDS minimum) and push <-> pull switching SSSP / SSWP on graphs of several blocks: f32 bits equal to the
@@ -1160,6 +1202,58 @@ def test_sssp_pull_and_direction_optimising(kind, scale, ef, renumber, ctx, orac
             assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all() and st["push_steps"] == 0
         plan.close()
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,scale,ef,piece", [("rmat", 16, 16, ""), ("ru", 15, 8, ""), ("rmat", 15, 16, "40000")])
+def test_path_structure_is_built_once_per_graph_and_shared_between_weight_arrays(kind, scale, ef, piece, ctx, oracle):
+    """Round 5 (the reference derives every edge-array layout from ONE permutation, csr_edges_array.hpp:31-40): the blocked layout of the path
+    algorithms is a per-graph STRUCTURE that keeps the CSR position behind every value slot (vgl_hip_sssp_prepare) + per-weights value arrays filled
+    by one gather pass.  Two plans with different weights share the structure and stay independent; a plan outlives the graph handle's own
+    reference to the structure; and once the structure exists SSSP_ALL_ACTIVE -- the reference's schedule -- runs as blocked passes with the bits of
+    the atomic push kernel (VGL_SSSP_ALL_ACTIVE_PUSH=1) and of the oracle."""
+    import os
+    from vectorgraphlibrary_amd import api
+    O = oracle
+    V, seed = 1 << scale, 91
+    src, dst = (ctx.gen_rmat if kind == "rmat" else ctx.gen_uniform)(scale, ef, seed)
+    g = api.Graph.from_coo(ctx, V, src, dst, want_perm=True, renumber="total" if kind == "rmat" else None)
+    rowptr, adj = g.out_rowptr.cpu().numpy(), g.out_adj.cpu().numpy()
+    wa_d = ctx.gather_u32(g.perm, ctx.gen_weights(src.numel(), seed))
+    wb_d = ctx.gather_u32(g.perm, ctx.gen_weights(src.numel(), seed + 1))
+    wa, wb = wa_d.cpu().numpy(), wb_d.cpu().numpy()
+    assert not np.array_equal(wa, wb)
+    s = O.pick_source(rowptr, seed, 0)
+    ref_a, _ = O.sssp_bellman_ford(rowptr, adj, wa, s)
+    ref_b, _ = O.sssp_bellman_ford(rowptr, adj, wb, s)
+    d0, st0 = api.sssp(g, wa_d, s, api.SSSP_ALL_ACTIVE, raw=True)                 # no structure yet: the atomic push kernel
+    assert st0["pull_steps"] == 0 and (d0.cpu().numpy().view(np.int32) == ref_a.view(np.int32)).all()
+    if piece:
+        os.environ["VGL_BLK_PIECE_EDGES"] = piece                                 # the structure in row-range pieces (every piece keeps its own base)
+    try:
+        g.prepare_sssp()
+        pa, pb = api.SsspPullPlan(g, wa_d), api.SsspPullPlan(g, wb_d)
+        assert pa.info()["edges"] == src.numel() == pb.info()["edges"]
+        for plan, w_d, ref in ((pa, wa_d, ref_a), (pb, wb_d, ref_b), (pa, wa_d, ref_a)):
+            for mode in (api.SSSP_PULL, api.SSSP_DIRECTION_OPT):
+                d, st = api.sssp(g, w_d, s, mode, raw=True, plan=plan)
+                assert (d.cpu().numpy().view(np.int32) == ref.view(np.int32)).all(), mode
+        d1, st1 = api.sssp(g, wb_d, s, api.SSSP_ALL_ACTIVE, raw=True)             # routed: blocked passes
+        assert st1["pull_steps"] == st1["iterations"] > 0 and st1["push_steps"] == 0
+        assert (d1.cpu().numpy().view(np.int32) == ref_b.view(np.int32)).all()
+        os.environ["VGL_SSSP_ALL_ACTIVE_PUSH"] = "1"
+        try:
+            d2, st2 = api.sssp(g, wb_d, s, api.SSSP_ALL_ACTIVE, raw=True)
+        finally:
+            del os.environ["VGL_SSSP_ALL_ACTIVE_PUSH"]
+        assert st2["pull_steps"] == 0 and (d2.cpu().numpy().view(np.int32) == ref_b.view(np.int32)).all()
+        wd, _ = api.sswp(g, wa_d, s, api.SSSP_ALL_ACTIVE, raw=True)               # the widest-path algebra over the same structure
+        assert (wd.cpu().numpy().view(np.int32) == O.sswp_bellman_ford(rowptr, adj, wa, s)[0].view(np.int32)).all()
+    finally:
+        os.environ.pop("VGL_BLK_PIECE_EDGES", None)
+    pa.close()
+    g.close()                                                                     # the structure is still shared by pb: its last sharer frees it
+    pb.close()
 
 
 @pytest.mark.gpu

@@ -204,6 +204,11 @@ class Graph:
         _l.check(self.ctx.L.vgl_hip_pr_prepare(self.ctx.h, self.h, int(mode), C.byref(m)))
         return m.value
 
+    def prepare_sssp(self):
+        """build the blocked STRUCTURE of the path algorithms now (once per graph; vgl_hip_sssp_prepare): afterwards a pull plan for any weights
+        array is one gather pass and SSSP_ALL_ACTIVE runs as blocked passes"""
+        _l.check(self.ctx.L.vgl_hip_sssp_prepare(self.ctx.h, self.h))
+
     def prepare_cc(self):
         _l.check(self.ctx.L.vgl_hip_cc_prepare(self.ctx.h, self.h))
 
@@ -381,6 +386,16 @@ def page_rank(graph, iterations, indeg_noloops=None, ranks=None, raw=False, mode
     st = _l.PrStats()
     _l.check(ctx.L.vgl_hip_pr_run_mode(ctx.h, graph.h, _ptr(indeg_noloops), int(iterations), int(mode), _ptr(ranks), C.byref(st)))
     return (ranks if raw else graph.to_original(ranks)), _stats(st)
+
+
+def sum_over_edges(graph, values, bound=1.0):
+    """sums[src] = sum of values[dst] over the edges src -> dst with dst != src (graph's own numbering; the declared operator VGL_SUM_OVER_EDGES):
+    exact fixed-point sums rounded to f32 once.  values: non-negative f32, every per-vertex sum at most `bound`."""
+    ctx = graph.ctx
+    sums = ctx.empty(graph.V, torch.float32)
+    _l.check(ctx.L.vgl_hip_sum_over_edges_f32(ctx.h, graph.h, _ptr(values), C.c_float(float(bound)), _ptr(sums)))
+    ctx.sync()
+    return sums
 
 
 def strongly_connected_components(graph, raw=False):

@@ -1262,7 +1262,7 @@ static int vgl_bfs_bu_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *levels, 
                              const uint64_t *front, uint64_t *next, int64_t *seq_out, int heavy_blocks = VGL_BU_BLOCKS)
 {
     const int32_t chunk = (int32_t)(vgl_ceil_div(vgl_ceil_div(g->nrows, VGL_BU_BLOCKS), VGL_BLOCK) * VGL_BLOCK);
-    static const bool split = getenv("VGL_BU_SPLIT") && getenv("VGL_BU_SPLIT")[0] == '1';
+    const bool split = c->bfs.bu_split;
     const int64_t seq = vgl_next_seq(c);
     if (!split) {
         vgl_timed_launch tl(c, "bfs_bottom_up");
@@ -1371,6 +1371,8 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     const int64_t E = g->out.edges;
     const int64_t words = vgl_ceil_div(V, 64);
     if (source < 0 || source >= V) VGL_FAIL("bfs_run: source vertex out of range");
+    vgl_ctx_refresh_env(c);                                  // (a pass over the pointers of `environ`; the strings are parsed only when something was set since)
+    const vgl_bfs_tunables &tn = c->bfs;
     hipLaunchKernelGGL(vgl_k_bfs_init_all, dim3(vgl_grid(V)), dim3(VGL_BLOCK), 0, c->stream, V, source, d_levels, words, g->bm_visited, g->bm_front,
                        g->bm_next, g->tickets, reinterpret_cast<unsigned long long *>(c->d_counters + C_HEAVY));
 
@@ -1394,15 +1396,15 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     // vertex that arrives before the first store is visible issues its own: a 500 K-edge level took 170 us) -- and the scan it avoids is
     // cheaper (vgl_k_bfs_scan_bound: 13 us): V / 24 0.317 ms per traversal, V / 64 0.305, V / 256 0.3047, V / 1024 0.306, never 0.317.
     int64_t VGL_TD_EMIT_EDGES = std::max<int64_t>(65536, (int64_t)V / 256);
-    if (const char *e = getenv("VGL_TD_EMIT_EDGES")) VGL_TD_EMIT_EDGES = atoll(e);
+    if (tn.td_emit_edges >= 0) VGL_TD_EMIT_EDGES = tn.td_emit_edges;
     double td_filter_share = 0.125;
-    if (const char *e = getenv("VGL_TD_FILTER_SHARE")) td_filter_share = atof(e);
+    if (tn.td_filter_share >= 0.0) td_filter_share = tn.td_filter_share;
     // Late levels: once all but a few of the vertices that CAN be discovered (rows with incoming edges; known when the incoming CSR is stored)
     // are visited, an emitting level is cheap whatever its edge count -- its visited-bitmap probe turns almost every edge away before the
     // atomic -- and it leaves the next frontier as a bitmap (2 MiB to count) instead of only in `levels` (64 MiB to scan).  VGL_TD_LATE_SHARE:
     // "few" as a share of V (0 = rule off).
     double td_late_share = 1.0 / 64;
-    if (const char *e = getenv("VGL_TD_LATE_SHARE")) td_late_share = atof(e);
+    if (tn.td_late_share >= 0.0) td_late_share = tn.td_late_share;
     auto late = [&]() -> bool {          // evaluated when visited_total already holds the frontier about to be expanded
         if (g->in_nz_rows <= 0 || td_late_share <= 0.0) return false;
         const int64_t remain = std::max<int64_t>(0, (int64_t)g->in_nz_rows + 1 - visited_total);      // (+1: the source may have no incoming edge)
@@ -1410,16 +1412,16 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     };
     int bu_in_a_row = 0;                                 // bottom-up levels since the last top-down one
     int later_heavy_blocks = 256;                        // RMAT-24 traversal: 0.376 ms with 2048, 0.368-0.370 with 512 / 256 / 128
-    if (const char *e = getenv("VGL_BU_LATER_HEAVY_BLOCKS")) later_heavy_blocks = std::max(1, std::min(VGL_BU_BLOCKS, atoi(e)));
+    if (tn.later_heavy_blocks >= 0) later_heavy_blocks = std::max(1, std::min(VGL_BU_BLOCKS, tn.later_heavy_blocks));
     double blocked_share = 0.1;                          // top-down levels with at least this share of the edges take the blocked pass (when prepared;
                                                          // RMAT-24 top-down traversal: 1.83 ms at 0.2, 1.67 at 0.1, 1.66 at 0.05, 1.69 at 0.02)
-    if (const char *e = getenv("VGL_BFS_BLOCKED_SHARE")) blocked_share = atof(e);
+    if (tn.blocked_share >= 0.0) blocked_share = tn.blocked_share;
     // hint_ready: the launch that produced the frontier about to be counted left its F and M on the device (a counting top-down level, or
     // the list kernel leaving with a frontier too long for its list): the count launch may then skip everything but the bitmaps when the
     // rule turns the level bottom-up (`skipped`; the rule below must -- and does, same integers -- come to the same conclusion)
     bool hint_ready = false, skipped = false;
-    const bool use_hints = mode == VGL_HIP_BFS_DIRECTION_OPT && !(getenv("VGL_BFS_NO_HINT") && getenv("VGL_BFS_NO_HINT")[0] == '1');
-    const bool scan_bound = mode == VGL_HIP_BFS_DIRECTION_OPT && !(getenv("VGL_BFS_NO_SCAN_BOUND") && getenv("VGL_BFS_NO_SCAN_BOUND")[0] == '1');
+    const bool use_hints = mode == VGL_HIP_BFS_DIRECTION_OPT && !tn.no_hint;
+    const bool scan_bound = mode == VGL_HIP_BFS_DIRECTION_OPT && !tn.no_scan_bound;
     auto count_frontier = [&]() -> int {
         skipped = false;
         if (front_valid) {
@@ -1462,11 +1464,11 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     // small frontiers (the first and the last levels): several levels in one single-workgroup launch, vgl_k_bfs_small_levels.  The edge
     // bound also keeps the direction rule silent inside the kernel: it needs M >= ((V - visited) * factor + V) / ALPHA >= V / ALPHA.
     int64_t small_m = 8192;                              // 4096 .. 16384 measure the same on RMAT-24 (0.628 ms against 0.711 without, 0.646 at 65536)
-    if (const char *e = getenv("VGL_BFS_SMALL_M")) small_m = std::min<int64_t>(atoll(e), 1 << 20);     // (the kernel scans 32-bit degree sums)
+    if (tn.small_m >= 0) small_m = std::min<int64_t>(tn.small_m, 1 << 20);     // (the kernel scans 32-bit degree sums)
     if (mode == VGL_HIP_BFS_DIRECTION_OPT) small_m = std::min<int64_t>(small_m, (int64_t)V / VGL_DO_ALPHA - 1);
     if (small_m < 64) small_m = 0;                       // not worth a launch of its own
     // VGL_BFS_TRACE=1: one line per dispatch (level, frontier, edges, path taken, milliseconds since the start; every line synchronises)
-    const bool trace_on = getenv("VGL_BFS_TRACE") && getenv("VGL_BFS_TRACE")[0] == '1';
+    const bool trace_on = tn.trace;
     const auto trace_t0 = std::chrono::steady_clock::now();
     auto trace = [&](const char *what) {
         if (!trace_on) return;
@@ -1480,7 +1482,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
     unsigned long long *list_count = reinterpret_cast<unsigned long long *>(c->d_counters + C_HEAVY);      // slot unused by the fused traversal
     const unsigned bm_blocks = (unsigned)vgl_ceil_div(words, VGL_BLOCK);
     int64_t bm_expand_f = 262144;                        // bottom-up -> top-down switch: frontiers up to this size are expanded from the bitmap
-    if (const char *e = getenv("VGL_BFS_BM_EXPAND")) bm_expand_f = atoll(e);
+    if (tn.bm_expand >= 0) bm_expand_f = tn.bm_expand;
     if (bm_blocks > 8192) bm_expand_f = 0;               // (edge partials live in g->bu_partials: 4 * VGL_BU_BLOCKS slots)
     // from_bitmap: level `cur` is expanded from bm_front by vgl_k_bm_expand first, the list kernel starts at level cur + 1
     auto small_levels = [&](int32_t listF, int32_t src, bool from_bitmap = false) -> int {
@@ -1689,7 +1691,7 @@ int vgl_hip_bfs_step_top_down_bits(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_
     // afterwards: V * 4 bytes streamed against ~40 us per million edges of atomics (a 4.3 M-edge level of an RMAT-24 traversal: 180 us
     // with the atomics; the fused traversal draws the same line at V / 24 edges, VGL_TD_EMIT_EDGES)
     int64_t emit_edges = std::max<int64_t>(65536, (int64_t)g->V / 256);        // (round 4: as VGL_TD_EMIT_EDGES of the fused traversal)
-    if (const char *e = getenv("VGL_SHARD_TD_EMIT_EDGES")) emit_edges = atoll(e);
+    if (c->bfs.shard_td_emit_edges >= 0) emit_edges = c->bfs.shard_td_emit_edges;
     const bool emit = M <= emit_edges;
     const int64_t words = vgl_ceil_div(g->V, 64);
     if (emit) VGL_TRY(vgl_zero_words(c, d_next_bits, words));

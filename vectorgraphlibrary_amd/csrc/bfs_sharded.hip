@@ -200,7 +200,8 @@ extern "C" int vgl_hip_bfs_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_
     }
     // capacity of a rank's id list: lists pay while all of them together stay well below the V/8 bytes of a bitmap exchange
     int32_t sparse_cap = (int32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(4096, (int64_t)V / (128 * (int64_t)P)));
-    if (const char *e = getenv("VGL_SHARD_SPARSE_CAP")) sparse_cap = std::max(0, atoi(e));
+    vgl_ctx_refresh_env(c);
+    if (c->bfs.shard_sparse_cap >= 0) sparse_cap = c->bfs.shard_sparse_cap;
     if (!active) sparse_cap = 0;
     const int64_t nz_total = active ? bounds[(size_t)P + 1] : 0;         // rows with incoming edges, all ranks: what a bottom-up level can find at most
 

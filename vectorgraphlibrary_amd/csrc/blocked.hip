@@ -121,7 +121,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_nchunks(uint32_t nG, uint
 // one wavefront per A-order chunk: find its segment, place the chunk in both orders
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill(uint32_t nchunks, uint32_t nG, uint32_t nA, const uint32_t *a_start, const uint32_t *m_start,
                                                             const uint32_t *seg_first, const uint32_t *seg_end, const uint32_t *packed_sorted,
-                                                            const float *w_sorted, int a_bits, uint16_t *g_lo, uint16_t *a_lo, float *w_mid, uint32_t *mid_to_a)
+                                                            const uint32_t *idx_sorted, int a_bits, uint16_t *g_lo, uint16_t *a_lo, uint32_t *w_src_mid, uint32_t *mid_to_a)
 {
     const uint32_t nseg = nG * nA;
     const int lane = threadIdx.x & 63;
@@ -137,16 +137,16 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill(uint32_t nchunks, ui
         const uint32_t m = m_start[gb * nA + ab] + within;
         const uint32_t pos = within * VGL_CHUNK + lane, cnt = seg_end[k] - seg_first[k];
         uint16_t gl = 0, al = (uint16_t)((1u << a_bits) + lane);
-        float w = 0.0f;
+        uint32_t from = 0xFFFFFFFFu;                               // pad entry: no edge behind it
         if (pos < cnt) {
             const uint32_t pk = packed_sorted[seg_first[k] + pos];
             gl = (uint16_t)(pk & 0xFFFFu);
             al = (uint16_t)(pk >> 16);
-            if (w_sorted) w = w_sorted[seg_first[k] + pos];
+            if (idx_sorted) from = idx_sorted[seg_first[k] + pos];
         }
         g_lo[(size_t)m * VGL_CHUNK + lane] = gl;
         a_lo[(size_t)j * VGL_CHUNK + lane] = al;
-        if (w_mid) w_mid[(size_t)m * VGL_CHUNK + lane] = w;
+        if (w_src_mid) w_src_mid[(size_t)m * VGL_CHUNK + lane] = from;
         if (lane == 0) mid_to_a[m] = j;
     }
 }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill(uint32_t nchunks, ui
 // fused tiles: one wavefront per chunk; seg_chunk0[s] = first chunk of dense pair s (ascending, seg_chunk0[nsegs] = nchunks), seg_key[s] = its sort key
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill_fused(uint32_t nchunks, uint32_t nsegs, const uint32_t *seg_chunk0, const uint32_t *seg_key,
                                                                   const uint32_t *seg_first, const uint32_t *seg_end, const uint32_t *packed_sorted,
-                                                                  const float *w_sorted, uint16_t *g_lo, uint16_t *a_lo, float *w_out)
+                                                                  const uint32_t *idx_sorted, uint16_t *g_lo, uint16_t *a_lo, uint32_t *w_src)
 {
     const int lane = threadIdx.x & 63;
     for (uint32_t j = blockIdx.x * VGL_WAVES + (threadIdx.x >> 6); j < nchunks; j += gridDim.x * VGL_WAVES) {
@@ -166,16 +166,33 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_fill_fused(uint32_t nchun
         const uint32_t k = seg_key[lo];
         const uint32_t pos = (j - seg_chunk0[lo]) * VGL_CHUNK + lane, cnt = seg_end[k] - seg_first[k];
         uint16_t gl = 0, al = (uint16_t)(VGL_FBLK + lane);         // pad entries: x[0] folded into a dummy accumulator behind the window
-        float w = 0.0f;
+        uint32_t from = 0xFFFFFFFFu;
         if (pos < cnt) {
             const uint32_t pk = packed_sorted[seg_first[k] + pos];
             gl = (uint16_t)(pk & 0xFFFFu);
             al = (uint16_t)(pk >> 16);
-            if (w_sorted) w = w_sorted[seg_first[k] + pos];
+            if (idx_sorted) from = idx_sorted[seg_first[k] + pos];
         }
         g_lo[(size_t)j * VGL_CHUNK + lane] = gl;
         a_lo[(size_t)j * VGL_CHUNK + lane] = al;
-        if (w_out) w_out[(size_t)j * VGL_CHUNK + lane] = w;
+        if (w_src) w_src[(size_t)j * VGL_CHUNK + lane] = from;
+    }
+}
+
+// values of a layout from the CSR-order array they come from: out[slot] = weights[w_src[slot]] (0 behind pad entries); 16 bytes per lane and step
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_blk_load_weights(size_t slots, const uint32_t *w_src, const float *weights, float *out)
+{
+    const size_t quads = slots / 4;                                 // (slots is a multiple of VGL_CHUNK = 64)
+    for (size_t q = (size_t)blockIdx.x * VGL_BLOCK + threadIdx.x; q < quads; q += (size_t)gridDim.x * VGL_BLOCK) {
+        const uint4 from = reinterpret_cast<const uint4 *>(w_src)[q];
+        float4 w;
+        w.x = weights[from.x == 0xFFFFFFFFu ? 0 : from.x]; w.y = weights[from.y == 0xFFFFFFFFu ? 0 : from.y];      // (unconditional loads, issued together)
+        w.z = weights[from.z == 0xFFFFFFFFu ? 0 : from.z]; w.w = weights[from.w == 0xFFFFFFFFu ? 0 : from.w];
+        if (from.x == 0xFFFFFFFFu) w.x = 0.0f;
+        if (from.y == 0xFFFFFFFFu) w.y = 0.0f;
+        if (from.z == 0xFFFFFFFFu) w.z = 0.0f;
+        if (from.w == 0xFFFFFFFFu) w.w = 0.0f;
+        reinterpret_cast<float4 *>(out)[q] = w;
     }
 }
 
@@ -189,7 +206,7 @@ struct stage_trace {
     bool on;
     hipStream_t st;
     std::chrono::steady_clock::time_point t;
-    stage_trace(hipStream_t s) : on(getenv("VGL_BLK_BUILD_TRACE") != nullptr), st(s), t(std::chrono::steady_clock::now()) {}
+    stage_trace(vgl_hip_ctx *c, hipStream_t s) : on(vgl_env(c, "VGL_BLK_BUILD_TRACE") != nullptr), st(s), t(std::chrono::steady_clock::now()) {}
     void mark(const char *what)
     {
         if (!on) return;
@@ -200,9 +217,9 @@ struct stage_trace {
     }
 };
 
-int env_int(const char *name, int dflt)
+int env_int(vgl_hip_ctx *c, const char *name, int dflt)
 {
-    const char *s = getenv(name);
+    const char *s = vgl_env(c, name);
     return (s && *s) ? atoi(s) : dflt;
 }
 
@@ -233,10 +250,18 @@ void vgl_blocked_plan_destroy(vgl_blocked_plan *p)
 {
     if (!p) return;
     if (p->next) { vgl_blocked_plan_destroy(p->next); p->next = nullptr; }
+    if (p->shared) {                                                // a second set of value arrays over somebody else's structure
+        vgl_pool_free(p->stream, p->w_mid); vgl_pool_free(p->stream, p->f_w); vgl_pool_free(p->stream, p->g_dirty);
+        vgl_blocked_plan *s = p->shared_from;
+        delete p;
+        if (s && --s->sharers == 0 && s->orphan) { s->orphan = false; vgl_blocked_plan_destroy(s); }      // its owner is gone already
+        return;
+    }
+    if (p->sharers > 0) { p->orphan = true; return; }               // still in use by plans that share it: the last of them frees it
     if (p->piece_rowptr) hipFree(p->piece_rowptr);
     if (p->piece_tile_row) hipFree(p->piece_tile_row);
     void *ptrs[] = {p->g_lo, p->a_lo, p->w_mid, p->mid_to_a, p->vals, p->g_units, p->a_units, p->multi, p->slabs, p->g_dirty,
-                    p->f_g_lo, p->f_a_lo, p->f_w, p->f_segs, p->f_units};
+                    p->f_g_lo, p->f_a_lo, p->f_w, p->f_segs, p->f_units, p->w_src_mid, p->w_src_f};
     for (void *q : ptrs) vgl_pool_free(p->stream, q);
     delete p;
 }
@@ -245,8 +270,9 @@ void vgl_blocked_plan_destroy(vgl_blocked_plan *p)
 // nrows_total = rows of the whole direction)
 static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
                                       int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges,
-                                      int32_t row_off, int32_t nrows_total)
+                                      int32_t row_off, int32_t nrows_total, int keep_edge_index, int64_t w_base)
 {
+    if (d_weights) keep_edge_index = 1;
     if (value_bits != 32 && value_bits != 1) VGL_FAIL("blocked_plan_build: values are 32 bits or 1 bit per edge");
     if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
     if (a_bits != VGL_BLK_BITS && a_bits != VGL_BLK_BITS - 1) VGL_FAIL("blocked_plan_build: accumulate blocks hold 2^15 (4-byte) or 2^14 (8-byte) accumulators");
@@ -274,11 +300,11 @@ static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, in
     dev_bufs tmp;
     tmp.st = st;
     p->stream = st;
-    stage_trace trace(st);
+    stage_trace trace(c, st);
     std::unique_ptr<vgl_timed_launch> timed;
     uint32_t *keys = nullptr, *keys2 = nullptr, *packed = nullptr, *packed2 = nullptr, *seg_first = nullptr, *seg_end = nullptr;
     uint32_t *nch_a = nullptr, *nch_m = nullptr, *a_start = nullptr, *m_start = nullptr, *picked = nullptr;
-    float *w2 = nullptr;
+    uint32_t *idx2 = nullptr;                                       // CSR positions in sorted order (layouts with edge values)
     void *sort_tmp = nullptr;
     uint32_t *count16 = nullptr;
     VGL_HIP_TRY(tmp.alloc(&seg_first, (size_t)nkeys + 1));
@@ -320,20 +346,21 @@ static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, in
         VGL_HIP_TRY(tmp.alloc((char **)&sort_tmp, std::max<size_t>(need, 16)));
         VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need, keys, keys2, packed, packed2, (size_t)E, 0, bits, st));
         trace.mark("sort (block pair, packed ids)");
-        if (d_weights) {                                            // same keys, same stable sort: the weights land in the same order
+        if (keep_edge_index) {                                      // same keys, same stable sort: the CSR positions land in the order of the entries
             VGL_HIP_TRY(hipStreamSynchronize(st));
             tmp.release(packed);
             packed = nullptr;
-            VGL_HIP_TRY(tmp.alloc(&w2, (size_t)E));
+            VGL_HIP_TRY(tmp.alloc(&idx2, (size_t)E));
             size_t need2 = 0;
             uint32_t *keys3 = nullptr;
             VGL_HIP_TRY(tmp.alloc(&keys3, (size_t)E));
-            VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need2, keys, keys3, d_weights, w2, (size_t)E, 0, bits, st));
+            rocprim::counting_iterator<uint32_t> positions(0);
+            VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need2, keys, keys3, positions, idx2, (size_t)E, 0, bits, st));
             if (need2 > need) VGL_FAIL("blocked_plan_build: radix sort scratch grew between two calls of the same size");
-            VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need2, keys, keys3, d_weights, w2, (size_t)E, 0, bits, st));
+            VGL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, need2, keys, keys3, positions, idx2, (size_t)E, 0, bits, st));
             VGL_HIP_TRY(hipStreamSynchronize(st));
             tmp.release(keys3);
-            trace.mark("sort weights");
+            trace.mark("sort edge positions");
         }
         hipLaunchKernelGGL(vgl_k_blk_runs, dim3((unsigned)std::min<int64_t>(16384, vgl_ceil_div(E, VGL_BLOCK))), dim3(VGL_BLOCK), 0, st, E,
                            (const uint32_t *)keys2, seg_first, seg_end);
@@ -373,14 +400,18 @@ static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, in
     VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->a_lo, sizeof(uint16_t) * std::max<size_t>(slots, 8)));
     VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->vals, value_bits == 1 ? sizeof(uint64_t) * std::max<size_t>(p->nchunks, 1) : sizeof(uint32_t) * std::max<size_t>(slots, 8)));
     VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->mid_to_a, sizeof(uint32_t) * std::max<size_t>(p->nchunks, 1)));
-    if (d_weights) VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
+    if (keep_edge_index) {
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->w_src_mid, sizeof(uint32_t) * std::max<size_t>(slots, 8)));
+    }
+    p->w_base = w_base;
     VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->g_dirty, (size_t)nG));
     VGL_HIP_TRY(hipMemsetAsync(p->g_dirty, 1, (size_t)nG, st));
     trace.mark("allocate plan arrays");
     if (p->nchunks > 0) {
         hipLaunchKernelGGL(vgl_k_blk_fill, dim3((unsigned)std::min<int64_t>(65536, vgl_ceil_div(p->nchunks, VGL_WAVES))), dim3(VGL_BLOCK), 0, st, p->nchunks, nG, nA,
                            (const uint32_t *)a_start, (const uint32_t *)m_start, (const uint32_t *)seg_first, (const uint32_t *)seg_end,
-                           (const uint32_t *)packed2, (const float *)w2, a_bits, p->g_lo, p->a_lo, p->w_mid, p->mid_to_a);
+                           (const uint32_t *)packed2, (const uint32_t *)idx2, a_bits, p->g_lo, p->a_lo, p->w_src_mid, p->mid_to_a);
         VGL_HIP_TRY(hipGetLastError());
     }
     trace.mark("fill kernel");
@@ -389,7 +420,7 @@ static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, in
         // one workgroup must not be left alone with it), pieces grouped into units per gather block
         std::vector<uint32_t> cnt((size_t)nseg16);
         VGL_TRY(vgl_hip_memcpy_d2h(c, cnt.data(), count16, sizeof(uint32_t) * cnt.size()));
-        const uint32_t f_cap = (uint32_t)std::max(64, env_int("VGL_BLK_FUSED_UNIT", 4096));
+        const uint32_t f_cap = (uint32_t)std::max(64, env_int(c, "VGL_BLK_FUSED_UNIT", 4096));
         std::vector<uint32_t> seg_chunk0, seg_key;
         std::vector<vgl_blk_fseg> fsegs;
         std::vector<vgl_blk_funit> funits;
@@ -431,14 +462,17 @@ static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, in
             const size_t fslots = (size_t)chunk * VGL_CHUNK;
             VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_g_lo, sizeof(uint16_t) * fslots));
             VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_a_lo, sizeof(uint16_t) * fslots));
-            if (d_weights) VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_w, sizeof(float) * fslots));
+            if (keep_edge_index) {
+                VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_w, sizeof(float) * fslots));
+                VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->w_src_f, sizeof(uint32_t) * fslots));
+            }
             VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_segs, sizeof(vgl_blk_fseg) * fsegs.size()));
             VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&p->f_units, sizeof(vgl_blk_funit) * funits.size()));
             VGL_TRY(vgl_hip_memcpy_h2d(c, p->f_segs, fsegs.data(), sizeof(vgl_blk_fseg) * fsegs.size()));
             VGL_TRY(vgl_hip_memcpy_h2d(c, p->f_units, funits.data(), sizeof(vgl_blk_funit) * funits.size()));
             hipLaunchKernelGGL(vgl_k_blk_fill_fused, dim3((unsigned)std::min<int64_t>(65536, vgl_ceil_div(chunk, VGL_WAVES))), dim3(VGL_BLOCK), 0, st, chunk,
                                (uint32_t)seg_key.size(), (const uint32_t *)d_chunk0, (const uint32_t *)d_key, (const uint32_t *)seg_first, (const uint32_t *)seg_end,
-                               (const uint32_t *)packed2, (const float *)w2, p->f_g_lo, p->f_a_lo, p->f_w);
+                               (const uint32_t *)packed2, (const uint32_t *)idx2, p->f_g_lo, p->f_a_lo, p->w_src_f);
             VGL_HIP_TRY(hipGetLastError());
         }
         trace.mark("fused tiles (tables + fill)");
@@ -453,8 +487,8 @@ static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, in
     // (accumulate blocks up to 1.5x the average stay whole -- on a uniform graph every block is one unit and nothing goes through slabs --
     // but never beyond 16 K chunks = 1 M entries, ~0.25 ms of one CU's share of the HBM stream)
     const uint32_t avg_a = (uint32_t)(p->nchunks / nA);
-    const uint32_t g_cap = (uint32_t)std::max(64, env_int("VGL_BLK_GATHER_UNIT", 4096));
-    const uint32_t a_cap = (uint32_t)std::max(64, env_int("VGL_BLK_ACCUM_UNIT", (int)std::min<uint32_t>(16384, std::max<uint32_t>(4096, avg_a + avg_a / 2))));
+    const uint32_t g_cap = (uint32_t)std::max(64, env_int(c, "VGL_BLK_GATHER_UNIT", 4096));
+    const uint32_t a_cap = (uint32_t)std::max(64, env_int(c, "VGL_BLK_ACCUM_UNIT", (int)std::min<uint32_t>(16384, std::max<uint32_t>(4096, avg_a + avg_a / 2))));
     std::vector<vgl_blk_unit> gu, au;
     std::vector<vgl_blk_multi> multi, none;
     int dummy = 0;
@@ -472,6 +506,12 @@ static int vgl_blocked_plan_build_one(vgl_hip_ctx *c, const vgl_dir_csr &dir, in
     trace.mark("work units");
     tmp.free_all();
     trace.mark("free temporaries");
+    if (d_weights) {
+        p->next = nullptr;
+        VGL_TRY(vgl_blocked_plan_load_weights(c, p, d_weights - w_base));       // (load_weights takes the direction's array and adds the piece's base itself)
+        VGL_HIP_TRY(hipStreamSynchronize(st));
+        trace.mark("load weights");
+    }
     own.p = nullptr;
     *out = p;
     return 0;
@@ -482,15 +522,71 @@ __global__ void vgl_k_blk_rebase_rows(int32_t n, const int64_t *rowptr, int64_t 
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) out[i] = rowptr[i] - base;
 }
 
+int vgl_blocked_plan_load_weights(vgl_hip_ctx *c, vgl_blocked_plan *p, const float *d_weights)
+{
+    if (!c || !p || !d_weights) VGL_FAIL("blocked_plan_load_weights: null argument");
+    for (vgl_blocked_plan *q = p; q; q = q->next) {
+        if ((q->nchunks > 0 && (!q->w_src_mid || !q->w_mid)) || (q->f_nchunks > 0 && (!q->w_src_f || !q->f_w)))
+            VGL_FAIL("blocked_plan_load_weights: the layout was built without its edge index");
+        vgl_timed_launch tl(c, "blk_load_weights");
+        const size_t slots = (size_t)q->nchunks * VGL_CHUNK, fslots = (size_t)q->f_nchunks * VGL_CHUNK;
+        if (slots) hipLaunchKernelGGL(vgl_k_blk_load_weights, dim3((unsigned)std::min<size_t>(16384, (slots / 4 + VGL_BLOCK - 1) / VGL_BLOCK)), dim3(VGL_BLOCK), 0, c->stream,
+                                      slots, (const uint32_t *)q->w_src_mid, d_weights + q->w_base, q->w_mid);
+        if (fslots) hipLaunchKernelGGL(vgl_k_blk_load_weights, dim3((unsigned)std::min<size_t>(16384, (fslots / 4 + VGL_BLOCK - 1) / VGL_BLOCK)), dim3(VGL_BLOCK), 0, c->stream,
+                                       fslots, (const uint32_t *)q->w_src_f, d_weights + q->w_base, q->f_w);
+        VGL_HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int vgl_blocked_plan_share(vgl_hip_ctx *c, const vgl_blocked_plan *structure, vgl_blocked_plan **out)
+{
+    if (!c || !structure || !out) VGL_FAIL("blocked_plan_share: null argument");
+    vgl_blocked_plan *head = nullptr, *tail = nullptr;
+    struct guard { vgl_blocked_plan **h; ~guard() { if (*h) vgl_blocked_plan_destroy(*h); } } own{&head};
+    for (const vgl_blocked_plan *s = structure; s; s = s->next) {
+        if ((s->nchunks > 0 && !s->w_src_mid) || (s->f_nchunks > 0 && !s->w_src_f)) VGL_FAIL("blocked_plan_share: the layout was built without its edge index");
+        vgl_blocked_plan *q = new vgl_blocked_plan(*s);
+        q->shared = true; q->next = nullptr; q->w_mid = nullptr; q->f_w = nullptr; q->g_dirty = nullptr;
+        q->stream = c->stream;
+        if (tail) tail->next = q; else head = q;
+        tail = q;
+        const size_t slots = (size_t)q->nchunks * VGL_CHUNK, fslots = (size_t)q->f_nchunks * VGL_CHUNK;
+        VGL_HIP_TRY(vgl_pool_alloc(c->stream, (void **)&q->w_mid, sizeof(float) * std::max<size_t>(slots, 8)));
+        if (fslots) VGL_HIP_TRY(vgl_pool_alloc(c->stream, (void **)&q->f_w, sizeof(float) * fslots));
+        VGL_HIP_TRY(vgl_pool_alloc(c->stream, (void **)&q->g_dirty, (size_t)std::max(q->nG, 1)));
+        VGL_HIP_TRY(hipMemsetAsync(q->g_dirty, 1, (size_t)std::max(q->nG, 1), c->stream));
+    }
+    own.h = &tail; tail = nullptr;                                  // (disarm)
+    head->shared_from = const_cast<vgl_blocked_plan *>(structure);
+    const_cast<vgl_blocked_plan *>(structure)->sharers++;
+    *out = head;
+    return 0;
+}
+
+static int vgl_blocked_plan_build_any(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                                      int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges, int keep_edge_index);
+
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
                            int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges)
+{
+    return vgl_blocked_plan_build_any(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, d_weights ? 1 : 0);
+}
+int vgl_blocked_plan_build_indexed(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                                   int skip_self, int a_bits, vgl_blocked_plan **out, int fuse_min_edges)
+{
+    return vgl_blocked_plan_build_any(c, dir, nrows, row_base, ncols, gather_rows, skip_self, nullptr, a_bits, out, 32, fuse_min_edges, 1);
+}
+
+static int vgl_blocked_plan_build_any(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                                      int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits, int fuse_min_edges, int keep_edge_index)
 {
     if (!c || !out) VGL_FAIL("blocked_plan_build: null argument");
     // chunk positions are 32-bit: a direction is laid out whole below 2^32 - 2048 edges (VGL_BLK_PIECE_EDGES lowers the bound: tests)
     int64_t limit = (1LL << 32) - VGL_TILE;
     const bool cuttable = value_bits == 32 && a_bits == VGL_BLK_BITS;            // (the variable only lowers the bound of layouts that can be cut)
-    if (const char *e = getenv("VGL_BLK_PIECE_EDGES")) if (cuttable) limit = std::max<int64_t>(4096, atoll(e));
-    if (dir.edges < limit) return vgl_blocked_plan_build_one(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, 0, nrows);
+    if (const char *e = vgl_env(c, "VGL_BLK_PIECE_EDGES")) if (cuttable) limit = std::max<int64_t>(4096, atoll(e));
+    if (dir.edges < limit) return vgl_blocked_plan_build_one(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, 0, nrows, keep_edge_index, 0);
     if (!cuttable) VGL_FAIL("blocked_plan_build: only 4-byte min / max-type layouts can be cut into row-range pieces (2^32 edges or more)");
     // row ranges of at most `piece` edges each (a single row above the bound cannot be cut)
     const int64_t piece = std::min<int64_t>(limit, 1LL << 31);
@@ -515,13 +611,13 @@ int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows
         int rc = vgl_build_tile_rows(c, view, hi - lo);
         vgl_blocked_plan *q = nullptr;
         if (!rc) rc = vgl_blocked_plan_build_one(c, view, hi - lo, row_base, ncols, gather_rows, skip_self, d_weights ? d_weights + e0 : nullptr, a_bits, &q, value_bits,
-                                                 fuse_min_edges, lo, nrows);
+                                                 fuse_min_edges, lo, nrows, keep_edge_index, e0);
         if (rc) { hipFree(rp); if (view.tile_row) hipFree(view.tile_row); return rc; }
         q->piece_rowptr = rp; q->piece_tile_row = view.tile_row;
         if (tail) tail->next = q; else head = q;
         tail = q;
     }
-    if (!head) return vgl_blocked_plan_build_one(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, 0, nrows);
+    if (!head) return vgl_blocked_plan_build_one(c, dir, nrows, row_base, ncols, gather_rows, skip_self, d_weights, a_bits, out, value_bits, fuse_min_edges, 0, nrows, keep_edge_index, 0);
     *out = head;
     head = nullptr;
     return 0;

@@ -191,9 +191,9 @@ struct vgl_cc_blk_op {
 };
 
 // blocked from 2^25 stored edges (below that the labels sit in L2 and the atomic kernel needs fewer passes); VGL_CC_BLOCKED=0|1 overrides
-static bool vgl_cc_use_blocked(const vgl_hip_graph *g)
+static bool vgl_cc_use_blocked(vgl_hip_ctx *c, const vgl_hip_graph *g)
 {
-    const char *s = getenv("VGL_CC_BLOCKED");
+    const char *s = vgl_env(c, "VGL_CC_BLOCKED");
     if (s && *s) return atoi(s) != 0;
     return g->out.edges >= (1LL << 25);
 }
@@ -203,7 +203,7 @@ extern "C" int vgl_hip_cc_prepare(vgl_hip_ctx *c, vgl_hip_graph *g);
 int vgl_cc_hook_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *comp)
 {
     if (g->out.ntiles == 0) return 0;
-    if (vgl_cc_use_blocked(g)) {
+    if (vgl_cc_use_blocked(c, g)) {
         if (!g->blk_cc) VGL_TRY(vgl_hip_cc_prepare(c, g));      // dense pairs of 16384-id blocks as fused tiles (vgl_blocked.h): 4 B per edge streamed instead of 12
         const vgl_cc_blk_op op{comp, g->row_begin, c->d_counters};
         return vgl_blocked_pass<vgl_cc_blk_op, false, false>(c, g->blk_cc, op, "cc_hook_gather", "cc_hook_accumulate", false, "cc_hook_fused");
@@ -220,8 +220,8 @@ extern "C" {
 int vgl_hip_cc_prepare(vgl_hip_ctx *c, vgl_hip_graph *g)
 {
     if (!c || !g) VGL_FAIL("cc_prepare: null argument");
-    if (vgl_cc_use_blocked(g) && !g->blk_cc && g->out.ntiles > 0) {
-        const char *fm = getenv("VGL_BLK_FUSE_MIN");
+    if (vgl_cc_use_blocked(c, g) && !g->blk_cc && g->out.ntiles > 0) {
+        const char *fm = vgl_env(c, "VGL_BLK_FUSE_MIN");
         const int fuse_min = (fm && *fm) ? atoi(fm) : 16384;
         VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, nullptr, VGL_BLK_BITS, &g->blk_cc, 32, fuse_min));
     }

@@ -43,6 +43,47 @@ hipMemPool_t vgl_lib_pool(int device)
     return g_lib_pool[device];
 }
 
+extern char **environ;
+// setenv / putenv / unsetenv replace or move entries of `environ`: the pointers change, so a hash of the pointers tells whether anything was set
+// since the last look without reading a single string
+static uint64_t vgl_env_signature()
+{
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)(uintptr_t)environ;
+    if (environ) for (char **e = environ; *e; e++) h = (h ^ (uint64_t)(uintptr_t)*e) * 1099511628211ull;
+    return h ? h : 1;
+}
+void vgl_ctx_refresh_env(vgl_hip_ctx *c)
+{
+    const uint64_t sig = vgl_env_signature();
+    if (sig == c->env_signature) return;
+    c->env_signature = sig;
+    c->env.clear();
+    if (environ)
+        for (char **e = environ; *e; e++)
+            if (strncmp(*e, "VGL_", 4) == 0)
+                if (const char *eq = strchr(*e, '=')) c->env[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+    vgl_bfs_tunables t;
+    auto str = [&](const char *n) -> const char * { auto it = c->env.find(n); return it == c->env.end() ? nullptr : it->second.c_str(); };
+    auto on = [&](const char *n) { const char *v = str(n); return v && v[0] == '1'; };
+    if (const char *v = str("VGL_TD_EMIT_EDGES")) t.td_emit_edges = atoll(v);
+    if (const char *v = str("VGL_BFS_SMALL_M")) t.small_m = atoll(v);
+    if (const char *v = str("VGL_BFS_BM_EXPAND")) t.bm_expand = atoll(v);
+    if (const char *v = str("VGL_SHARD_TD_EMIT_EDGES")) t.shard_td_emit_edges = atoll(v);
+    if (const char *v = str("VGL_TD_FILTER_SHARE")) t.td_filter_share = atof(v);
+    if (const char *v = str("VGL_TD_LATE_SHARE")) t.td_late_share = atof(v);
+    if (const char *v = str("VGL_BFS_BLOCKED_SHARE")) t.blocked_share = atof(v);
+    if (const char *v = str("VGL_BU_LATER_HEAVY_BLOCKS")) t.later_heavy_blocks = atoi(v);
+    if (const char *v = str("VGL_SHARD_SPARSE_CAP")) t.shard_sparse_cap = std::max(0, atoi(v));
+    t.no_hint = on("VGL_BFS_NO_HINT"); t.no_scan_bound = on("VGL_BFS_NO_SCAN_BOUND"); t.trace = on("VGL_BFS_TRACE"); t.bu_split = on("VGL_BU_SPLIT");
+    c->bfs = t;
+}
+const char *vgl_env(vgl_hip_ctx *c, const char *name)
+{
+    vgl_ctx_refresh_env(c);
+    auto it = c->env.find(name);
+    return it == c->env.end() ? nullptr : it->second.c_str();
+}
+
 extern "C" {
 
 int vgl_hip_abi_version(void) { return VGL_HIP_ABI_VERSION; }
@@ -67,6 +108,7 @@ int vgl_hip_ctx_create(int device, void *stream, vgl_hip_ctx **out)
     VGL_HIP_TRY(hipMalloc((void **)&c->d_shards, sizeof(int64_t) * VGL_NSHARD));
     VGL_HIP_TRY(hipMemsetAsync(c->d_shards, 0, sizeof(int64_t) * VGL_NSHARD, c->stream));
     memset(c->h_counters, 0, sizeof(int64_t) * (C_NSLOTS + 8));
+    vgl_ctx_refresh_env(c);
     *out = c;
     return 0;
 }

@@ -214,18 +214,22 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
     void *temp = nullptr;
     size_t temp_bytes = 0, need = 0;
     // whatever is still allocated when the function leaves -- normally or through VGL_HIP_TRY on a failed allocation -- is freed (an
-    // out-of-memory in the middle of a scale-27 shard build must not leak the multi-GB temporaries of the piece before it)
+    // out-of-memory in the middle of a scale-27 shard build must not leak the multi-GB temporaries of the piece before it).
+    // Round 5: the temporaries (about 26 bytes per edge) come from the library's stream-ordered pool, like those of the plan builders: what the graph
+    // build has touched once is what the blocked-plan build of the same graph gets next -- the PageRank plan of uniform-25 paid 1.2 s for FRESH memory
+    // (first touch, ~14 ms per GB, and the allocator's stalls) in front of 60 ms of kernels while the build before it took and returned device memory directly
     struct cleanup {
+        hipStream_t st;
         int64_t *&a, *&b, *&c; int32_t *&d, *&e; void *&f;
-        ~cleanup() { for (void *p : {(void *)a, (void *)b, (void *)c, (void *)d, (void *)e, f}) if (p) hipFree(p); }
-    } guard{kept_idx, sorted_idx, d_nkept, keys, keys_sorted, temp};
-    VGL_HIP_TRY(hipMalloc((void **)&kept_idx, sizeof(int64_t) * (size_t)count));
-    VGL_HIP_TRY(hipMalloc((void **)&d_nkept, sizeof(int64_t)));
+        ~cleanup() { for (void *p : {(void *)a, (void *)b, (void *)c, (void *)d, (void *)e, f}) vgl_pool_free(st, p); }
+    } guard{st, kept_idx, sorted_idx, d_nkept, keys, keys_sorted, temp};
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&kept_idx, sizeof(int64_t) * (size_t)count));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&d_nkept, sizeof(int64_t)));
     rocprim::counting_iterator<int64_t> iota(0);
     vgl_in_range pred{d_src, row_begin, row_end};
     VGL_HIP_TRY(rocprim::select(nullptr, need, iota, kept_idx, (size_t *)d_nkept, (size_t)count, pred, st));
     temp_bytes = need;
-    VGL_HIP_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+    VGL_HIP_TRY(vgl_pool_alloc(st, &temp, temp_bytes ? temp_bytes : 16));
     VGL_HIP_TRY(rocprim::select(temp, temp_bytes, iota, kept_idx, (size_t *)d_nkept, (size_t)count, pred, st));
     int64_t nkept = 0;
     VGL_HIP_TRY(hipMemcpyAsync(&nkept, d_nkept, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -233,9 +237,9 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
     if (kept_out) *kept_out = nkept;
     if (nkept > 0) {
         // 2. keys = local rows, row histogram
-        VGL_HIP_TRY(hipMalloc((void **)&keys, sizeof(int32_t) * (size_t)nkept));
-        VGL_HIP_TRY(hipMalloc((void **)&keys_sorted, sizeof(int32_t) * (size_t)nkept));
-        VGL_HIP_TRY(hipMalloc((void **)&sorted_idx, sizeof(int64_t) * (size_t)nkept));
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&keys, sizeof(int32_t) * (size_t)nkept));
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&keys_sorted, sizeof(int32_t) * (size_t)nkept));
+        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&sorted_idx, sizeof(int64_t) * (size_t)nkept));
         hipLaunchKernelGGL(vgl_k_keys, dim3(vgl_grid_for(nkept)), dim3(VGL_BLOCK), 0, st, nkept, kept_idx, d_src, row_begin,
                            keys, (unsigned long long *)(d_rowptr + 1));
         VGL_HIP_TRY(hipGetLastError());
@@ -244,7 +248,7 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
         while (bits < 31 && (1LL << bits) < (int64_t)nrows) bits++;
         need = 0;
         VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys_sorted, kept_idx, sorted_idx, (size_t)nkept, 0, bits, st));
-        if (need > temp_bytes) { VGL_HIP_TRY(hipFree(temp)); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(hipMalloc(&temp, temp_bytes)); }
+        if (need > temp_bytes) { vgl_pool_free(st, temp); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(vgl_pool_alloc(st, &temp, temp_bytes)); }
         VGL_HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys, keys_sorted, kept_idx, sorted_idx, (size_t)nkept, 0, bits, st));
         // 4. adjacency + optional permutation
         hipLaunchKernelGGL(vgl_k_gather<int32_t>, dim3(vgl_grid_for(nkept)), dim3(VGL_BLOCK), 0, st, nkept, sorted_idx, d_dst, d_adj);
@@ -253,7 +257,7 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
         // 5. row offsets: inclusive scan of the histogram stored at rowptr[1..nrows]
         need = 0;
         VGL_HIP_TRY(rocprim::inclusive_scan(nullptr, need, d_rowptr + 1, d_rowptr + 1, (size_t)nrows, rocprim::plus<int64_t>(), st));
-        if (need > temp_bytes) { VGL_HIP_TRY(hipFree(temp)); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(hipMalloc(&temp, temp_bytes)); }
+        if (need > temp_bytes) { vgl_pool_free(st, temp); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(vgl_pool_alloc(st, &temp, temp_bytes)); }
         VGL_HIP_TRY(rocprim::inclusive_scan(temp, need, d_rowptr + 1, d_rowptr + 1, (size_t)nrows, rocprim::plus<int64_t>(), st));
     }
     VGL_HIP_TRY(hipStreamSynchronize(st));
@@ -292,16 +296,17 @@ int vgl_hip_degree_order_from_degrees(vgl_hip_ctx *c, int32_t V, const uint32_t 
     void *temp = nullptr;
     size_t need = 0;
     struct cleanup {
+        hipStream_t st;
         uint32_t *&a, *&b; int32_t *&c; void *&d;
-        ~cleanup() { for (void *p : {(void *)a, (void *)b, (void *)c, d}) if (p) hipFree(p); }
-    } guard{keys, keys_out, ids, temp};
-    VGL_HIP_TRY(hipMalloc((void **)&keys, sizeof(uint32_t) * (size_t)V));
-    VGL_HIP_TRY(hipMalloc((void **)&keys_out, sizeof(uint32_t) * (size_t)V));
-    VGL_HIP_TRY(hipMalloc((void **)&ids, sizeof(int32_t) * (size_t)V));
+        ~cleanup() { for (void *p : {(void *)a, (void *)b, (void *)c, d}) vgl_pool_free(st, p); }
+    } guard{st, keys, keys_out, ids, temp};
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&keys, sizeof(uint32_t) * (size_t)V));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&keys_out, sizeof(uint32_t) * (size_t)V));
+    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&ids, sizeof(int32_t) * (size_t)V));
     hipLaunchKernelGGL(vgl_k_order_keys, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, st, V, deg, keys, ids);
     VGL_HIP_TRY(hipGetLastError());
     VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys_out, ids, d_bwd, (size_t)V, 0, 32, st));
-    VGL_HIP_TRY(hipMalloc(&temp, need ? need : 16));
+    VGL_HIP_TRY(vgl_pool_alloc(st, &temp, need ? need : 16));
     VGL_HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys, keys_out, ids, d_bwd, (size_t)V, 0, 32, st));
     hipLaunchKernelGGL(vgl_k_invert, dim3(vgl_grid_for(V)), dim3(VGL_BLOCK), 0, st, V, d_bwd, d_fwd);
     VGL_HIP_TRY(hipGetLastError());

@@ -358,6 +358,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     if (g->blk_pr) { vgl_blocked_plan_destroy(g->blk_pr); g->blk_pr = nullptr; }
     if (g->blk_cc) { vgl_blocked_plan_destroy(g->blk_cc); g->blk_cc = nullptr; }
     if (g->blk_bfs) { vgl_blocked_plan_destroy(g->blk_bfs); g->blk_bfs = nullptr; }
+    if (g->blk_path) { vgl_blocked_plan_destroy(g->blk_path); g->blk_path = nullptr; }
     void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->in_nz_rank, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
                     g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->out.hub_rows, g->in.hub_rows, g->out.giant_rows, g->in.giant_rows, g->out.pull_blk_row,

@@ -149,7 +149,7 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
     VGL_HIP_TRY(hipGetLastError());
     VGL_TRY(vgl_hip_memcpy_d2h(c, &dir.nhubs, d_count, sizeof(int32_t)));
     const size_t n = (size_t)dir.nhubs;
-    const int hub_blocks_cap = getenv("VGL_PULL_HUB_BLOCKS") ? std::max(1, atoi(getenv("VGL_PULL_HUB_BLOCKS"))) : VGL_PULL_HUB_BLOCKS;
+    const int hub_blocks_cap = vgl_env(c, "VGL_PULL_HUB_BLOCKS") ? std::max(1, atoi(vgl_env(c, "VGL_PULL_HUB_BLOCKS"))) : VGL_PULL_HUB_BLOCKS;
     dir.hub_blocks = n ? (int)std::min<int64_t>(hub_blocks_cap, vgl_ceil_div((int64_t)n, VGL_WAVES)) : 0;
     const int W = dir.hub_blocks * VGL_WAVES;
     // device layout: [n hub rows grouped by wavefront][W+1 offsets]
@@ -162,10 +162,10 @@ int vgl_pull_find_hubs(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_dir_csr &dir)
         std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return deg[x] != deg[y] ? deg[x] > deg[y] : rows[x] < rows[y]; });
         // giants (vgl_pull.h): the longest rows go to whole workgroups, longest-processing-time over at most VGL_PULL_GIANT_BLOCKS of them
         size_t ng = 0;
-        const int giant_degree = getenv("VGL_PULL_GIANT_DEGREE") ? atoi(getenv("VGL_PULL_GIANT_DEGREE")) : VGL_PULL_GIANT_DEGREE;
+        const int giant_degree = vgl_env(c, "VGL_PULL_GIANT_DEGREE") ? atoi(vgl_env(c, "VGL_PULL_GIANT_DEGREE")) : VGL_PULL_GIANT_DEGREE;
         while (ng < n && deg[order[ng]] >= giant_degree) ng++;
-        if (getenv("VGL_PULL_NO_GIANTS")) ng = 0;
-        if (getenv("VGL_PULL_TRACE")) {
+        if (vgl_env(c, "VGL_PULL_NO_GIANTS")) ng = 0;
+        if (vgl_env(c, "VGL_PULL_TRACE")) {
             int64_t ge = 0, he = 0;
             for (size_t i = 0; i < n; i++) (i < ng ? ge : he) += deg[order[i]];
             fprintf(stderr, "[vgl pull] %zu hubs (%lld entries), %zu giants (%lld entries, largest %d)\n", n, (long long)(ge + he), ng, (long long)ge, n ? deg[order[0]] : 0);
@@ -304,12 +304,37 @@ struct vgl_pr_blk_op {
     }
 };
 
+// The declared operator VGL_SUM_OVER_EDGES (hip/vgl_hip.hpp): sums[src] = sum of values[dst] over the edges src -> dst, dst != src -- the pull of
+// pr.hpp:109-123 with the caller's own arrays.  Same fixed-point accumulation as vgl_pr_blk_op, the unit scaled by the caller's bound on a
+// per-vertex sum (rounded up to a power of two, so the scaling is exact); the epilogue stores the sum, the caller's post operator does the rest.
+struct vgl_sum_blk_op {
+    typedef unsigned long long acc_t;
+    static constexpr bool MARK = false;
+    const float *values;
+    float *sums;
+    int32_t a_base;
+    int bound_exp;                                          // per-vertex sums stay below 2^bound_exp
+    __device__ __forceinline__ uint32_t load(int32_t i) const { return __float_as_uint(values[i]); }
+    __device__ __forceinline__ uint32_t edge(uint32_t x, float) const { return x; }
+    __device__ __forceinline__ acc_t identity() const { return 0ull; }
+    __device__ __forceinline__ void accumulate(acc_t *p, uint32_t bits) const
+    {
+        const int ex = (int)(bits >> 23) & 0xFF;
+        const unsigned long long m = (unsigned long long)((bits & 0x7FFFFFu) | (ex ? 0x800000u : 0u));
+        const int sh = (ex ? ex : 1) - 150 + 62 - bound_exp;
+        __hip_atomic_fetch_add(p, sh >= 0 ? m << sh : (sh > -24 ? m >> -sh : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ acc_t combine(acc_t a, acc_t b) const { return a + b; }
+    __device__ __forceinline__ bool partial(int32_t, acc_t) const { return false; }
+    __device__ __forceinline__ void finish(int32_t i, acc_t acc) const { sums[a_base + i] = (float)ldexp((double)acc, bound_exp - 62); }
+};
+
 // VGL_PR_MODE=0|1 overrides AUTO (anything else is refused)
-int vgl_pr_env_mode(int mode, int *out)
+int vgl_pr_env_mode(vgl_hip_ctx *c, int mode, int *out)
 {
     *out = mode;
     if (mode != VGL_HIP_PR_AUTO) return 0;
-    const char *s = getenv("VGL_PR_MODE");
+    const char *s = vgl_env(c, "VGL_PR_MODE");
     if (!s || !*s) return 0;
     if ((s[0] != '0' && s[0] != '1') || s[1] != 0) VGL_FAIL("VGL_PR_MODE must be 0 (ordered chain) or 1 (blocked exact sums)");
     *out = s[0] - '0';
@@ -344,7 +369,7 @@ int vgl_pr_longest_row(vgl_hip_ctx *c, vgl_hip_graph *g, int64_t *out)
 
 static int vgl_pr_mode_auto(vgl_hip_ctx *c, vgl_hip_graph *g, int *mode)
 {
-    VGL_TRY(vgl_pr_env_mode(*mode, mode));
+    VGL_TRY(vgl_pr_env_mode(c, *mode, mode));
     if (*mode != VGL_HIP_PR_AUTO) return 0;
     *mode = VGL_HIP_PR_EXACT_ORDER;
     if (g->out.edges < (1LL << 25)) return 0;
@@ -406,6 +431,19 @@ int vgl_hip_indegree_noloops_add(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *d_in
                        g->out.tile_row, g->out.edges, g->row_begin, d_indeg);
     VGL_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int vgl_hip_sum_over_edges_f32(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_values, float sum_bound, float *d_sums)
+{
+    if (!c || !g || !d_values || !d_sums) VGL_FAIL("sum_over_edges: null argument");
+    if (d_values == d_sums) VGL_FAIL("sum_over_edges: the sums cannot be written over the values they are formed from");
+    if (!(sum_bound > 0.0f) || !(sum_bound <= 0x1p60f)) VGL_FAIL("sum_over_edges: the bound of a per-vertex sum must be positive (and at most 2^60)");
+    int bound_exp = 0;
+    (void)frexpf(sum_bound, &bound_exp);                    // sum_bound = m * 2^bound_exp, 0.5 <= m < 1: sums < 2^bound_exp, one spare bit on top
+    bound_exp += 1;
+    if (!g->blk_pr) VGL_TRY(vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 0, 1, nullptr, VGL_BLK_BITS - 1, &g->blk_pr));
+    const vgl_sum_blk_op op{d_values, d_sums, g->row_begin, bound_exp};
+    return vgl_blocked_pass<vgl_sum_blk_op, false, true>(c, g->blk_pr, op, "sum_blk_gather", "sum_blk_accumulate");
 }
 
 int vgl_hip_pr_setup(vgl_hip_ctx *c, int32_t V, const int32_t *d_indeg, float *d_ranks, float *d_rdeg)

@@ -122,7 +122,7 @@ int vgl_hip_pr_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g
     const int32_t V = g->V;
     const int P = m->world;
     // AUTO is resolved ONCE from global numbers, so that every rank takes the same evaluation whatever its shard looks like
-    VGL_TRY(vgl_pr_env_mode(mode, &mode));
+    VGL_TRY(vgl_pr_env_mode(c, mode, &mode));
     int64_t global_edges = g->out.edges;
     if (mode == VGL_HIP_PR_AUTO) {
         int64_t longest = 0;

@@ -324,7 +324,7 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     if (g->row_begin != 0 || g->row_end != g->V) return fail("graph handle must own all rows");
     if (source < 0 || source >= g->V) return fail("source vertex out of range");
     if (mode != VGL_HIP_SSSP_PULL && mode != VGL_HIP_SSSP_DIRECTION_OPT) return fail("unknown mode");
-    const char *env = getenv("VGL_SSSP_PULL_SHARE");
+    const char *env = vgl_env(c, "VGL_SSSP_PULL_SHARE");
     const double share = (env && *env) ? atof(env) : 0.2;       // pull when the rows that changed own more than this share of the edges (with the fused-tile
                                                                 // pass, RMAT-24, mean of 5 sources: 0.1 15.5 ms, 0.15 15.4, 0.2 15.35, 0.25 15.6, 0.35 15.9, 0.5 17.6)
     hipLaunchKernelGGL(vgl_k_sssp_init<Path>, dim3(vgl_grid1(g->V)), dim3(VGL_BLOCK), 0, c->stream, g->V, source, d_dist, (int32_t *)nullptr);
@@ -335,7 +335,7 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     // instead of the V * 4 of an epoch array (two 50 us scans per step of RMAT-24 before, 2.8 of 17.7 ms).  An empty frontier ends the run
     // (do { ... } while(changes), shortest_paths.hpp:112-154); its edge share picks the direction of a DIRECTION_OPT step.
     const int64_t words = vgl_ceil_div(g->V, 64);
-    const bool debug = getenv("VGL_HIP_DEBUG") != nullptr;
+    const bool debug = vgl_env(c, "VGL_HIP_DEBUG") != nullptr;
     uint64_t *front = g->bm_front, *next = g->bm_next;
     hipLaunchKernelGGL(vgl_k_sssp_seed_bits, dim3(vgl_grid1(words)), dim3(VGL_BLOCK), 0, c->stream, words, source, front, next);
     for (int32_t iter = 1;; iter++) {
@@ -370,18 +370,39 @@ static int vgl_path_run_pull(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     return 0;
 }
 
+// the path structure of a graph (vgl_hip_graph::blk_path), built on first use and rebuilt when a layout switch changed since
+static int vgl_path_structure(vgl_hip_ctx *c, vgl_hip_graph *g)
+{
+    // pairs of 16384-id blocks with at least VGL_BLK_FUSE_MIN (16384) edges become fused tiles (vgl_blocked.h): on a degree-sorted RMAT graph
+    // 82 % of the edges, streamed at 8 instead of 16 bytes each (RMAT-24 pull pass 1.70 -> 1.10 ms; 2048: 94 % fused but 1.78 ms,
+    // the sweep over a tile's 16384 accumulators then costs more than its edges; 65536: 71 %, 1.11 ms; 262144: 52 %, 1.30 ms).  Graphs below 2^22 edges stay two-pass unless the variable is set.
+    const char *fm = vgl_env(c, "VGL_BLK_FUSE_MIN");
+    const int fuse_min = (fm && *fm) ? atoi(fm) : (g->out.edges >= (1LL << 22) ? 16384 : 0);
+    std::string key = std::to_string(fuse_min);
+    for (const char *name : {"VGL_BLK_GATHER_UNIT", "VGL_BLK_ACCUM_UNIT", "VGL_BLK_FUSED_UNIT", "VGL_BLK_PIECE_EDGES"}) {
+        const char *v = vgl_env(c, name);
+        key += "|"; key += v ? v : "";
+    }
+    if (g->blk_path && g->blk_path_key == key) return 0;
+    if (g->blk_path) { VGL_HIP_TRY(hipStreamSynchronize(c->stream)); vgl_blocked_plan_destroy(g->blk_path); g->blk_path = nullptr; }
+    VGL_TRY(vgl_blocked_plan_build_indexed(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, VGL_BLK_BITS, &g->blk_path, fuse_min));
+    g->blk_path_key = key;
+    return 0;
+}
+
 static int vgl_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan **out)
 {
     if (!c || !g || !d_weights || !out) VGL_FAIL("sssp_pull_plan_create: null argument");
     vgl_hip_sssp_pull_plan *p = new vgl_hip_sssp_pull_plan();
     p->g = g; p->g_uid = g->uid; p->weights = d_weights;
-    // pairs of 16384-id blocks with at least VGL_BLK_FUSE_MIN (16384) edges become fused tiles (vgl_blocked.h): on a degree-sorted RMAT graph
-    // 82 % of the edges, streamed at 8 instead of 16 bytes each (RMAT-24 pull pass 1.70 -> 1.10 ms; 2048: 94 % fused but 1.78 ms,
-    // the sweep over a tile's 16384 accumulators then costs more than its edges; 65536: 71 %, 1.11 ms; 262144: 52 %, 1.30 ms).  Graphs below 2^22 edges stay two-pass unless the variable is set.
-    const char *fm = getenv("VGL_BLK_FUSE_MIN");
-    const int fuse_min = (fm && *fm) ? atoi(fm) : (g->out.edges >= (1LL << 22) ? 16384 : 0);
-    const int rc = vgl_blocked_plan_build(c, g->out, g->nrows, g->row_begin, g->V, 1, 0, d_weights, VGL_BLK_BITS, &p->blk, 32, fuse_min);
-    if (rc) { delete p; return rc; }
+    // Round 5: the layout is a per-GRAPH structure (one radix sort of the edges by block pair, the CSR position behind every value slot kept -- the
+    // role of the reference's edges_reorder_indexes, csr_edges_array.hpp:31-40) plus per-WEIGHTS value arrays filled by one gather pass: a second
+    // weights array on the same graph costs ~3 ms instead of the 37 ms of a full build (RMAT-24)
+    int rc = vgl_path_structure(c, g);
+    if (!rc) rc = vgl_blocked_plan_share(c, g->blk_path, &p->blk);
+    if (!rc) rc = vgl_blocked_plan_load_weights(c, p->blk, d_weights);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = vgl_set_error(__FILE__, __LINE__, "sssp_pull_plan_create: the weights pass failed");
+    if (rc) { if (p->blk) vgl_blocked_plan_destroy(p->blk); delete p; return rc; }
     *out = p;
     return 0;
 }
@@ -395,7 +416,14 @@ static int vgl_path_run(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights
     if (!c || !g || !d_weights || !d_dist) return fail("null argument");
     if (g->row_begin != 0 || g->row_end != g->V) return fail("graph handle must own all rows (use the *_relax_owned step for shards)");
     if (source < 0 || source >= g->V) return fail("source vertex out of range");
-    if (mode == VGL_HIP_SSSP_PULL || mode == VGL_HIP_SSSP_DIRECTION_OPT) {      // one-off: build the blocked layout, run, drop it
+    // the reference's own schedule -- every edge relaxed in every super-step until one changes nothing (shortest_paths.hpp:112-154) -- runs as blocked
+    // passes once the graph carries the path structure (vgl_hip_sssp_prepare, or any pull plan built before): the same fixed point, hence the same
+    // bits, at the rate of the LDS-window pass instead of one atomic and one random line per edge.  VGL_SSSP_ALL_ACTIVE_PUSH=1 keeps the atomic kernel.
+    if (mode == VGL_HIP_SSSP_ALL_ACTIVE && g->blk_path) {
+        const char *push = vgl_env(c, "VGL_SSSP_ALL_ACTIVE_PUSH");
+        if (!(push && push[0] == '1')) mode = VGL_HIP_SSSP_PULL;
+    }
+    if (mode == VGL_HIP_SSSP_PULL || mode == VGL_HIP_SSSP_DIRECTION_OPT) {      // one-off: the layout's value arrays for these weights (the structure stays with the graph)
         vgl_hip_sssp_pull_plan *plan = nullptr;
         VGL_TRY(vgl_pull_plan_create(c, g, d_weights, &plan));
         const int rc = vgl_path_run_pull<Path>(c, g, d_weights, plan, source, mode, d_dist, stats, who);
@@ -431,6 +459,15 @@ int vgl_sssp_relax_enqueue(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weig
 }
 
 extern "C" {
+
+int vgl_hip_sssp_prepare(vgl_hip_ctx *c, vgl_hip_graph *g)
+{
+    if (!c || !g) VGL_FAIL("sssp_prepare: null argument");
+    if (g->row_begin != 0 || g->row_end != g->V) VGL_FAIL("sssp_prepare: graph handle must own all rows");
+    VGL_TRY(vgl_path_structure(c, g));
+    VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
 
 int vgl_hip_sssp_pull_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_weights, vgl_hip_sssp_pull_plan **out)
 {

@@ -777,10 +777,14 @@ int vgl_hip_sssp_plan_create(vgl_hip_ctx *c, vgl_hip_graph *g, const float *d_we
     // ten passes of 0.5 ms instead of five sweeps of 0.5 - 0.9 ms over the active rows' edges (RMAT-24: 11.5 ms per run with both parts
     // blocked against 11.85 with none); the heavy step runs once per bucket over nearly all of its part: 3.37 -> 1.27 ms.
     {
-        const char *e = getenv("VGL_DS_BLOCKED");
+        const char *e0 = vgl_env(c, "VGL_DS_BLOCKED");
+        const std::string e_keep = e0 ? e0 : "";
+        const char *e = e0 ? e_keep.c_str() : nullptr;
         const int level = (e && *e) ? atoi(e) : (E >= (1LL << 25) ? 1 : 0);
         const bool want = level > 0;
-        const char *fm = getenv("VGL_BLK_FUSE_MIN");
+        const char *fm0 = vgl_env(c, "VGL_BLK_FUSE_MIN");
+        const std::string fm_keep = fm0 ? fm0 : "";
+        const char *fm = fm0 ? fm_keep.c_str() : nullptr;
         for (int k = level >= 2 ? 0 : 1; k < 2 && want; k++) {
             if (part_edges[k] < (1LL << 20) && !(e && *e)) continue;
             const int fuse_min = (fm && *fm) ? atoi(fm) : (part_edges[k] >= (1LL << 22) ? 16384 : 0);
@@ -812,7 +816,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     if (source < 0 || source >= g->V) VGL_FAIL("sssp_run_plan: source vertex out of range");
     const int32_t V = g->V;
     hipStream_t st = c->stream;
-    const bool debug = getenv("VGL_HIP_DEBUG") != nullptr;
+    const bool debug = vgl_env(c, "VGL_HIP_DEBUG") != nullptr;
     hipLaunchKernelGGL(vgl_k_ds_init, dim3(vgl_ds_grid(V, 8192)), dim3(VGL_BLOCK), 0, st, V, source, d_dist, p->state);
     vgl_hip_sssp_stats s = {0, 0, 0};
     float T = p->delta;
@@ -824,7 +828,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     // dense = sweep the whole part as static tiles (rows marked in p->active) instead of walking a compacted frontier: chosen by
     // the caller from a PREDICTION of the step's size, so a wrong guess only costs time
     unsigned long long *cursor = reinterpret_cast<unsigned long long *>(p->partials + 1024 + VGL_DS_BLOCKS + 1);
-    const bool wide_select = getenv("VGL_DS_WIDE") ? atoi(getenv("VGL_DS_WIDE")) != 0 : true;     // 0: count + scan + write (+ the small-step selection)
+    const bool wide_select = vgl_env(c, "VGL_DS_WIDE") ? atoi(vgl_env(c, "VGL_DS_WIDE")) != 0 : true;     // 0: count + scan + write (+ the small-step selection)
     auto step = [&](uint8_t bit, bool dense, bool small) -> int {
         const int k = bit == 1 ? 0 : 1;                     // which part this step walks
         if (dense && p->part[k].ntiles > 0) {
@@ -881,7 +885,7 @@ int vgl_hip_sssp_run_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_sssp_plan *p
     // bucket width: delta, multiplied by 16 after every bucket that relaxed fewer than E/16 edges (the sparse tail: fewer steps).  Narrower buckets in the dense core were measured
     // (W0 = 1/4 .. 1/16): 10 % fewer relaxed edges but 2-3x the steps, i.e. slower -- the per-step passes dominate.  The
     // light/heavy edge split always uses the plan's delta.  Any width is correct, it only changes the amount of re-relaxation.
-    auto envf = [](const char *n, double dflt) { const char *v = getenv(n); return v ? atof(v) : dflt; };
+    auto envf = [c](const char *n, double dflt) { const char *v = vgl_env(c, n); return v ? atof(v) : dflt; };
     float width = (float)(p->delta * envf("VGL_DS_W0", 1.0));
     const int64_t rows_hi = (int64_t)envf("VGL_DS_HI", 1.0e18), rows_lo = (int64_t)envf("VGL_DS_LO", 4096.0);
     T = width;

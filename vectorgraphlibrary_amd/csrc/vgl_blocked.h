@@ -94,6 +94,16 @@ struct vgl_blocked_plan {
     vgl_blocked_plan *next = nullptr;
     int64_t *piece_rowptr = nullptr;             // the piece's rebased row offsets and tile table (owned; null for a whole-direction plan)
     int32_t *piece_tile_row = nullptr;
+    // Edge values (round 5).  The STRUCTURE above depends on the graph alone; a layout that carries edge values also keeps, per slot of w_mid / f_w,
+    // the CSR position its value comes from (0xFFFFFFFF: a pad entry) -- the counterpart of the reference's edges_reorder_indexes, from which every
+    // weight layout is derived (csr_edges_array.hpp:31-40).  Loading another weights array is then one gather pass (vgl_blocked_plan_load_weights)
+    // instead of a second radix sort, and several value arrays can share one structure (vgl_blocked_plan_share).
+    uint32_t *w_src_mid = nullptr, *w_src_f = nullptr;
+    int64_t w_base = 0;                          // CSR position of the piece's first edge (a piece indexes the direction's weights from there)
+    bool shared = false;                         // everything but w_mid / f_w / g_dirty belongs to the plan this one was shared from
+    vgl_blocked_plan *shared_from = nullptr;     // (head of a shared chain only) the structure's head
+    int sharers = 0;                             // (structure head) plans that share it; a structure destroyed while shared is freed by its last sharer
+    bool orphan = false;
 };
 
 // Build the plan from one CSR direction.  gather_rows = 0: x is indexed by the adjacency ids (range `ncols`), y by the local rows;
@@ -105,6 +115,13 @@ struct vgl_blocked_plan {
 // fused tiles.
 int vgl_blocked_plan_build(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
                            int skip_self, const float *d_weights, int a_bits, vgl_blocked_plan **out, int value_bits = 32, int fuse_min_edges = 0);
+// keep_edge_index != 0 (implied by d_weights): the layout keeps the CSR position behind every value slot, see vgl_blocked_plan::w_src_mid
+int vgl_blocked_plan_build_indexed(vgl_hip_ctx *c, const vgl_dir_csr &dir, int32_t nrows, int32_t row_base, int32_t ncols, int gather_rows,
+                                   int skip_self, int a_bits, vgl_blocked_plan **out, int fuse_min_edges);
+// (re)fills the value arrays of a layout that keeps its edge index from d_weights (f32 per CSR position of the direction): one gather pass
+int vgl_blocked_plan_load_weights(vgl_hip_ctx *c, vgl_blocked_plan *p, const float *d_weights);
+// a second set of value arrays over the structure of `structure` (which must outlive the result and keep its edge index)
+int vgl_blocked_plan_share(vgl_hip_ctx *c, const vgl_blocked_plan *structure, vgl_blocked_plan **out);
 void vgl_blocked_plan_destroy(vgl_blocked_plan *p);
 static inline int64_t vgl_blocked_plan_edges(const vgl_blocked_plan *p) { int64_t e = 0; for (; p; p = p->next) e += p->edges; return e; }
 

@@ -76,7 +76,7 @@ int vgl_cc_hook_launch(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t *comp);
 int vgl_pr_iteration(vgl_hip_ctx *c, vgl_hip_graph *g, const int32_t *indeg, const float *rdeg, float *ranks, float *contrib,
                      float *ranks_out, int mode);
 int vgl_pr_longest_row(vgl_hip_ctx *c, vgl_hip_graph *g, int64_t *out);
-int vgl_pr_env_mode(int mode, int *out);
+int vgl_pr_env_mode(vgl_hip_ctx *c, int mode, int *out);
 int vgl_hits_init(vgl_hip_ctx *c, int32_t V, double *d_auth, double *d_hub);
 int vgl_hits_pull_owned(vgl_hip_ctx *c, vgl_hip_graph *g, bool incoming, const double *x, double *out, double *d_sumsq);
 int vgl_hits_scale_owned(vgl_hip_ctx *c, vgl_hip_graph *g, double *x, const double *d_sumsq);

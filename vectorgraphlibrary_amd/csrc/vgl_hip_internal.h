@@ -46,7 +46,20 @@ struct vgl_timing_slot {
     double total_ms = 0.0;
 };
 
+// Tunables of the fused traversal (DESIGN "Run-time switches"), parsed from the environment when the context is created and again only when the
+// process environment has changed since (vgl_ctx_refresh_env: one pass over the pointers of `environ`, no string is looked at) -- not a dozen
+// getenv() per traversal.  A negative / NaN value = "not set": the traversal derives its default from the graph.
+struct vgl_bfs_tunables {
+    int64_t td_emit_edges = -1, small_m = -1, bm_expand = -1, shard_td_emit_edges = -1;
+    double td_filter_share = -1.0, td_late_share = -1.0, blocked_share = -1.0;
+    int later_heavy_blocks = -1, shard_sparse_cap = -1;
+    bool no_hint = false, no_scan_bound = false, trace = false, bu_split = false;
+};
+
 struct vgl_hip_ctx {
+    std::map<std::string, std::string> env;      // the VGL_* variables as they stood at the last refresh
+    uint64_t env_signature = 0;
+    vgl_bfs_tunables bfs;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -63,6 +76,10 @@ struct vgl_hip_ctx {
     std::map<std::string, vgl_timing_slot> slots;
     std::vector<hipEvent_t> event_pool;
 };
+
+// the environment as the context sees it: refresh at the entry of a run (cheap when nothing changed), then read from the snapshot
+void vgl_ctx_refresh_env(vgl_hip_ctx *c);
+const char *vgl_env(vgl_hip_ctx *c, const char *name);            // refreshes, then looks up; nullptr when unset (use the value at once)
 
 struct vgl_dir_csr {                 // one direction of the graph (borrowed) + derived tile table (owned)
     const int64_t *rowptr = nullptr; // nrows+1, rebased to 0
@@ -123,6 +140,9 @@ struct vgl_hip_graph {
     struct vgl_blocked_plan *blk_pr = nullptr;  // PageRank's blocked pull over the outgoing CSR (lazy, owned; vgl_blocked.h)
     struct vgl_blocked_plan *blk_cc = nullptr;  // the Shiloach-Vishkin hook as a blocked pass (lazy, owned)
     struct vgl_blocked_plan *blk_bfs = nullptr; // the large top-down BFS levels as a blocked pass (vgl_hip_bfs_prepare_blocked, owned)
+    struct vgl_blocked_plan *blk_path = nullptr; // STRUCTURE of the path layouts (Bellman-Ford / widest-path pull: rows gather, edge values; lazy, owned): built once
+                                                 // per graph, every vgl_hip_sssp_pull_plan shares it and loads its own weights with one gather pass
+    std::string blk_path_key;                    // the layout switches it was built under (fuse threshold, unit sizes, piece bound: the tests vary them per plan)
 };
 
 struct vgl_hip_frontier {

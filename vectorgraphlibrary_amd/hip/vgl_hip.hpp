@@ -456,6 +456,55 @@ struct vgl_file_container {
     }
 };
 
+// A `.vcsr` graph file straight from an edge list, every stage on the device (round 5; VGL_Graph::save_to_binary_file below goes through this class's
+// stored graph, which keeps ONE numbering for both directions, and rebuilds the reference's two per-direction containers on the host: minutes at
+// RMAT-24).  VGL_Graph::import + save of the reference (vgl_graph.hpp:57-68,109-130, vect_csr/import.hpp:61-99,257-337): the outgoing container
+// renumbers by out-degree (largest first, ties by id) and sorts the edges stably by renumbered source; the incoming container is built the same way
+// from the list AS THE OUTGOING BUILD LEFT IT, transposed.  The edge list is left reordered, like the reference's EdgesContainer.
+inline bool vgl_write_vect_csr_file(EdgesContainer &ec, const std::string &file_name)
+{
+    vgl_hip_ctx *c = VGL_RUNTIME::ctx();
+    const int V = ec.get_vertices_count(); const long long E = ec.get_edges_count();
+    FILE *f = fopen(file_name.c_str(), "wb");
+    if (!f) return false;
+    const int type = (int)VECTOR_CSR_GRAPH;
+    fwrite(&V, sizeof(int), 1, f); fwrite(&E, sizeof(long long), 1, f); fwrite(&type, sizeof(int), 1, f);
+    int *fwd = nullptr, *bwd = nullptr, *rs = nullptr, *rd = nullptr, *adj = nullptr, *s2 = nullptr, *d2 = nullptr;
+    long long *rowptr = nullptr, *perm = nullptr;
+    const size_t e1 = (size_t)std::max<long long>(E, 1);
+    MemoryAPI::allocate_device_array(&fwd, (size_t)V); MemoryAPI::allocate_device_array(&bwd, (size_t)V);
+    MemoryAPI::allocate_device_array(&rs, e1); MemoryAPI::allocate_device_array(&rd, e1); MemoryAPI::allocate_device_array(&adj, e1);
+    MemoryAPI::allocate_device_array(&s2, e1); MemoryAPI::allocate_device_array(&d2, e1);
+    MemoryAPI::allocate_device_array(&rowptr, (size_t)V + 1); MemoryAPI::allocate_device_array(&perm, e1);
+    std::vector<char> host(std::max<size_t>(sizeof(long long) * e1, sizeof(long long) * ((size_t)V + 1)));
+    auto put = [&](const void *device, size_t bytes) {
+        if (bytes) VGL_HIP_CALL(vgl_hip_memcpy_d2h(c, host.data(), device, bytes));
+        return fwrite(host.data(), 1, bytes, f) == bytes;
+    };
+    bool ok = true;
+    int *src = ec.get_src_ids(), *dst = ec.get_dst_ids();
+    for (int direction = 0; direction < 2 && ok; direction++) {
+        int64_t kept = 0;
+        VGL_HIP_CALL(vgl_hip_degree_order(c, V, E, src, dst, 0, fwd, bwd));                       // by the degree of THIS direction's sources
+        VGL_HIP_CALL(vgl_hip_relabel_i32(c, E, fwd, src, rs));
+        VGL_HIP_CALL(vgl_hip_relabel_i32(c, E, fwd, dst, rd));
+        VGL_HIP_CALL(vgl_hip_coo_to_csr(c, V, E, rs, rd, 0, V, (int64_t *)rowptr, adj, (int64_t *)perm, &kept));
+        if (kept != E) { fclose(f); throw "Error in vgl_write_vect_csr_file : edge list holds source ids outside [0, vertices count)"; }
+        fwrite(&V, sizeof(int), 1, f); fwrite(&E, sizeof(long long), 1, f); fwrite(&type, sizeof(int), 1, f);
+        ok = put(rowptr, sizeof(long long) * ((size_t)V + 1)) && put(adj, sizeof(int) * (size_t)E) && put(fwd, sizeof(int) * (size_t)V) && put(bwd, sizeof(int) * (size_t)V) &&
+             put(perm, sizeof(long long) * (size_t)E);
+        // the list in the order of this container (original ids), then transposed for the incoming container (EdgesContainer::transpose, vgl_graph.hpp:62)
+        VGL_HIP_CALL(vgl_hip_gather_u32(c, E, (const int64_t *)perm, src, s2));
+        VGL_HIP_CALL(vgl_hip_gather_u32(c, E, (const int64_t *)perm, dst, d2));
+        VGL_HIP_RT(hipMemcpyAsync(src, d2, sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, VGL_RUNTIME::stream()));
+        VGL_HIP_RT(hipMemcpyAsync(dst, s2, sizeof(int) * (size_t)E, hipMemcpyDeviceToDevice, VGL_RUNTIME::stream()));
+    }
+    // (after the second pass the list is back in (src, dst) orientation, in the incoming container's order -- what the reference's container holds
+    // after VGL_Graph::import transposed it twice)
+    for (void *q : {(void *)fwd, (void *)bwd, (void *)rs, (void *)rd, (void *)adj, (void *)s2, (void *)d2, (void *)rowptr, (void *)perm}) MemoryAPI::free_device_array((char *)q);
+    return fclose(f) == 0 && ok;
+}
+
 template <class T>
 __global__ void vgl_k_permute_values(int n, const int *idx, const T *in, T *out)
 {
@@ -940,6 +989,13 @@ inline vgl_declared_min_label VGL_MIN_LABEL_OVER_EDGES(VerticesArray<int> &label
 struct vgl_declared_relax { float *distances; const float *weights; unsigned long long weights_version; };
 inline vgl_declared_relax VGL_RELAX_OVER_EDGES(VerticesArray<float> &distances, EdgesArray<float> &weights)
 { return vgl_declared_relax{distances.get_ptr(), weights.get_ptr(), weights.version()}; }
+// VGL_SUM_OVER_EDGES(sums, values[, bound]): "sums[src] = sum of values[dst] over every edge src -> dst with dst != src" (the pull of PageRank,
+// pr.hpp:109-123, whose edge operator is `page_ranks[src] += old_rank[dst] * reversed_degree[dst]` outside self loops).  Runs as the blocked pass:
+// values from LDS windows, exact fixed-point accumulation (the same bits for any schedule; <= 1e-6 of the f32 chain while rows are short).
+// values must be non-negative, every per-vertex sum at most `bound`.  Pre / post vertex operators are honoured around it.
+struct vgl_declared_sum { float *sums; const float *values; float bound; };
+inline vgl_declared_sum VGL_SUM_OVER_EDGES(VerticesArray<float> &sums, VerticesArray<float> &values, float bound = 1.0f)
+{ return vgl_declared_sum{sums.get_ptr(), values.get_ptr(), bound}; }
 
 class GraphAbstractionsHIP {
     VGL_Graph *processed_graph_ptr; TraversalDirection current_traversal_direction;
@@ -1095,6 +1151,20 @@ public:
         performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, false);
         return changed != 0;
     }
+    template <class PreOp, class PostOp>
+    void scatter(VGL_Graph &g, VGL_Frontier &f, vgl_declared_sum op, PreOp &&pre_op, PostOp &&post_op)
+    {
+        if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";
+        if (f.get_sparsity_type() != ALL_ACTIVE_FRONTIER) throw "VGL ERROR: a declared operator needs an all-active frontier";
+        const vgl_stopwatch watch;
+        if (!is_empty_vertex_op<PreOp>()) vertex_pass(g, f, SCATTER, pre_op);
+        VGL_HIP_CALL(vgl_hip_sum_over_edges_f32(VGL_RUNTIME::ctx(), g.get_handle(), op.values, op.bound, op.sums));
+        if (!is_empty_vertex_op<PostOp>()) vertex_pass(g, f, SCATTER, post_op);
+        if (sync_after_primitive()) VGL_RUNTIME::sync();
+        const long long work = g.get_direction_view(SCATTER).edges;
+        performance_stats.update_advance_stats(watch.seconds(), (size_t)(work * INT_ELEMENTS_PER_EDGE * sizeof(int)), (size_t)work, false);
+    }
+    void scatter(VGL_Graph &g, VGL_Frontier &f, vgl_declared_sum op) { scatter(g, f, op, EMPTY_VERTEX_OP, EMPTY_VERTEX_OP); }
     bool scatter(VGL_Graph &g, VGL_Frontier &f, vgl_declared_min_label op)
     {
         if (current_traversal_direction != SCATTER) throw "VGL ERROR: incorrect traversal direction in scatter";
