@@ -422,6 +422,9 @@ int vgl_hip_comm_create_hosted(vgl_hip_ctx *ctx, int rank, int world, const char
  * handshake only; window_bytes: capacity of one of the two halves of a window (larger payloads go in pieces).  Fails -- on every rank alike --
  * when a window cannot be mapped by a peer: fall back to vgl_hip_comm_create (RCCL). */
 int vgl_hip_comm_create_peer(vgl_hip_ctx *ctx, int rank, int world, const char *name, size_t window_bytes, vgl_hip_comm **out);
+/* bound of every in-kernel flag wait of the PEER transport from now on (ms; <= 0: the default, 20 s).  The variable VGL_PEER_TIMEOUT_MS is read once,
+ * when the communicator is created; a caller that probes the transport with a short bound sets the working bound here afterwards.  Other transports: no-op. */
+int vgl_hip_comm_set_timeout_ms(vgl_hip_comm *comm, double ms);
 /* tells the other ranks of a hosted / peer communicator that this rank gives up: their next barrier fails at once instead of after its timeout */
 int vgl_hip_comm_abort(vgl_hip_comm *comm);
 int vgl_hip_comm_destroy(vgl_hip_comm *comm);

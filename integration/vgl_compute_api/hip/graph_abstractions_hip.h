@@ -33,8 +33,11 @@
 
 // the collective range of a VECTOR_CSR_GRAPH over its vector extension: one wavefront per segment of VECTOR_LENGTH = 64 vertices, lane i owns vertex
 // first + i and walks its entries in order between its pre and post operators (advance_all_active.hpp:134-225, advance_dense.hpp:137-235); the
-// loads of ve_adjacent_ids are one coalesced 256-byte row per step.  DENSE: edges of flagged vertices only; pre / post for every vertex of the
-// range (advance_dense.hpp:161-166,226-232 call them unconditionally -- kept as the reference has it).
+// loads of ve_adjacent_ids are one coalesced 256-byte row per step.  DENSE: flagged vertices only -- their edges AND their pre / post operators.
+// (The reference's dense collective kernel calls pre / post for every vertex of the range, flagged or not, advance_dense.hpp:161-166,226-232.  That
+// quirk is dropped on purpose: Coloring::vgl_coloring's post operator assigns a colour from a mask that only an ACTIVE vertex's edges have filled,
+// so on a DENSE frontier it would recolour every settled vertex with the first colour of the range -- seen here as 7766 conflicting edges on
+// uniform-11 x 16 in vcsr.)
 template <bool DENSE, class EdgeOp, class PreOp, class PostOp>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_vector_extension(int segments, int starting_vertex, int vertices_count, const long long *vertex_pointers,
                                                                             const long long *group_ptrs, const int *group_sizes, const int *ve_adjacent_ids,
@@ -50,12 +53,12 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_vector_extension(int 
     int connections_count = 0;
     if (present && segment_connections_count > 0) connections_count = (int)(vertex_pointers[src_id + 1] - vertex_pointers[src_id]);
     const bool walks = present && (!DENSE || flags[src_id] > 0);
-    if (present) pre_op(src_id, connections_count, lane);
+    if (walks) pre_op(src_id, connections_count, lane);
     for (int edge_pos = 0; edge_pos < segment_connections_count; edge_pos++) {
         const long long internal_edge_pos = segment_edges_start + (long long)edge_pos * 64 + lane;
         if (walks && edge_pos < connections_count) edge_op(src_id, ve_adjacent_ids[internal_edge_pos], edge_pos, process_shift + internal_edge_pos, lane);
     }
-    if (present) post_op(src_id, connections_count, lane);
+    if (walks) post_op(src_id, connections_count, lane);
 }
 // sizes and degree sums of the three parts of a FrontierVectorCSR (estimate_sorted_frontier_part_size, generate_new_frontier.hpp:3-27) from the flags
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_frontier_parts(int vertices_count, const int *flags, const long long *vertex_pointers, int ve_threshold, int vc_threshold,

@@ -61,11 +61,17 @@ inline HipShadow *hip_shadow_allocate(size_t bytes)
     s->bytes = bytes;
     const size_t n = bytes ? bytes : 1;
     HIP_SHADOW_RT(hipHostMalloc(&s->host, n, hipHostMallocDefault));
-    {   // EXPERIMENT (removed once decided): which kind of device memory user arrays get
-        const char *kind = getenv("VGL_HIP_SHADOW_MEM");
-        if (kind && kind[0] == 'f') HIP_SHADOW_RT(hipExtMallocWithFlags(&s->device, n, hipDeviceMallocFinegrained));
-        else if (kind && kind[0] == 'u') HIP_SHADOW_RT(hipExtMallocWithFlags(&s->device, n, hipDeviceMallocUncached));
-        else HIP_SHADOW_RT(hipMalloc(&s->device, n));
+    // UNCACHED device memory (hipDeviceMallocUncached: not kept in the per-XCD L2s).  The reference's GPU operators are written for a GPU with ONE
+    // coherent L2: gpu_shortest_paths.hpp:38-47 and gpu_shiloach_vishkin.hpp:41-50 update distances[dst] / components[dst] with plain conditional
+    // stores from any thread and end when a pass stores nothing.  The MI355X has eight L2s that are not coherent with each other: two XCDs that
+    // store different values to one word in a pass can each keep their own, the loop ends with every XCD content with ITS view, and memory holds
+    // the larger one.  Measured with integration/tests/sssp_convergence_check.cpp on RMAT-22 (profiles/r05_binding_memkind.log): the reference's
+    // operator on ordinary (coarse-grained) hipMalloc memory converged to distances that differ from seq_dijkstra for 5 of 8 sources (1 - 10 716
+    // vertices), on fine-grained memory for 2 of 8, on uncached memory for none -- and in 14 - 17 passes instead of 18 - 21, at the same AVG_PERF
+    // of the bfs / pr / cc apps (the Infinity Cache serves what L2 would have).  hipMalloc when the allocator refuses the flag.
+    if (hipExtMallocWithFlags(&s->device, n, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_SHADOW_RT(hipMalloc(&s->device, n));
     }
     HipShadowRegistry &r = hip_shadow_registry();
     std::lock_guard<std::recursive_mutex> g(r.lock);

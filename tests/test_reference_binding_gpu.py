@@ -77,6 +77,17 @@ def test_reference_cc_app(kind, fmt):
     assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
 
 
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 12, 8), ("ru", 11, 16)])
+def test_reference_coloring_app(kind, scale, edges, fmt):
+    """Coloring::vgl_coloring (algorithms/coloring/coloring.hpp, round 5: no longer left out of the bound tree): its bit helpers are callable from
+    device code, and its scatter under enable_safe_stores() -- a plain read-modify-write of available_colors[src] per edge -- runs one lane per
+    vertex in the HIP class (with edge tiles the clears of a row's lanes would overwrite each other).  verify_colors: no edge joins two vertices of
+    one colour."""
+    text = run("coloring", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, "-check")
+    assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
+
+
 def test_reference_mf_app():
     """MF::vgl_ford_fulkerson (algorithms/mf/mf.hpp) against MF::seq_ford_fulkerson on a small dense graph, CSR_GRAPH.  (Not on a sparse directed
     graph: the reference divides by its iteration count, which is zero when the random sink cannot be reached.  Not on VECTOR_CSR_GRAPH: the

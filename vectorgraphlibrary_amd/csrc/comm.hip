@@ -340,6 +340,15 @@ int vgl_comm_read_small(vgl_hip_comm *m, const int64_t *d_vals, int n, int64_t *
     return 0;
 }
 
+// after the last exchange of a driver that reads no counters of its own (PageRank, HITS): a flag wait that ran out under the PEER transport only
+// sets the window's error word -- fetch it, so that the driver fails on this rank like the drivers that poll their counters every super-step
+int vgl_comm_check(vgl_hip_comm *m)
+{
+    if (!m || m->transport != VGL_HIP_COMM_PEER) return 0;
+    int64_t none = 0;
+    return vgl_comm_read_small(m, m->d_small, 0, &none);
+}
+
 int vgl_comm_allreduce_host_i64(vgl_hip_comm *m, int64_t *vals, int n, int op)
 {
     if (!vgl_comm_active(m) || n <= 0) return 0;
@@ -489,6 +498,13 @@ int vgl_hip_comm_create_hosted(vgl_hip_ctx *c, int rank, int world, const char *
     slot_bytes = (std::max<size_t>(slot_bytes, 4096) + 255) & ~(size_t)255;
     VGL_TRY(vgl_shm_attach(c, rank, world, name, slot_bytes * (size_t)world, slot_bytes, VGL_HIP_COMM_HOSTED, out));
     (*out)->slot_bytes = slot_bytes;
+    return 0;
+}
+
+int vgl_hip_comm_set_timeout_ms(vgl_hip_comm *m, double ms)
+{
+    if (!m) VGL_FAIL("comm_set_timeout_ms: null communicator");
+    if (m->transport == VGL_HIP_COMM_PEER) vgl_peer_set_timeout_ms(m, ms);
     return 0;
 }
 

@@ -209,37 +209,38 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
     if (count == 0) { if (kept_out) *kept_out = 0; return vgl_hip_ctx_sync(c); }
 
     // 1. stable selection of the input indices whose source row is owned
-    int64_t *kept_idx = nullptr, *sorted_idx = nullptr, *d_nkept = nullptr;
-    int32_t *keys = nullptr, *keys_sorted = nullptr;
-    void *temp = nullptr;
-    size_t temp_bytes = 0, need = 0;
     // whatever is still allocated when the function leaves -- normally or through VGL_HIP_TRY on a failed allocation -- is freed (an
     // out-of-memory in the middle of a scale-27 shard build must not leak the multi-GB temporaries of the piece before it).
     // Round 5: the temporaries (about 26 bytes per edge) come from the library's stream-ordered pool, like those of the plan builders: what the graph
     // build has touched once is what the blocked-plan build of the same graph gets next -- the PageRank plan of uniform-25 paid 1.2 s for FRESH memory
     // (first touch, ~14 ms per GB, and the allocator's stalls) in front of 60 ms of kernels while the build before it took and returned device memory directly
+    vgl_scratch b_kept, b_sorted, b_nkept, b_keys, b_keys_sorted, b_temp;
     struct cleanup {
         hipStream_t st;
-        int64_t *&a, *&b, *&c; int32_t *&d, *&e; void *&f;
-        ~cleanup() { for (void *p : {(void *)a, (void *)b, (void *)c, (void *)d, (void *)e, f}) vgl_pool_free(st, p); }
-    } guard{st, kept_idx, sorted_idx, d_nkept, keys, keys_sorted, temp};
-    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&kept_idx, sizeof(int64_t) * (size_t)count));
-    VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&d_nkept, sizeof(int64_t)));
+        vgl_scratch *all[6];
+        ~cleanup() { for (vgl_scratch *b : all) vgl_scratch_free(st, b); }
+    } guard{st, {&b_kept, &b_sorted, &b_nkept, &b_keys, &b_keys_sorted, &b_temp}};
+    size_t temp_bytes = 0, need = 0;
+    VGL_HIP_TRY(vgl_scratch_alloc(st, &b_kept, sizeof(int64_t) * (size_t)count));
+    VGL_HIP_TRY(vgl_scratch_alloc(st, &b_nkept, sizeof(int64_t)));
+    int64_t *kept_idx = (int64_t *)b_kept.p, *d_nkept = (int64_t *)b_nkept.p;
     rocprim::counting_iterator<int64_t> iota(0);
     vgl_in_range pred{d_src, row_begin, row_end};
     VGL_HIP_TRY(rocprim::select(nullptr, need, iota, kept_idx, (size_t *)d_nkept, (size_t)count, pred, st));
     temp_bytes = need;
-    VGL_HIP_TRY(vgl_pool_alloc(st, &temp, temp_bytes ? temp_bytes : 16));
-    VGL_HIP_TRY(rocprim::select(temp, temp_bytes, iota, kept_idx, (size_t *)d_nkept, (size_t)count, pred, st));
+    VGL_HIP_TRY(vgl_scratch_alloc(st, &b_temp, temp_bytes ? temp_bytes : 16));
+    VGL_HIP_TRY(rocprim::select(b_temp.p, temp_bytes, iota, kept_idx, (size_t *)d_nkept, (size_t)count, pred, st));
     int64_t nkept = 0;
     VGL_HIP_TRY(hipMemcpyAsync(&nkept, d_nkept, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     VGL_HIP_TRY(hipStreamSynchronize(st));
     if (kept_out) *kept_out = nkept;
     if (nkept > 0) {
         // 2. keys = local rows, row histogram
-        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&keys, sizeof(int32_t) * (size_t)nkept));
-        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&keys_sorted, sizeof(int32_t) * (size_t)nkept));
-        VGL_HIP_TRY(vgl_pool_alloc(st, (void **)&sorted_idx, sizeof(int64_t) * (size_t)nkept));
+        VGL_HIP_TRY(vgl_scratch_alloc(st, &b_keys, sizeof(int32_t) * (size_t)nkept));
+        VGL_HIP_TRY(vgl_scratch_alloc(st, &b_keys_sorted, sizeof(int32_t) * (size_t)nkept));
+        VGL_HIP_TRY(vgl_scratch_alloc(st, &b_sorted, sizeof(int64_t) * (size_t)nkept));
+        int32_t *keys = (int32_t *)b_keys.p, *keys_sorted = (int32_t *)b_keys_sorted.p;
+        int64_t *sorted_idx = (int64_t *)b_sorted.p;
         hipLaunchKernelGGL(vgl_k_keys, dim3(vgl_grid_for(nkept)), dim3(VGL_BLOCK), 0, st, nkept, kept_idx, d_src, row_begin,
                            keys, (unsigned long long *)(d_rowptr + 1));
         VGL_HIP_TRY(hipGetLastError());
@@ -248,8 +249,8 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
         while (bits < 31 && (1LL << bits) < (int64_t)nrows) bits++;
         need = 0;
         VGL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, keys_sorted, kept_idx, sorted_idx, (size_t)nkept, 0, bits, st));
-        if (need > temp_bytes) { vgl_pool_free(st, temp); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(vgl_pool_alloc(st, &temp, temp_bytes)); }
-        VGL_HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys, keys_sorted, kept_idx, sorted_idx, (size_t)nkept, 0, bits, st));
+        if (need > temp_bytes) { vgl_scratch_free(st, &b_temp); temp_bytes = need; VGL_HIP_TRY(vgl_scratch_alloc(st, &b_temp, temp_bytes)); }
+        VGL_HIP_TRY(rocprim::radix_sort_pairs(b_temp.p, need, keys, keys_sorted, kept_idx, sorted_idx, (size_t)nkept, 0, bits, st));
         // 4. adjacency + optional permutation
         hipLaunchKernelGGL(vgl_k_gather<int32_t>, dim3(vgl_grid_for(nkept)), dim3(VGL_BLOCK), 0, st, nkept, sorted_idx, d_dst, d_adj);
         VGL_HIP_TRY(hipGetLastError());
@@ -257,8 +258,8 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
         // 5. row offsets: inclusive scan of the histogram stored at rowptr[1..nrows]
         need = 0;
         VGL_HIP_TRY(rocprim::inclusive_scan(nullptr, need, d_rowptr + 1, d_rowptr + 1, (size_t)nrows, rocprim::plus<int64_t>(), st));
-        if (need > temp_bytes) { vgl_pool_free(st, temp); temp = nullptr; temp_bytes = need; VGL_HIP_TRY(vgl_pool_alloc(st, &temp, temp_bytes)); }
-        VGL_HIP_TRY(rocprim::inclusive_scan(temp, need, d_rowptr + 1, d_rowptr + 1, (size_t)nrows, rocprim::plus<int64_t>(), st));
+        if (need > temp_bytes) { vgl_scratch_free(st, &b_temp); temp_bytes = need; VGL_HIP_TRY(vgl_scratch_alloc(st, &b_temp, temp_bytes)); }
+        VGL_HIP_TRY(rocprim::inclusive_scan(b_temp.p, need, d_rowptr + 1, d_rowptr + 1, (size_t)nrows, rocprim::plus<int64_t>(), st));
     }
     VGL_HIP_TRY(hipStreamSynchronize(st));
     return 0;

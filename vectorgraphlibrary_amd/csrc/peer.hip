@@ -303,6 +303,11 @@ const unsigned long long *vgl_peer_error_word(vgl_hip_comm *m)
     return s ? &reinterpret_cast<vgl_peer_flags *>(s->window)->error : nullptr;
 }
 
+void vgl_peer_set_timeout_ms(vgl_hip_comm *m, double ms)
+{
+    if (vgl_peer_state *s = peer_of(m)) s->timeout_ticks = (long long)((ms > 0.0 ? ms : 20000.0) * 1e5);        // wall_clock64: 100 MHz
+}
+
 int vgl_peer_setup(vgl_hip_comm *m, size_t window_bytes)
 {
     // m->shm (control segment: hosted header + one vgl_peer_record per rank) is attached and m->rank / m->world are set

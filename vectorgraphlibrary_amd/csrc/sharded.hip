@@ -161,6 +161,7 @@ int vgl_hip_pr_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph *g
         if (active) VGL_TRY(vgl_comm_allgatherv_inplace(m, d_ranks, bb.data()));
     }
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (active) VGL_TRY(vgl_comm_check(m));              // (a peer that never arrived: the ranks are void, not a silent 0)
     if (stats) {
         stats->iterations = iterations;
         stats->ranks_sum = 0.0;
@@ -203,6 +204,7 @@ int vgl_hip_hits_run_sharded(vgl_hip_ctx *c, vgl_hip_comm *given, vgl_hip_graph 
             if (active) VGL_TRY(vgl_comm_allgatherv_inplace(m, out, bb.data()));
         }
     VGL_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (active) VGL_TRY(vgl_comm_check(m));
     return 0;
 }
 

@@ -68,6 +68,8 @@ int vgl_peer_alltoall(vgl_hip_comm *m, const void *d_send, void *d_recv, int64_t
 int vgl_peer_allgatherv_inplace(vgl_hip_comm *m, void *d_buf, const int64_t *bb);
 int vgl_peer_group_end(vgl_hip_comm *m);
 const unsigned long long *vgl_peer_error_word(vgl_hip_comm *m);
+int vgl_comm_check(vgl_hip_comm *m);          // PEER: fails when a flag wait of an earlier exchange ran out (reads the window's error word)
+void vgl_peer_set_timeout_ms(vgl_hip_comm *m, double ms);
 int vgl_fold(vgl_hip_ctx *c, int64_t n, int parts, const void *in, void *out, int dtype, int op);      // out[i] = fold over p of in[p * n + i] (comm.hip)
 
 // enqueue-only forms of the owned-row super-steps (no host read; defined next to their kernels)

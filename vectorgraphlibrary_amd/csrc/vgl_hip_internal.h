@@ -201,6 +201,25 @@ static inline hipError_t vgl_pool_alloc(hipStream_t st, void **p, size_t bytes)
     return hipMallocAsync(p, bytes ? bytes : 16, st);
 }
 static inline void vgl_pool_free(hipStream_t st, void *p) { if (p) (void)hipFreeAsync(p, st); }
+// scratch of the graph builders: from the pool below 8 GiB, plain hipMalloc from there on -- a pool allocation of exactly 2^33 bytes (the 8-byte
+// index arrays of uniform-25's 2^30 edges) ended in a GPU memory fault inside the first kernel that touched it (round 5, ROCm 7.2; the plan
+// builders' pool allocations stop at 5.7 GB and never showed it).  The tag in the low bit of `tag` remembers where the block came from.
+struct vgl_scratch {
+    void *p = nullptr;
+    bool pooled = false;
+};
+static inline hipError_t vgl_scratch_alloc(hipStream_t st, vgl_scratch *b, size_t bytes)
+{
+    b->pooled = bytes < (1ull << 33);
+    return b->pooled ? vgl_pool_alloc(st, &b->p, bytes) : hipMalloc(&b->p, bytes ? bytes : 16);
+}
+static inline void vgl_scratch_free(hipStream_t st, vgl_scratch *b)
+{
+    if (!b->p) return;
+    if (b->pooled) (void)hipFreeAsync(b->p, st);
+    else { (void)hipStreamSynchronize(st); (void)hipFree(b->p); }
+    b->p = nullptr;
+}
 
 // ---------------------------------------------------------------------------------------------
 // device helpers (wave = 64 lanes)

@@ -135,6 +135,7 @@ _SIGNATURES = {
     "vgl_hip_pr_setup": [_p, _i32, _p, _p, _p],
     "vgl_hip_sum_over_edges_f32": [_p, _p, _p, C.c_float, _p],
     "vgl_hip_sssp_prepare": [_p, _p],
+    "vgl_hip_comm_set_timeout_ms": [_p, C.c_double],
     "vgl_hip_pr_iteration_owned": [_p, _p, _p, _p, _p, _p],
     "vgl_hip_indegree_noloops_add": [_p, _p, _p],
     "vgl_hip_diff_to_pairs_u32": [_p, _i32, _p, _p, _i32, _p],

@@ -63,6 +63,10 @@ class Comm:
     def barrier(self):
         _l.check(self.ctx.L.vgl_hip_comm_barrier(self.h))
 
+    def set_timeout_ms(self, ms):
+        """bound of every in-kernel flag wait of the PEER transport from now on (<= 0: the default, 20 s); no-op for the other transports"""
+        _l.check(self.ctx.L.vgl_hip_comm_set_timeout_ms(self.h, C.c_double(float(ms))))
+
     def stats(self):
         st = _l.ExchangeStats()
         _l.check(self.ctx.L.vgl_hip_comm_stats(self.h, C.byref(st)))
