@@ -515,7 +515,14 @@ int vgl_hip_comm_create_peer(vgl_hip_ctx *c, int rank, int world, const char *na
     VGL_HIP_TRY(hipSetDevice(c->device));
     vgl_hip_comm *m = nullptr;
     VGL_TRY(vgl_shm_attach(c, rank, world, name, (size_t)128 * (size_t)world, (uint64_t)window_bytes, VGL_HIP_COMM_PEER, &m));
-    if (vgl_peer_setup(m, window_bytes)) { vgl_hip_comm_destroy(m); return 1; }
+    if (vgl_peer_setup(m, window_bytes)) {
+        // the set-up failed on this rank (an allocation, an IPC handle) or on all ranks alike (the agreed vote): say so in the shared header before
+        // leaving, so that no peer waits out the hosted timeout in a barrier -- of its own set-up or of its teardown -- for a rank that is gone
+        const std::string err = vgl_hip_last_error();
+        (void)vgl_hip_comm_abort(m);
+        vgl_hip_comm_destroy(m);
+        return vgl_set_error(__FILE__, __LINE__, err.c_str());
+    }
     *out = m;
     return 0;
 }

@@ -321,8 +321,10 @@ int vgl_peer_setup(vgl_hip_comm *m, size_t window_bytes)
     const size_t total = VGL_PEER_FLAG_BYTES + 2 * s->half_bytes;
     // fine-grained device memory: stores arriving over xGMI and the polling loads of the owner must not be served from a stale L2 line
     // (coarse-grained hipMalloc memory is only coherent at kernel boundaries); plain hipMalloc when the allocator refuses the flag
+    bool fine_grained = true;
     if (hipExtMallocWithFlags((void **)&s->window, total, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
+        fine_grained = false;
         VGL_HIP_TRY(hipMalloc((void **)&s->window, total));
     }
     VGL_HIP_TRY(hipMemset(s->window, 0, VGL_PEER_FLAG_BYTES));
@@ -336,6 +338,14 @@ int vgl_peer_setup(vgl_hip_comm *m, size_t window_bytes)
     const bool have_handle = e == hipSuccess;
     if (!have_handle) (void)hipGetLastError();
     rec[r].pad[0] = have_handle ? 1 : 0;
+    rec[r].pad[1] = fine_grained ? 1 : 0;
+    {   // which physical GPU the window lives on (device indices are per process): a hash of the PCI bus id
+        char bus[64] = {0};
+        uint32_t h = 2166136261u;
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), m->ctx->device) != hipSuccess) (void)hipGetLastError();
+        for (const char *q = bus; *q; q++) h = (h ^ (uint8_t)*q) * 16777619u;
+        memcpy(&rec[r].pad[4], &h, sizeof(h));
+    }
     VGL_TRY(vgl_hosted_barrier(m));                     // every record is written
     s->opened.assign((size_t)P, false);
     int failed = 0;
@@ -348,6 +358,17 @@ int vgl_peer_setup(vgl_hip_comm *m, size_t window_bytes)
         s->opened[(size_t)p] = true;
     }
     for (int p = P; p < VGL_PEER_MAX; p++) s->tab.win[p] = nullptr;
+    // a coarse-grained window (the allocator refused the fine-grained flag) is coherent at kernel boundaries only: good enough while every rank sits
+    // on ONE GPU (tests, rehearsals), not across GPUs, where polled flags and payload could be served from stale L2 lines
+    {
+        uint32_t mine = 0;
+        memcpy(&mine, &rec[r].pad[4], sizeof(mine));
+        for (int p = 0; p < P; p++) {
+            uint32_t theirs = 0;
+            memcpy(&theirs, &rec[p].pad[4], sizeof(theirs));
+            if (theirs != mine && (!rec[p].pad[1] || !rec[r].pad[1])) failed = 1;
+        }
+    }
     // all ranks agree on success: one failure anywhere voids the transport everywhere (the caller falls back to RCCL)
     std::atomic<uint32_t> *bad = reinterpret_cast<std::atomic<uint32_t> *>(&reinterpret_cast<char *>(m->shm)[192]);
     if (failed) bad->fetch_add(1);
