@@ -200,10 +200,19 @@ def bfs_levels_certificate(levels, shard, source, chunk_rows=1 << 22):
         deg = rowptr[r0 + 1:r1 + 1] - rowptr[r0:r1]
         return torch.repeat_interleave(torch.arange(lo + r0, lo + r1, device=dev), deg), int(rowptr[r0]), int(rowptr[r1])
 
+    def row_chunks(rowptr, max_edges=1 << 27):
+        # at most chunk_rows rows AND about max_edges entries per piece: the first rows of a degree-sorted RMAT-27 hold billions of entries, and
+        # torch's masked indexing fails beyond 2^31 elements (it asked for 6.7e7 GiB in the first round-5 run of the bench)
+        r0 = 0
+        while r0 < nrows:
+            cut = int(torch.searchsorted(rowptr[r0:nrows + 1], int(rowptr[r0]) + max_edges, right=True)) - 1 + r0
+            r1 = max(r0 + 1, min(cut, r0 + chunk_rows, nrows))
+            yield r0, r1
+            r0 = r1
+
     edges_ok = int(lv[source]) == 1
     nrows = hi - lo
-    for r0 in range(0, nrows, chunk_rows):
-        r1 = min(nrows, r0 + chunk_rows)
+    for r0, r1 in row_chunks(shard.out_rowptr):
         rows, e0, e1 = row_index(shard.out_rowptr, r0, r1)
         ls, ld = lv[rows], lv[shard.out_adj[e0:e1].long()]
         reached = ls > 0
@@ -212,8 +221,7 @@ def bfs_levels_certificate(levels, shard, source, chunk_rows=1 << 22):
     parents_ok = None
     if shard.in_rowptr is not None and shard.in_adj is not None:
         parents_ok = True
-        for r0 in range(0, nrows, chunk_rows):
-            r1 = min(nrows, r0 + chunk_rows)
+        for r0, r1 in row_chunks(shard.in_rowptr):
             rows, e0, e1 = row_index(shard.in_rowptr, r0, r1)
             has = torch.zeros(r1 - r0, dtype=torch.int32, device=dev)
             good = (lv[shard.in_adj[e0:e1].long()] == lv[rows] - 1) & (lv[rows] > 1)
