@@ -42,6 +42,8 @@ struct PageRank {
             reversed_degrees[src_id] = (dg == 0) ? (_T)0 : (_T)(1.0 / dg);
         };
         graph_API.compute(graph, frontier, calculate_reversed_degrees);
+        if (deterministic == 3)          // the layout behind the declared sum: once per graph, outside the run like the library's own plan (vgl_hip_pr_prepare)
+            std::cout << "PR declared-sum layout (blocked adjacency, once per graph): " << 1000.0 * graph_API.prepare(graph, VGL_SUM_OVER_EDGES(page_ranks, contributions)) << " ms" << std::endl;
         Timer tm;
         tm.start();
         for (int it = 0; it < max_iterations; it++) {
