@@ -17,7 +17,9 @@ context; the anchors below are the shortest strings that locate each edit):
   * move_to_device / move_to_host   : the CUDA flavour's family exists; on user arrays they are real copies mirror <-> HBM
   * algorithms/{pr,sssp,cc}         : the reference's GPU variants (gpu_pr.hpp, gpu_shortest_paths.hpp, gpu_shiloach_vishkin.hpp) compile for __USE_HIP__;
                                       three CUDA runtime calls by name get a HIP branch
-  * algorithms/coloring             : bit helpers callable from device code; graph_library.h leaves tc.h out (EDGES_LIST_GRAPH + host-side copy_if)
+  * algorithms/coloring             : bit helpers callable from device code
+  * algorithms/tc                   : ParallelPrimitives::copy_if_indexes evaluates a device condition in kernels; EDGES_LIST_GRAPH served by the class;
+                                      the condensed graph gets the vertex its largest component id needs
 (the hipcc command line is in oracle/Makefile, target `binding`)
 Every rule must apply (an anchor that is not found is an error): the script is also the test that the reference still has the shape the
 binding was written against.  tests/test_reference_binding.py applies it to a copy in /tmp and compiles seven of the reference's apps with hipcc."""
@@ -49,11 +51,23 @@ RULES = [
     # ---- coloring.hpp calls its bit helpers (clear_bit, smallest_bit_pos) from operator lambdas: they become callable from device code (clang, unlike
     #      nvcc, checks this in templates that are never instantiated too).  Its scatter under enable_safe_stores() -- a read-modify-write of per-vertex
     #      data without atomics -- runs one lane per vertex in the HIP class (GraphAbstractionsHIP::enable_safe_stores).
-    #      tc.hpp stays out: it hands a device lambda to the host-side copy_if and runs its condensed graph as an EDGES_LIST_GRAPH, a container the
-    #      reference's own GPU backend does not serve either (gpu/advance.hpp:37) ----
+    #      ----
     ("algorithms/coloring/coloring.hpp", "sub", r"^inline (size_t|int) (set_bit|clear_bit|get_bit|smallest_bit_pos)\(",
      r"#if defined(__USE_GPU__) || defined(__USE_HIP__)\n__host__ __device__\n#endif\ninline \1 \2(", 4),
-    ("graph_library.h", "sub", r'^(#include "algorithms/tc/tc.h")$', r"#ifndef __USE_HIP__\n\1\n#endif"),
+    # ---- tc.hpp (TransitiveClosure::vgl_purdoms) hands a DEVICE lambda to ParallelPrimitives::copy_if_indexes, whose only body is a host loop
+    #      (copy_if/copy_if.hpp:285-298: the reference's own GPU flavour cannot build it): the condition runs in kernels (vgl_compute_api/hip/
+    #      parallel_primitives_hip.h).  Its condensed graph is an EDGES_LIST_GRAPH: the class serves that container (graph_abstractions_hip.h), the
+    #      container tells the backend when it frees its arrays.  One correction of the algorithm, for this architecture only: tc.hpp:104-110 sizes the
+    #      condensed graph by the LARGEST component id (REDUCE_MAX) instead of the number of ids, so the component with that id is a vertex one past
+    #      every array of the condensed graph -- an unnoticed stray access in a host build, not something a kernel may do ----
+    ("vgl_runtime/helpers/parallel_primitives/primitives.h", "before", r'^#include "copy_if/copy_if.hpp"$',
+     "#ifdef __USE_HIP__\n#include \"vgl_compute_api/hip/parallel_primitives_hip.h\"\n#endif\n"),
+    ("vgl_runtime/helpers/parallel_primitives/copy_if/copy_if.hpp", "sub", r"^(\s*)#elif defined\(__USE_MULTICORE__\)\n(\s*num_elements = omp_copy_if_indexes\()",
+     r"\1#elif defined(__USE_HIP__)\n\1num_elements = hip_copy_if_indexes(_cond, _out_data, _size, _index_offset);\n\1#elif defined(__USE_MULTICORE__)\n\2", 1),
+    ("algorithms/tc/tc.hpp", "after", r"^\s*int new_vertices_count = graph_API\.reduce<int>\(_graph, frontier, max_component_num, REDUCE_MAX\);$",
+     "    #ifdef __USE_HIP__\n    new_vertices_count += 1;          // ids are 0 .. max: the condensed graph has max + 1 vertices\n    #endif\n"),
+    ("vgl_datastructures/graphs/undirected_containers/edges_list/edges_list_graph.hpp", "sub", r"^(void EdgesListGraph::free\(\)\n\{\n)",
+     r"\1    #ifdef __USE_HIP__\n    hip_container_changed(this);\n    #endif\n", 1),
     # ---- memory: managed allocations, as the CUDA flavour (__USE_MANAGED_MEMORY__, settings.h) ----
     ("vgl_runtime/helpers/memory_API/memory_API.hpp", "before", r"^\s*#elif defined\(__USE_KNL__\)$",
      "    #elif defined(__USE_HIP__)\n    if(hipMallocManaged((void**)_ptr, _size * sizeof(_T)) != hipSuccess) throw \"Error in MemoryAPI::allocate_array : hipMallocManaged failed\";\n", 2, 0),

@@ -19,7 +19,9 @@
 // ranges and the padded vector extension (advance_worker.hpp:204-319, advance_{all_active,dense,sparse}.hpp, generate_new_frontier.hpp:29-111):
 // the collective range of an ALL_ACTIVE or DENSE frontier walks the VE copy of the adjacency and hands the collective operators VE-space
 // global_edge_pos (process shift of VE_STORAGE + segment start + edge_pos * VECTOR_LENGTH + lane), a SPARSE frontier hands them CSR positions,
-// as the reference does.  EDGES_LIST_GRAPH and CSR_VG_GRAPH throw (as the CUDA backend does for what it lacks, gpu/advance.hpp:37).
+// as the reference does.  EDGES_LIST_GRAPH (round 5; the condensed graph of TransitiveClosure::vgl_purdoms, tc.hpp:113-133): every edge of the list per
+// advance, flags + count per frontier generation, as gpu/advance.hpp:44-68 and gpu/generate_new_frontier.hpp:266-292.  CSR_VG_GRAPH throws (as the CUDA
+// backend does for what it lacks, gpu/advance.hpp:37).
 // Every primitive returns synchronised (SAFE_KERNEL_CALL of the CUDA backend, cuda_error_handling.h:15-27).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -104,6 +106,39 @@ struct vgl_range_vertex_op {
         else collective(src, connections, lane);
     }
 };
+
+// EDGES_LIST_GRAPH: one lane per stored edge (multicore/advance_worker.hpp:10-57, gpu/advance.hpp:44-68: the frontier is not consulted, local and
+// global edge position are both the position in the list).  Endpoints outside [0, vertices_count) are skipped: tc.hpp:104-110 sizes its condensed
+// graph by the LARGEST component id (one vertex short; the binding adds the missing one, apply_hip_binding.py) -- a kernel must not follow such an id.
+template <class EdgeOp>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_edges_list(long long edges_count, int vertices_count, const int *src_ids, const int *dst_ids, EdgeOp edge_op)
+{
+    for (long long e = (long long)blockIdx.x * VGL_BLOCK + threadIdx.x; e < edges_count; e += (long long)gridDim.x * VGL_BLOCK) {
+        const int src_id = src_ids[e], dst_id = dst_ids[e];
+        if ((unsigned)src_id < (unsigned)vertices_count && (unsigned)dst_id < (unsigned)vertices_count)
+            edge_op(src_id, dst_id, (int)e, e, (int)(threadIdx.x & 63));
+    }
+}
+// generate_new_frontier on an EDGES_LIST_GRAPH (multicore/generate_new_frontier.hpp:235-270): flags from the condition (connections_count = 0, as there),
+// their count in *count
+template <class Cond>
+__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_edges_list_flags(int vertices_count, Cond cond, int *flags, unsigned long long *count)
+{
+    __shared__ unsigned long long s_count[VGL_BLOCK / 64];
+    unsigned long long n = 0;
+    for (int v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < vertices_count; v += gridDim.x * VGL_BLOCK) {
+        const int flag = cond(v, 0);
+        flags[v] = flag;
+        n += flag > 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < VGL_BLOCK / 64; w++) n += s_count[w];
+        if (n) atomicAdd(count, n);                        // one atomic per workgroup
+    }
+}
 
 class GraphAbstractionsHIP : public GraphAbstractions
 {
@@ -207,6 +242,44 @@ private:
     }
     template <typename GraphContainer>
     vgl_hip_graph *handle_of(GraphContainer &_graph) { return binding_of(_graph).handle; }
+
+    // EDGES_LIST_GRAPH: device copies of the two id arrays and an exclusive prefix of the containers' per-vertex edge counts (get_connections_count) in
+    // the place of vertex_pointers, so that the per-vertex kernels hand the operators the connection counts the reference's do.  Same identity rule as
+    // the CSR bindings (EdgesListGraph::free bumps the version).
+    struct edges_list_binding {
+        const void *src_ids = nullptr, *dst_ids = nullptr;
+        long long edges_count = 0;
+        int vertices_count = 0;
+        unsigned long long version = 0;
+        int *d_src_ids = nullptr, *d_dst_ids = nullptr;
+        long long *d_degree_prefix = nullptr;
+    };
+    static std::map<void *, edges_list_binding> &edges_list_bindings() { static std::map<void *, edges_list_binding> table; return table; }
+    const edges_list_binding &edges_list_of(EdgesListGraph &_graph)
+    {
+        std::map<void *, edges_list_binding> &table = edges_list_bindings();
+        auto it = table.find((void *)&_graph);
+        if (it != table.end()) {
+            edges_list_binding &b = it->second;
+            if (b.src_ids == (const void *)_graph.get_src_ids() && b.dst_ids == (const void *)_graph.get_dst_ids() && b.edges_count == (long long)_graph.get_edges_count() &&
+                b.vertices_count == _graph.get_vertices_count() && b.version == hip_container_version((const void *)&_graph))
+                return b;
+            hipStreamSynchronize(stream);
+            hipFree(b.d_src_ids); hipFree(b.d_dst_ids); hipFree(b.d_degree_prefix);
+            table.erase(it);
+        }
+        edges_list_binding b;
+        const size_t V = (size_t)_graph.get_vertices_count(), E = (size_t)_graph.get_edges_count();
+        b.src_ids = (const void *)_graph.get_src_ids(); b.dst_ids = (const void *)_graph.get_dst_ids(); b.edges_count = (long long)E; b.vertices_count = (int)V;
+        b.version = hip_container_version((const void *)&_graph);
+        b.d_src_ids = device_copy(_graph.get_src_ids(), E);
+        b.d_dst_ids = device_copy(_graph.get_dst_ids(), E);
+        std::vector<long long> prefix(V + 1, 0);
+        for (size_t v = 0; v < V; v++) prefix[v + 1] = prefix[v] + _graph.get_connections_count((int)v);
+        b.d_degree_prefix = device_copy(prefix.data(), V + 1);
+        VGL_HIP_BIND_RT(hipStreamSynchronize(stream));                                   // (prefix is a local)
+        return table[(void *)&_graph] = b;
+    }
 
     // the frontier container may have been changed by host code since the last primitive (add_vertex, clear, set_all_active write its fields and
     // arrays directly): its description is taken as it stands before every use
@@ -329,6 +402,15 @@ private:
     template <typename ComputeOperation>
     void compute_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, ComputeOperation &&compute_op)
     { compute_on_csr_pointers(_graph, _frontier, compute_op); }
+    template <typename ComputeOperation>
+    void compute_worker(EdgesListGraph &_graph, FrontierEdgesList &_frontier, ComputeOperation &&compute_op)
+    {
+        LOAD_FRONTIER_DATA(_frontier);
+        hip_shadows_to_device(stream);
+        const int vertices_count = _graph.get_vertices_count();
+        vertex_pass(vertices_count, edges_list_of(_graph).d_degree_prefix, _frontier.get_sparsity_type(), frontier_flags, frontier_ids, frontier_size, 0, vertices_count, compute_op);
+        finish();
+    }
     template <typename ComputeOperation, typename GraphContainer, typename FrontierContainer>
     void compute_on_csr_pointers(GraphContainer &_graph, FrontierContainer &_frontier, ComputeOperation &&compute_op)
     {
@@ -348,14 +430,19 @@ private:
     template <typename _T, typename ReduceOperation>
     void reduce_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
     { reduce_on_csr_pointers(_graph, _frontier, reduce_op, _reduce_type, _result); }
+    template <typename _T, typename ReduceOperation>
+    void reduce_worker(EdgesListGraph &_graph, FrontierEdgesList &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
+    { reduce_on_pointers(edges_list_of(_graph).d_degree_prefix, _graph, _frontier, reduce_op, _reduce_type, _result); }
     template <typename _T, typename ReduceOperation, typename GraphContainer, typename FrontierContainer>
     void reduce_on_csr_pointers(GraphContainer &_graph, FrontierContainer &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
+    { reduce_on_pointers(binding_of(_graph).d_vertex_pointers, _graph, _frontier, reduce_op, _reduce_type, _result); }
+    template <typename _T, typename ReduceOperation, typename GraphContainer, typename FrontierContainer>
+    void reduce_on_pointers(const long long *vertex_pointers, GraphContainer &_graph, FrontierContainer &_frontier, ReduceOperation &&reduce_op, REDUCE_TYPE _reduce_type, _T &_result)
     {
         if (_reduce_type != REDUCE_SUM && _reduce_type != REDUCE_MAX) throw "Error in GraphAbstractionsHIP::reduce_worker: unsupported reduce type";   // multicore/reduce.hpp:144-150
         using R = typename std::decay<ReduceOperation>::type;
         LOAD_FRONTIER_DATA(_frontier);
         hip_shadows_to_device(stream);
-        const long long *vertex_pointers = binding_of(_graph).d_vertex_pointers;
         const FrontierSparsityType t = _frontier.get_sparsity_type();
         const int n = t == SPARSE_FRONTIER ? frontier_size : _graph.get_vertices_count();
         _result = 0;
@@ -397,6 +484,29 @@ private:
                         CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op,
                         CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op, bool _inner_mpi_processing);
 
+    // EDGES_LIST_GRAPH: the operator over every stored edge; pre / post / collective operators and the frontier are not consulted
+    // (multicore/advance_worker.hpp:10-57, gpu/advance.hpp:44-68)
+    template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
+              typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation>
+    void advance_worker(EdgesListGraph &_graph, FrontierEdgesList &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
+                        VertexPostprocessOperation &&vertex_postprocess_op, CollectiveEdgeOperation &&collective_edge_op,
+                        CollectiveVertexPreprocessOperation &&collective_vertex_preprocess_op,
+                        CollectiveVertexPostprocessOperation &&collective_vertex_postprocess_op, bool _inner_mpi_processing)
+    {
+        using E = typename std::decay<EdgeOperation>::type;
+        Timer tm;
+        tm.start();
+        hip_shadows_to_device(stream);
+        const edges_list_binding &eb = edges_list_of(_graph);
+        const long long edges_count = _graph.get_edges_count();
+        if (edges_count > 0)
+            hipLaunchKernelGGL((vgl_k_advance_edges_list<E>), dim3(grid_for(edges_count)), dim3(VGL_BLOCK), 0, stream, edges_count, _graph.get_vertices_count(),
+                               (const int *)eb.d_src_ids, (const int *)eb.d_dst_ids, edge_op);
+        finish();
+        tm.end();
+        performance_stats.update_advance_stats(tm.get_time(), edges_count * (INT_ELEMENTS_PER_EDGE + 1) * sizeof(int), edges_count);
+    }
+
     template <typename EdgeOperation, typename VertexPreprocessOperation, typename VertexPostprocessOperation, typename CollectiveEdgeOperation,
               typename CollectiveVertexPreprocessOperation, typename CollectiveVertexPostprocessOperation, typename GraphContainer, typename FrontierContainer>
     void advance_worker(GraphContainer &_graph, FrontierContainer &_frontier, EdgeOperation &&edge_op, VertexPreprocessOperation &&vertex_preprocess_op,
@@ -427,6 +537,29 @@ public:
     void generate_new_frontier_worker(CSRGraph &_graph, FrontierCSR &_frontier, FilterCondition &&filter_cond);
     template <typename FilterCondition>
     void generate_new_frontier_worker(VectorCSRGraph &_graph, FrontierVectorCSR &_frontier, FilterCondition &&filter_cond);
+    // EDGES_LIST_GRAPH (multicore/generate_new_frontier.hpp:235-270): flags from the condition, size = how many passed, the frontier stays ALL_ACTIVE
+    template <typename FilterCondition>
+    void generate_new_frontier_worker(EdgesListGraph &_graph, FrontierEdgesList &_frontier, FilterCondition &&filter_cond)
+    {
+        using C = typename std::decay<FilterCondition>::type;
+        Timer tm;
+        tm.start();
+        hip_shadows_to_device(stream);
+        _frontier.set_direction(current_traversal_direction);
+        const int vertices_count = _graph.get_vertices_count();
+        unsigned long long passed = 0;
+        VGL_HIP_BIND_RT(hipMemsetAsync(part_counters, 0, sizeof(unsigned long long), stream));
+        if (vertices_count > 0)
+            hipLaunchKernelGGL((vgl_k_edges_list_flags<C>), dim3(std::min(grid_for(vertices_count), 1024)), dim3(VGL_BLOCK), 0, stream, vertices_count, filter_cond, _frontier.flags, part_counters);
+        VGL_HIP_BIND_RT(hipMemcpyAsync(&passed, part_counters, sizeof(passed), hipMemcpyDeviceToHost, stream));
+        finish();
+        _frontier.size = (int)passed;
+        _frontier.neighbours_count = 0;
+        _frontier.sparsity_type = ALL_ACTIVE_FRONTIER;
+        tm.end();
+        performance_stats.update_gnf_time(tm);
+        performance_stats.update_bytes_requested((long long)vertices_count * 2.0 * sizeof(int));
+    }
     template <typename FilterCondition, typename GraphContainer, typename FrontierContainer>
     void generate_new_frontier_worker(GraphContainer &_graph, FrontierContainer &_frontier, FilterCondition &&filter_cond)
     { throw "Error in GraphAbstractionsHIP::generate_new_frontier : this graph container is not served by the HIP backend"; }

@@ -2,7 +2,7 @@
 `make -C oracle binding` copies /root/reference to a scratch directory in /tmp, applies integration/apply_hip_binding.py (the edits of INTEGRATION.md
 section 2: -D __USE_HIP__ selects GraphAbstractionsHIP, a class derived from GraphAbstractions in vgl_compute_api/hip/graph_abstractions_hip.h that
 works on CSRGraph / VectorCSRGraph / FrontierCSR / FrontierVectorCSR through friend access) and compiles the reference's applications
-apps/{bfs,sswp,hits,scc,pr,sssp,cc,mf}/*.cpp -- main() unchanged, algorithms unchanged but for three CUDA runtime calls by name in the GPU variants -- with hipcc for gfx950 against libvgl_hip.so.  Nothing of the reference
+apps/{bfs,sswp,hits,scc,pr,sssp,cc,mf,coloring,tc}/*.cpp -- main() unchanged, algorithms unchanged but for three CUDA runtime calls by name in the GPU variants -- with hipcc for gfx950 against libvgl_hip.so.  Nothing of the reference
 enters the repository; the binaries go to oracle/_ref (git-ignored, they travel to the GPU box, where tests/test_reference_binding_gpu.py runs
 them with the reference's own -check)."""
 import os
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 HIPCC = "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF) or not os.path.exists(HIPCC), reason="needs /root/reference and hipcc (CPU container)")
-APPS = ("bfs", "sswp", "hits", "scc", "pr", "sssp", "cc", "mf")
+APPS = ("bfs", "sswp", "hits", "scc", "pr", "sssp", "cc", "mf", "coloring", "tc")
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +28,7 @@ def built():
 
 
 def test_the_reference_apps_compile_with_the_backend_bound_in(built):
-    for app in APPS + ("plan_stamp_check",):            # (the last one: integration/tests/plan_stamp_check.cpp, our own program against the patched tree)
+    for app in APPS + ("plan_stamp_check", "tc_check"):  # (the last two: integration/tests/*.cpp, our own programs against the patched tree)
         assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "vgl_hip_" + app)), app
 
 

@@ -124,3 +124,20 @@ def test_host_rewrites_of_a_generated_frontier_void_its_advance_plan(kind, scale
     text = run("plan_stamp_check", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt)
     assert "PLAN STAMP CHECK PASSED" in text, text[-3000:]
     assert len(re.findall(r", 0 differences", text)) == 4, text[-3000:]
+
+
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 11, 8), ("ru", 10, 2), ("rmat", 8, 4)])
+def test_reference_tc_unchanged_against_a_sequential_search(kind, scale, edges):
+    """TransitiveClosure::vgl_purdoms (algorithms/tc/tc.hpp) bound in (round 5: tc.h is no longer left out of the tree): the edge filter writes two
+    EdgesArrays through global_edge_pos, ParallelPrimitives::copy_if_indexes evaluates its DEVICE condition in kernels
+    (vgl_compute_api/hip/parallel_primitives_hip.h), the condensed graph is an EDGES_LIST_GRAPH the class's edges-list workers traverse with the
+    reference's own BFS::fast_vgl_top_down.  integration/tests/tc_check.cpp compares every answer with a sequential search over the same graph (the
+    app's own -check compares zero elements, apps/tc/tc.cpp:67)."""
+    text = run("tc_check", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", "csr", "-it", "24")
+    assert "TC CHECK PASSED" in text and ", 0 wrong answers" in text, text[-3000:]
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+def test_reference_tc_app_runs(fmt):
+    text = run("tc", "-s", "10", "-e", "8", "-type", "rmat", "-format", fmt, "-it", "8", "-check")      # (its -check is vacuous, see above: this is "the app runs")
+    assert "AVG_PERF" in text, text[-3000:]
