@@ -142,7 +142,10 @@ int vgl_hip_frontier_advance_plan(vgl_hip_ctx *ctx, vgl_hip_graph *g, vgl_hip_fr
  * stream with the buffers vgl_hip_gnf_begin hands out (plain pointers: the caller never sees the library's internal structures).
  * vgl_hip_gnf_complete waits for that launch (sequence number `seq` from begin, published by the kernel's last workgroup) and does the
  * rest: size / neighbours / sparsity choice (generate_new_frontier.hpp:67-91,113-164) and, for a SPARSE result, the ascending-id
- * compaction -- with the exclusive out-edge offsets of the ids when want_plan != 0, which vgl_hip_frontier_advance_plan(direction 0) reuses. */
+ * compaction -- with the exclusive out-edge offsets of the ids when want_plan != 0, which vgl_hip_frontier_advance_plan(direction 0) reuses.
+ * Round 5: the count pass writes the predicate's bits as a BITMAP (V / 8 bytes) instead of V int32 flags, the compaction reads the bitmap, and only a
+ * DENSE / ALL_ACTIVE result gets its int32 flags (expanded from the bitmap): a BFS level on RMAT-24 moved 64 MiB of flags out and in again for a frontier
+ * of a few thousand ids.  VGL_GNF_INT_FLAGS=1 keeps the flags of every result (the reference's contract to the letter). */
 typedef struct {
     int32_t nrows, row_begin;          /* owned rows of the graph handle (generate_new_frontier needs a whole-graph handle) */
     int64_t nvtiles;                   /* 2048-vertex tiles = workgroups of the count launch (256 threads each) */
@@ -152,7 +155,10 @@ typedef struct {
     uint32_t *ticket;                  /* arrival counters of the launch (the last workgroup scans the tiles) */
     int64_t *counters;                 /* device counter slots */
     volatile int64_t *host_counters;   /* their pinned mirror */
-    int32_t *flags;                    /* the frontier's flags (written by the count pass) */
+    int32_t *flags;                    /* the frontier's int32 flags for the count pass to write, or NULL (round 5, the default): the pass then leaves only
+                                          front_bytes and vgl_hip_gnf_complete writes the flags of a DENSE / ALL_ACTIVE result itself -- the flags of a
+                                          SPARSE frontier are not materialised (nothing reads them: every primitive walks its ids) */
+    uint8_t *front_bytes;              /* the predicate's bits, byte v >> 3, bit v & 7 (always written by the count pass) */
     int64_t *plan_offs;                /* want_plan: edge-offset array whose terminator the count pass writes, else NULL */
     int64_t seq;                       /* sequence number the launch must publish */
 } vgl_hip_gnf_buffers;

@@ -62,19 +62,35 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_advance_vector_extension(int 
     }
     if (walks) post_op(src_id, connections_count, lane);
 }
-// sizes and degree sums of the three parts of a FrontierVectorCSR (estimate_sorted_frontier_part_size, generate_new_frontier.hpp:3-27) from the flags
-__global__ __launch_bounds__(VGL_BLOCK) void vgl_k_frontier_parts(int vertices_count, const int *flags, const long long *vertex_pointers, int ve_threshold, int vc_threshold,
-                                                                  unsigned long long *out)      // out[0..2] sizes, out[3..5] neighbours
+// sizes and degree sums of the three parts of a FrontierVectorCSR (estimate_sorted_frontier_part_size, generate_new_frontier.hpp:3-27) from what the
+// count pass of the frontier generation left: per 2048-vertex tile the number of flagged vertices and their degree sum (vt_cnt / vt_deg), and the
+// predicate's bitmap for the (at most two) tiles a part boundary cuts.  ONE workgroup, microseconds -- the pass over all V int32 flags and their row
+// offsets that this replaces cost 55 us per BFS level on RMAT-24 (profiles/r05_binding_bfs_vcsr_rmat24_kernel_stats.csv), a twelfth of a traversal.
+constexpr int VGL_PARTS_THREADS = 1024;
+__global__ __launch_bounds__(VGL_PARTS_THREADS) void vgl_k_frontier_parts_from_tiles(int vertices_count, long long tiles, const int *vt_cnt, const long long *vt_deg,
+                                                                                     const unsigned char *front_bytes, const long long *vertex_pointers, int ve_threshold,
+                                                                                     int vc_threshold, unsigned long long *out)      // out[0..2] sizes, out[3..5] neighbours
 {
     unsigned long long n[3] = {0, 0, 0}, d[3] = {0, 0, 0};
-    for (int v = blockIdx.x * VGL_BLOCK + threadIdx.x; v < vertices_count; v += gridDim.x * VGL_BLOCK)
-        if (flags[v] > 0) {
-            const int part = v < ve_threshold ? 0 : (v < vc_threshold ? 1 : 2);
-            n[part] += 1; d[part] += (unsigned long long)(vertex_pointers[v + 1] - vertex_pointers[v]);
-        }
-    // one atomic per counter and WORKGROUP: the six counters are single addresses, and one atomic per wavefront (98 000 of them for 2^20 vertices)
-    // queued behind each other for 131 us -- two thirds of a VectorCSR traversal of RMAT-20
-    __shared__ unsigned long long s_part[VGL_BLOCK / 64][6];
+    const int bounds[4] = {0, ve_threshold, vc_threshold, vertices_count};
+    for (long long t = threadIdx.x; t < tiles; t += VGL_PARTS_THREADS) {
+        const long long first = t * VGL_TILE, last = min((long long)vertices_count, first + VGL_TILE);      // [first, last)
+        for (int p = 0; p < 3; p++)
+            if (first >= bounds[p] && last <= bounds[p + 1]) { n[p] += (unsigned long long)vt_cnt[t]; d[p] += (unsigned long long)vt_deg[t]; }
+    }
+    // the tiles cut by a boundary, vertex by vertex (all threads, both boundaries)
+    for (int b = 1; b <= 2; b++) {
+        const int cut = bounds[b];
+        if (cut <= 0 || cut >= vertices_count || cut % VGL_TILE == 0) continue;
+        if (b == 2 && bounds[1] > 0 && bounds[1] / VGL_TILE == cut / VGL_TILE && bounds[1] % VGL_TILE != 0) continue;     // same tile as the first cut: done there
+        const long long first = (long long)(cut / VGL_TILE) * VGL_TILE, last = min((long long)vertices_count, first + VGL_TILE);
+        for (long long v = first + threadIdx.x; v < last; v += VGL_PARTS_THREADS)
+            if ((front_bytes[v >> 3] >> (v & 7)) & 1) {
+                const int part = v < ve_threshold ? 0 : (v < vc_threshold ? 1 : 2);
+                n[part] += 1; d[part] += (unsigned long long)(vertex_pointers[v + 1] - vertex_pointers[v]);
+            }
+    }
+    __shared__ unsigned long long s_part[VGL_PARTS_THREADS / 64][6];
     for (int p = 0; p < 3; p++) {
         for (int o = 32; o > 0; o >>= 1) { n[p] += __shfl_xor(n[p], o); d[p] += __shfl_xor(d[p], o); }
         if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][p] = n[p]; s_part[threadIdx.x >> 6][3 + p] = d[p]; }
@@ -82,8 +98,8 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_frontier_parts(int vertices_c
     __syncthreads();
     if (threadIdx.x < 6) {
         unsigned long long t = 0;
-        for (int w = 0; w < VGL_BLOCK / 64; w++) t += s_part[w][threadIdx.x];
-        if (t) atomicAdd(&out[threadIdx.x], t);
+        for (int w = 0; w < VGL_PARTS_THREADS / 64; w++) t += s_part[w][threadIdx.x];
+        out[threadIdx.x] = t;
     }
 }
 // SPARSE frontier of a VECTOR_CSR_GRAPH: ids below the vector-core threshold take (edge_op, pre, post), the others the collective set; ids are
@@ -772,7 +788,7 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(CSRGraph &_graph, Fronti
     VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 1, &b));
     const vgl_pred_user<C> pred{filter_cond, binding_of(_graph).d_vertex_pointers};
     hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
-                       (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
+                       b.front_bytes, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
     VGL_HIP_BIND_RT(hipGetLastError());
     VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.0, 1, b.seq));
     int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
@@ -803,12 +819,14 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
     VGL_HIP_BIND_CALL(vgl_hip_gnf_begin(ctx, gh, fh, 1, &b));
     const vgl_pred_user<C> pred{filter_cond, binding_of(_graph).d_vertex_pointers};
     hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, stream, pred, b.nrows, b.row_begin, b.out_rowptr, b.vt_cnt, b.vt_deg,
-                       (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
+                       b.front_bytes, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters, b.plan_offs, b.host_counters, b.seq);
+    VGL_HIP_BIND_RT(hipGetLastError());
+    // the three parts' sizes from the per-tile counts the pass above leaves (stream order: after it, before the host looks), while the host waits for the totals
+    hipLaunchKernelGGL(vgl_k_frontier_parts_from_tiles, dim3(1), dim3(VGL_PARTS_THREADS), 0, stream, vertices_count, (long long)b.nvtiles, (const int *)b.vt_cnt,
+                       (const long long *)b.vt_deg, (const unsigned char *)b.front_bytes, (const long long *)binding_of(_graph).d_vertex_pointers,
+                       _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
     VGL_HIP_BIND_RT(hipGetLastError());
     VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.7, 1, b.seq));
-    VGL_HIP_BIND_RT(hipMemsetAsync(part_counters, 0, sizeof(unsigned long long) * 8, stream));
-    hipLaunchKernelGGL(vgl_k_frontier_parts, dim3(std::min(grid_for(vertices_count), 512)), dim3(VGL_BLOCK), 0, stream, vertices_count, (const int *)_frontier.flags,
-                       (const long long *)binding_of(_graph).d_vertex_pointers, _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
     int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
     VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
     unsigned long long parts[6];

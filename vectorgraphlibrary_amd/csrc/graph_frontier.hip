@@ -362,7 +362,7 @@ int vgl_hip_graph_destroy(vgl_hip_ctx *c, vgl_hip_graph *g)
     void *ptrs[] = {g->out.tile_row, g->in.tile_row, g->bm_visited, g->bm_front, g->bm_next, g->bm_in_nz, g->in_head, g->in_nz_rank, g->bm_in_long, g->ids, g->offs, g->vt_cnt,
                     g->vt_cnt_off, g->vt_deg, g->vt_deg_off, g->tile_first, g->heavy, g->heavy_cnt, g->heavy_off, g->bu_partials, g->tickets, g->epoch, g->fscratch, g->fscratch2,
                     g->fscratch3, g->iscratch, g->ds_tile_active, g->ds_partials, g->out.hub_rows, g->in.hub_rows, g->out.giant_rows, g->in.giant_rows, g->out.pull_blk_row,
-                    g->in.pull_blk_row, g->vt_min_deg, g->out.hub_chunks, g->in.hub_chunks, g->out.hub_chunk_sums, g->in.hub_chunk_sums, g->pr_indeg};
+                    g->in.pull_blk_row, g->vt_min_deg, g->gnf_bits, g->out.hub_chunks, g->in.hub_chunks, g->out.hub_chunk_sums, g->in.hub_chunk_sums, g->pr_indeg};
     for (void *p : ptrs) if (p) hipFree(p);
     delete g;
     return 0;
@@ -471,6 +471,13 @@ static int vgl_frontier_reserve(vgl_hip_graph *g, vgl_hip_frontier *f)
     return 0;
 }
 
+// VGL_GNF_INT_FLAGS=1: the count pass of the operator classes writes the int32 flags of every result, as the reference does (read once per process)
+static bool vgl_gnf_int_flags()
+{
+    static const bool on = [] { const char *e = getenv("VGL_GNF_INT_FLAGS"); return e && e[0] == '1'; }();
+    return on;
+}
+
 extern "C" {
 
 int vgl_hip_gnf_begin(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, int want_plan, vgl_hip_gnf_buffers *out)
@@ -482,7 +489,13 @@ int vgl_hip_gnf_begin(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, int
     out->vt_cnt = g->vt_cnt; out->vt_cnt_off = g->vt_cnt_off; out->vt_deg = g->vt_deg; out->vt_deg_off = g->vt_deg_off;
     out->ticket = g->nvtiles <= 16384 ? g->tickets + 0 * VGL_TICKET_WORDS : nullptr;      // beyond 2^25 vertices vgl_hip_gnf_complete runs the scan pass
     out->counters = c->d_counters; out->host_counters = (volatile int64_t *)c->h_counters;
-    out->flags = f->flags; out->plan_offs = want_plan ? f->offs : nullptr;
+    if (!g->gnf_bits) {
+        VGL_TRY(vgl_alloc(&g->gnf_bits, (size_t)vgl_ceil_div(g->V, 8) + 8));
+        VGL_HIP_TRY(hipMemsetAsync(g->gnf_bits, 0, (size_t)vgl_ceil_div(g->V, 8) + 8, c->stream));
+    }
+    out->front_bytes = g->gnf_bits;
+    out->flags = vgl_gnf_int_flags() ? f->flags : nullptr;     // (NULL: the count pass leaves the bitmap only, vgl_hip_gnf_complete does the rest)
+    out->plan_offs = want_plan ? f->offs : nullptr;
     out->seq = vgl_next_seq(c);
     return 0;
 }
@@ -503,14 +516,25 @@ int vgl_hip_gnf_complete(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, 
     f->size = (int32_t)c->h_counters[C_FRONT];
     f->neighbours = c->h_counters[C_NEIGH];
     f->plan_dir = -1;
-    if (f->size == g->V) { f->sparsity = VGL_HIP_FRONTIER_ALL_ACTIVE; return 0; }
-    if (dense_threshold > 0.0 && (double)f->size / g->V > dense_threshold) { f->sparsity = VGL_HIP_FRONTIER_DENSE; return 0; }
+    const bool all = f->size == g->V, dense = !all && dense_threshold > 0.0 && (double)f->size / g->V > dense_threshold;
+    if (all || dense) {
+        f->sparsity = all ? VGL_HIP_FRONTIER_ALL_ACTIVE : VGL_HIP_FRONTIER_DENSE;
+        if (!vgl_gnf_int_flags()) {                          // the flags of a frontier that is walked by its flags: from the bitmap of the count pass
+            if (!g->gnf_bits) VGL_FAIL("gnf_complete: vgl_hip_gnf_begin has not run on this graph handle");
+            vgl_timed_launch tl(c, "gnf");
+            hipLaunchKernelGGL(vgl_k_bits_to_flags, dim3((unsigned)std::min<int64_t>(4096, std::max<int64_t>(1, vgl_ceil_div(vgl_ceil_div(g->nrows, 8), VGL_BLOCK)))), dim3(VGL_BLOCK), 0,
+                               c->stream, g->nrows, g->row_begin, (const uint8_t *)g->gnf_bits, f->flags);
+            VGL_HIP_TRY(hipGetLastError());
+        }
+        return 0;
+    }
     f->sparsity = VGL_HIP_FRONTIER_SPARSE;
     if (want_plan) VGL_TRY(vgl_frontier_reserve(g, f));
     {
         vgl_timed_launch tl(c, "gnf");
-        const vgl_pred_nonzero_i32 pred{f->flags};
-        hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_nonzero_i32>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows, g->row_begin,
+        if (!g->gnf_bits) VGL_FAIL("gnf_complete: vgl_hip_gnf_begin has not run on this graph handle");
+        const vgl_pred_bits pred{g->gnf_bits};               // (the bitmap is there in either mode: 2 MiB to read instead of 64 MiB of flags)
+        hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_bits>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows, g->row_begin,
                            g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, f->ids, want_plan ? f->offs : (int64_t *)nullptr);
     }
     VGL_HIP_TRY(hipGetLastError());

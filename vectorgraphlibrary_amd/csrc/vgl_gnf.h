@@ -53,6 +53,29 @@ struct vgl_pred_nonzero_i32 {               // flags[v] != 0
     }
 };
 
+struct vgl_pred_bits {                      // bit v of a bitmap (byte v >> 3, bit v & 7) left by an earlier count pass; v0 is a multiple of 8
+    const uint8_t *bytes;
+    __device__ uint32_t bits8(int32_t v0, int nvalid, uint32_t *aux) const
+    {
+        *aux = 0;
+        return (uint32_t)bytes[v0 >> 3] & ((1u << nvalid) - 1u);
+    }
+};
+// int32 flags (0 / 1) of a DENSE or ALL_ACTIVE frontier from the bitmap of its count pass: one byte -> eight flags per thread
+static __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_bits_to_flags(int32_t nrows, int32_t row_base, const uint8_t *bytes, int32_t *flags)
+{
+    const int64_t nbytes = ((int64_t)nrows + 7) >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * VGL_BLOCK + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * VGL_BLOCK) {
+        const int32_t v0 = row_base + (int32_t)(i << 3);
+        const uint32_t bits = bytes[v0 >> 3];
+        if (v0 + 8 <= row_base + nrows && (v0 & 7) == 0) {
+            *reinterpret_cast<int4 *>(flags + v0) = make_int4(bits & 1, (bits >> 1) & 1, (bits >> 2) & 1, (bits >> 3) & 1);
+            *reinterpret_cast<int4 *>(flags + v0 + 4) = make_int4((bits >> 4) & 1, (bits >> 5) & 1, (bits >> 6) & 1, (bits >> 7) & 1);
+        } else
+            for (int j = 0; v0 + j < row_base + nrows && j < 8; j++) flags[v0 + j] = (bits >> j) & 1;
+    }
+}
+
 // count pass.  Workgroup = tile of 2048 owned vertices, thread = 8 consecutive vertices.
 // front_bytes (optional): bitmap of active vertices (byte v>>3, bit v&7; little-endian uint64 words).
 // visited_bytes (optional): bitmap of the predicate's auxiliary bits (fused BFS: values[v] != -1).

@@ -123,6 +123,8 @@ struct vgl_hip_graph {
     int64_t *vt_deg = nullptr, *vt_deg_off = nullptr;
     int64_t nvtiles = 0;
     int32_t *vt_min_deg = nullptr;   // per vertex tile: smallest out-degree of its rows (lower bound of a frontier's edge count from its per-tile sizes)
+    uint8_t *gnf_bits = nullptr;     // generate_new_frontier of the operator classes: the predicate's bits (byte v >> 3, bit v & 7; lazy, V / 8 bytes) -- the
+                                     // compaction of a SPARSE result reads these 2 MiB instead of 64 MiB of int32 flags (vgl_hip_gnf_begin / _complete)
     int32_t *tile_first = nullptr;   // out.ntiles + 2
     int32_t *heavy = nullptr;        // nrows + slack: per-workgroup segments of deferred bottom-up vertices
     int32_t *heavy_cnt = nullptr;    // one count per bottom-up workgroup

@@ -1270,15 +1270,16 @@ public:
         // CSR_GRAPH frontiers are ALL_ACTIVE or SPARSE (generate_new_frontier.hpp:113-164); VECTOR_CSR_GRAPH ones turn DENSE (flags only)
         // above FRONTIER_TYPE_CHANGE_THRESHOLD = 0.7 of the vertices (generate_new_frontier.hpp:67-91, settings.h)
         const double dense_threshold = g.get_format() == VECTOR_CSR_GRAPH ? 0.7 : 0.0;
-        // ONE pass evaluates the condition, writes the flags and counts (the last workgroup scans the per-tile counts and hands size and
-        // neighbour count to the host); the compaction then reads the flags and leaves the ids' out-edge offsets behind for scatter
+        // ONE pass evaluates the condition, writes its bits (a V / 8-byte bitmap; int32 flags only under VGL_GNF_INT_FLAGS=1) and counts (the last
+        // workgroup scans the per-tile counts and hands size and neighbour count to the host); the compaction then reads the bitmap and leaves the
+        // ids' out-edge offsets behind for scatter; a DENSE / ALL_ACTIVE result gets its int32 flags from the bitmap
         vgl_hip_ctx *c = VGL_RUNTIME::ctx();
         const bool plan = current_traversal_direction == SCATTER;
         vgl_hip_gnf_buffers b;
         VGL_HIP_CALL(vgl_hip_gnf_begin(c, g.get_handle(), f.get_handle(), plan ? 1 : 0, &b));
         const vgl_pred_user<C> pred{filter_cond, v.rowptr};
         hipLaunchKernelGGL((vgl_k_gnf_count<vgl_pred_user<C>>), dim3((unsigned)b.nvtiles), dim3(VGL_BLOCK), 0, VGL_RUNTIME::stream(), pred, b.nrows, b.row_begin,
-                           b.out_rowptr, b.vt_cnt, b.vt_deg, (uint8_t *)nullptr, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters,
+                           b.out_rowptr, b.vt_cnt, b.vt_deg, b.front_bytes, (uint8_t *)nullptr, b.flags, b.ticket, b.vt_cnt_off, b.vt_deg_off, b.counters,
                            b.plan_offs, b.host_counters, b.seq);
         VGL_HIP_RT(hipGetLastError());
         VGL_HIP_CALL(vgl_hip_gnf_complete(c, g.get_handle(), f.get_handle(), dense_threshold, plan ? 1 : 0, b.seq));

@@ -259,6 +259,18 @@ struct vgl_pred_user {
     {
         uint32_t b = 0;
         *aux = 0;
+        if (nvalid == 8) {
+            // a full thread: the eight evaluations UNROLLED, so that whatever the condition loads (levels[v], distances[v] ...) is requested for
+            // all eight vertices before the first result is needed.  As a loop with a run-time trip count each evaluation waited for its own loads:
+            // eight dependent round trips per thread, 57 us for the 64 MiB of a BFS level's `levels` on RMAT-24 against 13 us for the library's own
+            // scan of the same array (profiles/r05_binding_bfs_vcsr_rmat24_kernel_stats.csv, vgl_k_bfs_scan_bound).
+            int hit[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) hit[j] = cond(v0 + j, (int)(rowptr[v0 + j + 1] - rowptr[v0 + j]));
+#pragma unroll
+            for (int j = 0; j < 8; j++) b |= (uint32_t)(hit[j] > 0) << j;
+            return b;
+        }
         for (int j = 0; j < nvalid; j++) b |= (uint32_t)(cond(v0 + j, (int)(rowptr[v0 + j + 1] - rowptr[v0 + j])) > 0) << j;
         return b;
     }
