@@ -100,6 +100,7 @@ __global__ __launch_bounds__(VGL_PARTS_THREADS) void vgl_k_frontier_parts_from_t
         unsigned long long t = 0;
         for (int w = 0; w < VGL_PARTS_THREADS / 64; w++) t += s_part[w][threadIdx.x];
         out[threadIdx.x] = t;
+        __threadfence_system();                              // (the words live in pinned host memory)
     }
 }
 // SPARSE frontier of a VECTOR_CSR_GRAPH: ids below the vector-core threshold take (edge_op, pre, post), the others the collective set; ids are
@@ -162,7 +163,9 @@ private:
     vgl_hip_ctx *ctx;
     hipStream_t stream;
     double *reduce_partials;                        // 1024 partials + the folded maximum
-    unsigned long long *part_counters;              // device: vgl_k_frontier_parts (atomics on host-resident memory would cross PCIe one by one)
+    unsigned long long *part_counters;              // device: the edges-list frontier generation's counter (atomics on host-resident memory would cross PCIe one by one)
+    unsigned long long *part_sizes;                 // PINNED host memory: vgl_k_frontier_parts_from_tiles stores its six results here (a hipMemcpyAsync into a stack
+                                                    // array took 22 - 58 us per BFS level in the API trace: pageable destination, staged copy)
     // Per direction container: the library's graph handle and DEVICE copies of the arrays the kernels traverse.  The containers themselves stay in
     // managed memory (host-resident on a pool without XNACK), where the reference's host code -- import, select_random_nz_vertex, the sequential
     // checkers -- reads them at full speed; a container that was resized / re-imported (other arrays or another edge count behind the same object)
@@ -645,6 +648,7 @@ GraphAbstractionsHIP::GraphAbstractionsHIP(VGL_Graph &_graph, TraversalDirection
     stream = (hipStream_t)vgl_hip_ctx_stream(ctx);
     VGL_HIP_BIND_RT(hipMalloc((void **)&reduce_partials, sizeof(double) * (1024 + 8)));
     VGL_HIP_BIND_RT(hipMalloc((void **)&part_counters, sizeof(unsigned long long) * 8));
+    VGL_HIP_BIND_RT(hipHostMalloc((void **)&part_sizes, sizeof(unsigned long long) * 8, hipHostMallocDefault));
     frontier_generation = bindings_generation();
     // the device copies of both direction containers are made HERE, before the algorithm starts its timer (the reference's algorithms construct the class
     // first and call _graph.move_to_device() next, bfs.hpp:58-72): the first primitive does not pay for 2 x (adjacency + vector extension) over PCIe
@@ -666,6 +670,7 @@ GraphAbstractionsHIP::~GraphAbstractionsHIP()
     // (the graph bindings stay: see graph_bindings())
     hipFree(reduce_partials);
     hipFree(part_counters);
+    hipHostFree(part_sizes);
 }
 
 template <typename ComputeOperation, typename GraphContainer, typename FrontierContainer>
@@ -824,14 +829,13 @@ void GraphAbstractionsHIP::generate_new_frontier_worker(VectorCSRGraph &_graph, 
     // the three parts' sizes from the per-tile counts the pass above leaves (stream order: after it, before the host looks), while the host waits for the totals
     hipLaunchKernelGGL(vgl_k_frontier_parts_from_tiles, dim3(1), dim3(VGL_PARTS_THREADS), 0, stream, vertices_count, (long long)b.nvtiles, (const int *)b.vt_cnt,
                        (const long long *)b.vt_deg, (const unsigned char *)b.front_bytes, (const long long *)binding_of(_graph).d_vertex_pointers,
-                       _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_counters);
+                       _graph.get_vector_engine_threshold_vertex(), _graph.get_vector_core_threshold_vertex(), part_sizes);
     VGL_HIP_BIND_RT(hipGetLastError());
     VGL_HIP_BIND_CALL(vgl_hip_gnf_complete(ctx, gh, fh, 0.7, 1, b.seq));
     int32_t size = 0; int64_t neighbours = 0; int sparsity = 0;
     VGL_HIP_BIND_CALL(vgl_hip_frontier_info(ctx, fh, &size, &neighbours, &sparsity));
-    unsigned long long parts[6];
-    VGL_HIP_BIND_RT(hipMemcpyAsync(parts, part_counters, sizeof(parts), hipMemcpyDeviceToHost, stream));
-    finish();
+    finish();                                       // (the kernel's stores to the pinned words are visible once the stream has drained)
+    const volatile unsigned long long *parts = part_sizes;
     _frontier.vector_engine_part_size = (int)parts[0]; _frontier.vector_engine_part_neighbours_count = (long long)parts[3];
     _frontier.vector_core_part_size = (int)parts[1]; _frontier.vector_core_part_neighbours_count = (long long)parts[4];
     _frontier.collective_part_size = (int)parts[2]; _frontier.collective_part_neighbours_count = (long long)parts[5];

@@ -28,7 +28,7 @@ def built():
 
 
 def test_the_reference_apps_compile_with_the_backend_bound_in(built):
-    for app in APPS + ("plan_stamp_check", "tc_check"):  # (the last two: integration/tests/*.cpp, our own programs against the patched tree)
+    for app in APPS + ("plan_stamp_check", "tc_check", "scc_check"):  # (the last two: integration/tests/*.cpp, our own programs against the patched tree)
         assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "vgl_hip_" + app)), app
 
 

@@ -17,6 +17,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def run_unchecked(app, *args, env=None):
+    exe = os.path.join(ROOT, "oracle", "_ref", "vgl_hip_" + app)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/vgl_hip_* are built where /root/reference exists (make -C oracle binding)")
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=env)
+    text = out.stdout + out.stderr
+    assert out.returncode in (0, 1) and "rror in" not in text, text[-3000:]
+    return text
+
+
 def run(app, *args, env=None):
     exe = os.path.join(ROOT, "oracle", "_ref", "vgl_hip_" + app)
     if not os.path.exists(exe):
@@ -50,8 +60,31 @@ def test_reference_hits_app(fmt):
 
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
 def test_reference_scc_app(fmt):
-    text = run("scc", "-s", "12", "-e", "8", "-type", "rmat", "-format", fmt, "-check")
-    assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
+    """The app runs and checks itself.  On VECTOR_CSR_GRAPH its check passes; on CSR_GRAPH the reference's forward-backward algorithm itself differs
+    from SCC::seq_tarjan by a few vertices on 1 - 8 % of small R-MAT graphs ON ANY BACKEND (its own multicore build included: found in round 5, when
+    this test -- the app seeds its generator with time(NULL) -- failed once in 25 runs), so there the verdict of the run is not asserted here: the
+    seeded comparison with the genuine reference below is the parity test."""
+    text = run_unchecked("scc", "-s", "12", "-e", "8", "-type", "rmat", "-format", fmt, "-check")
+    counts = re.findall(r"error count: (\d+)\b", text)
+    assert len(counts) == 1, text[-3000:]
+    if fmt == "vcsr":
+        assert counts == ["0"], text[-3000:]
+    else:
+        assert int(counts[0]) <= 16, text[-3000:]             # (the reference's own misses are a handful of vertices)
+
+
+def test_reference_scc_matches_the_reference_seed_for_seed():
+    """integration/tests/scc_check.cpp (our seeded driver of the UNCHANGED SCC::vgl_forward_backward against SCC::seq_tarjan) on the HIP backend
+    bound into the reference's tree, against tests/golden/scc_reference_disagreements.json = the same program on the genuine reference (multicore
+    flavour, oracle/make_golden_scc_check.py): for every seed the number of vertices whose component differs from Tarjan's must be the reference's
+    -- zero for most seeds, the reference's own 1 - 4 for the seeds its algorithm gets wrong."""
+    import json
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "scc_reference_disagreements.json")))
+    for case in golden["cases"]:
+        text = run_unchecked("scc_check", str(case["scale"]), str(case["edge_factor"]), str(case["first_seed"]), str(case["seeds"]), "0", case["format"])
+        got = {m.group(1): int(m.group(2)) for m in re.finditer(r"seed (\d+): (\d+) vertices disagree", text)}
+        assert re.search(r"%d seeds, %d with components" % (case["seeds"], len(got)), text), text[-2000:]
+        assert got == case["vertices_that_disagree_with_seq_tarjan"], (case["format"], case["scale"], got)
 
 
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])

@@ -1595,7 +1595,7 @@ int vgl_hip_bfs_run(vgl_hip_ctx *c, vgl_hip_graph *g, int32_t source, int mode, 
                 vgl_pred_equal_i32 pred{d_levels, cur};
                 vgl_timed_launch tl(c, "gnf");
                 hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_equal_i32>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred,
-                                   g->nrows, g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs);
+                                   g->nrows, g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, g->ids, g->offs, (int32_t *)nullptr, (int64_t)0);
             }
             trace("ids written");
             if (small_m > 0 && counted_from_bitmap && F <= VGL_SMALL_F && M <= small_m) {

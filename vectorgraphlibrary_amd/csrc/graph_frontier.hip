@@ -535,10 +535,11 @@ int vgl_hip_gnf_complete(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_frontier *f, 
         if (!g->gnf_bits) VGL_FAIL("gnf_complete: vgl_hip_gnf_begin has not run on this graph handle");
         const vgl_pred_bits pred{g->gnf_bits};               // (the bitmap is there in either mode: 2 MiB to read instead of 64 MiB of flags)
         hipLaunchKernelGGL(vgl_k_gnf_write<vgl_pred_bits>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows, g->row_begin,
-                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, f->ids, want_plan ? f->offs : (int64_t *)nullptr);
+                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, f->ids, want_plan ? f->offs : (int64_t *)nullptr,
+                           want_plan ? f->tile_first : (int32_t *)nullptr, (int64_t)f->neighbours);
     }
     VGL_HIP_TRY(hipGetLastError());
-    if (want_plan) f->plan_dir = 0;
+    if (want_plan) { f->plan_dir = 0; f->plan_edges = f->neighbours; }      // offsets AND tile table of the outgoing direction are in place
     return 0;
 }
 
@@ -555,10 +556,8 @@ int vgl_hip_frontier_advance_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_fron
     *d_offs = f->offs; *d_tile_first = f->tile_first; *edges = 0;
     if (F == 0) return 0;
     const int grid = (int)std::min<int64_t>(4096, vgl_ceil_div(F, VGL_BLOCK));
-    if (f->plan_dir == direction) {              // the frontier generation left ids' edge offsets behind: only the tile table is missing
-        hipLaunchKernelGGL(vgl_k_plan_tile_first, dim3(grid), dim3(VGL_BLOCK), 0, c->stream, F, f->offs, f->tile_first);
-        VGL_HIP_TRY(hipGetLastError());
-        *edges = f->neighbours;
+    if (f->plan_dir == direction) {              // the frontier generation (or an earlier call) left offsets and tile table of these ids behind
+        *edges = f->plan_edges;
         return 0;
     }
     hipLaunchKernelGGL(vgl_k_plan_sums, dim3((unsigned)nblk), dim3(VGL_BLOCK), 0, c->stream, F, f->ids, g->row_begin, d.rowptr, f->blk_sum);
@@ -568,7 +567,7 @@ int vgl_hip_frontier_advance_plan(vgl_hip_ctx *c, vgl_hip_graph *g, vgl_hip_fron
     VGL_HIP_TRY(hipGetLastError());
     VGL_TRY(vgl_read_counters(c, false));
     *edges = c->h_counters[C_NEIGH];
-    f->plan_dir = direction;
+    f->plan_dir = direction; f->plan_edges = *edges;
     return 0;
 }
 
@@ -605,7 +604,7 @@ static int vgl_gnf_frontier(vgl_hip_ctx *c, vgl_hip_graph *g, Pred pred, double 
         f->sparsity = VGL_HIP_FRONTIER_SPARSE;
         vgl_timed_launch tl(c, "gnf");
         hipLaunchKernelGGL(vgl_k_gnf_write<Pred>, dim3((unsigned)g->nvtiles), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows,
-                           g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, f->ids, (int64_t *)nullptr);
+                           g->row_begin, g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, f->ids, (int64_t *)nullptr, (int32_t *)nullptr, (int64_t)0);
     }
     VGL_HIP_TRY(hipGetLastError());
     return 0;

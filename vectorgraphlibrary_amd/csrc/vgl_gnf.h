@@ -252,11 +252,13 @@ static __global__ __launch_bounds__(VGL_SCAN_THREADS) void vgl_k_gnf_scan(int64_
     }
 }
 
-// write pass: ids[pos] = v ascending; offs[pos] = exclusive sum of degrees (optional)
+// write pass: ids[pos] = v ascending; offs[pos] = exclusive sum of degrees (optional).  tile_first (optional, with offs; M = the degree sum of
+// the whole frontier): the frontier position that owns edge t * VGL_TILE of the frontier's edge space, and in entry [#tiles] the owner of the last
+// edge -- every frontier vertex knows its own edge range, so the advance that follows needs no table pass of its own (vgl_k_plan_tile_first).
 template <class Pred>
 __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_write(Pred pred, int32_t nrows, int32_t row_base, const int64_t *rowptr,
                                                              const int32_t *vt_cnt_off, const int64_t *vt_deg_off,
-                                                             int32_t *ids, int64_t *offs)
+                                                             int32_t *ids, int64_t *offs, int32_t *tile_first, int64_t M)
 {
     __shared__ int64_t s64[VGL_WAVES];
     __shared__ int s32[VGL_WAVES];
@@ -288,7 +290,15 @@ __global__ __launch_bounds__(VGL_BLOCK) void vgl_k_gnf_write(Pred pred, int32_t 
         for (int j = 0; j < VGL_EPT; j++) {
             if ((bits >> j) & 1) {
                 ids[pos] = row_base + r0 + j;
-                if (offs) { offs[pos] = eoff; eoff += degs[j]; }
+                if (offs) {
+                    offs[pos] = eoff;
+                    const int64_t eend = eoff + degs[j];
+                    if (tile_first) {
+                        for (int64_t t = (eoff + VGL_TILE - 1) / VGL_TILE; t < (eend + VGL_TILE - 1) / VGL_TILE; t++) tile_first[t] = pos;
+                        if (eoff < eend && eend == M) tile_first[(M + VGL_TILE - 1) / VGL_TILE] = pos;
+                    }
+                    eoff = eend;
+                }
                 pos++;
             }
         }
@@ -322,7 +332,7 @@ static int vgl_gnf_run(vgl_hip_ctx *c, vgl_hip_graph *g, Pred pred, int32_t *ids
     if (write_ids) {
         vgl_timed_launch tl(c, "gnf");
         hipLaunchKernelGGL(vgl_k_gnf_write<Pred>, dim3((unsigned)nt), dim3(VGL_BLOCK), 0, c->stream, pred, g->nrows, g->row_begin,
-                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, ids, offs);
+                           g->out.rowptr, g->vt_cnt_off, g->vt_deg_off, ids, offs, (int32_t *)nullptr, (int64_t)0);
     }
     VGL_HIP_TRY(hipGetLastError());
     if (read_back) VGL_TRY(vgl_wait_counters(c, seq));

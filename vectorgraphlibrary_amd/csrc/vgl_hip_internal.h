@@ -159,7 +159,9 @@ struct vgl_hip_frontier {
     int32_t *tile_first = nullptr;   // ceil(E/VGL_TILE)+2
     int64_t *blk_sum = nullptr, *blk_off = nullptr;   // per 2048-id block degree sums / offsets
     bool borrowed = false;           // flags / ids belong to the caller (vgl_hip_frontier_create_on)
-    int plan_dir = -1;               // direction whose edge offsets `offs` describe the current ids (-1: none; set by vgl_hip_gnf_complete)
+    int plan_dir = -1;               // direction whose edge offsets `offs` AND tile table `tile_first` describe the current ids (-1: none; set by
+                                     // vgl_hip_gnf_complete and vgl_hip_frontier_advance_plan, voided by every change of the ids)
+    int64_t plan_edges = 0;          // edges of the ids in that direction
 };
 
 // timing helpers (no-ops unless ctx->timing)
