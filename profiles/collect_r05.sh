@@ -2,7 +2,7 @@
 # Round-5 profile collection, run on the GPU box from the repository root:  gpurun -- bash profiles/collect_r05.sh
 # Writes under gpurun_out/r5prof/ (progress lines in progress.txt); the summaries are then copied into profiles/ (see profiles/README.md).
 #   1. the DRIVER'S bench command (python bench.py --steps 20 --warmup 5): its JSON line -> r05_bench_line_driver_cmd.json
-#   2. rocprofv3 --kernel-trace --stats of the same command (CPU baseline / operator apps off: child processes) -> r05_bench_kernel_stats.csv
+#   2. rocprofv3 --kernel-trace --stats of the same command (CPU baseline / operator apps off: child processes; the RMAT-27 leg off: its launches of the same kernels would mix into the averages) -> r05_bench_kernel_stats.csv
 #   3. FETCH_SIZE / WRITE_SIZE of the BFS kernels in passes of their own (MI355X_MICROARCH.md) -> r05_pmc_bfs.json via pmc_reduce.py
 set -u
 cd "$(dirname "$0")/.."
@@ -12,7 +12,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line_driver_cmd.json 2> $OUT/bench_driver_cmd.err
 echo "driver command done" > $OUT/progress.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-operator-api > $OUT/trace_bench_line.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-operator-api --no-bfs-big > $OUT/trace_bench_line.json 2> $OUT/trace.err
 echo "trace done" >> $OUT/progress.txt
 BFS="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-sssp --no-pr-cc --no-operator-api"
 i=0
