@@ -16,7 +16,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-CASES = [("csr", 10, 4, 1, 60), ("csr", 12, 8, 1, 64), ("vcsr", 12, 8, 1, 8), ("vcsr", 10, 4, 1, 16)]
+CASES = [("csr", 10, 4, 1, 60), ("csr", 12, 8, 1, 10), ("vcsr", 12, 8, 1, 4), ("vcsr", 10, 4, 1, 8)]
 
 
 def main():
