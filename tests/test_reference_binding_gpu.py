@@ -170,7 +170,7 @@ def test_host_rewrites_of_a_generated_frontier_void_its_advance_plan(kind, scale
     assert len(re.findall(r", 0 differences", text)) == 4, text[-3000:]
 
 
-@pytest.mark.parametrize("kind,scale,edges", [("rmat", 11, 8), ("ru", 10, 2), ("rmat", 8, 4)])
+@pytest.mark.parametrize("kind,scale,edges", [("rmat", 11, 8), ("ru", 10, 2), ("rmat", 8, 4), ("rmat", 16, 16)])     # the last: 512 tiles of copy_if_indexes, two rounds of its scan
 def test_reference_tc_unchanged_against_a_sequential_search(kind, scale, edges):
     """TransitiveClosure::vgl_purdoms (algorithms/tc/tc.hpp) bound in (round 5: tc.h is no longer left out of the tree): the edge filter writes two
     EdgesArrays through global_edge_pos, ParallelPrimitives::copy_if_indexes evaluates its DEVICE condition in kernels
