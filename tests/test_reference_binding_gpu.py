@@ -46,6 +46,18 @@ def test_reference_bfs_app(kind, scale, edges, fmt):
 
 
 @pytest.mark.parametrize("fmt", ["csr", "vcsr"])
+def test_reference_apps_with_int_flags_for_every_frontier(fmt):
+    """VGL_GNF_INT_FLAGS=1: generate_new_frontier writes the int32 flags of every result in its count pass (the reference's contract to the letter)
+    instead of a bitmap + flags for DENSE / ALL_ACTIVE results only (round 5).  A dense uniform graph turns BFS frontiers DENSE on VECTOR_CSR_GRAPH
+    (more than 0.7 V vertices on one level), so both ways of producing the flags of a frontier that is walked by them run here."""
+    for env in (None, dict(os.environ, VGL_GNF_INT_FLAGS="1")):
+        text = run("bfs", "-s", "12", "-e", "32", "-type", "ru", "-format", fmt, "-check", "-it", "3", env=env)
+        assert len(re.findall(r"error count: 0\b", text)) == 3, text[-3000:]
+        text = run("sswp", "-s", "11", "-e", "32", "-type", "ru", "-format", fmt, "-check", "-it", "1", env=env)
+        assert len(re.findall(r"error count: 0\b", text)) == 1, text[-3000:]
+
+
+@pytest.mark.parametrize("fmt", ["csr", "vcsr"])
 @pytest.mark.parametrize("kind,scale,edges", [("rmat", 13, 16), ("ru", 12, 8), ("rmat", 7, 3)])
 def test_reference_sswp_app(kind, scale, edges, fmt):
     text = run("sswp", "-s", str(scale), "-e", str(edges), "-type", kind, "-format", fmt, "-check", "-it", "2")
