@@ -78,6 +78,28 @@ def frac(gbps):
     return round(gbps / HBM_PEAK_GBS, 5)
 
 
+def measured_copy_bandwidth(device, gib=2, reps=10):
+    """What a plain device-to-device copy reaches on THIS box (the roofline fractions are quoted against the 8 TB/s spec, the measured copy
+    rate says how much of that a streaming kernel can see): torch's copy of `gib` GiB, read + written bytes over the HIP-event time of `reps` copies."""
+    import torch
+    n = (gib << 30) // 4
+    a = torch.empty(n, dtype=torch.int32, device=device).fill_(1)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return {"GBps": round(2.0 * n * 4 / (ms * 1e-3) / 1e9, 1), "bytes_read_plus_written": 2 * n * 4, "ms": round(ms, 4),
+            "note": "torch device-to-device copy of %d GiB, %d repetitions, HIP events; bytes = read + written" % (gib, reps)}
+
+
 def timed_kernels(ctx, names):
     out = {}
     for name in names:
@@ -1229,6 +1251,27 @@ def main():
                        "vertex_numbering": "identity" if args.renumber == "none" else f"degree-sorted ({args.renumber})",
                        "graph_build_s": round(t_build, 2)},
         }
+        if world == 1:
+            try:
+                copy = measured_copy_bandwidth(ctx.device)
+                extra["hbm_copy_measured"] = copy
+                if roofline and copy["GBps"] > 0:
+                    roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy["GBps"], 5)
+                if copy["GBps"] > 0:                                    # the all-edges passes against what a copy streams on this box
+                    sr = extra.get("sssp_roofline")
+                    if sr:
+                        sr["frac_of_measured_copy"] = round(sr["achieved"] / copy["GBps"], 5)
+                        if sr.get("streamed_GBps"):
+                            sr["streamed_over_measured_copy"] = round(sr["streamed_GBps"] / copy["GBps"], 5)
+                    for key in ("pagerank_uniform25", "pagerank_rmat24"):
+                        pp = (extra.get(key) or {}).get("pull_pass")
+                        if pp and pp.get("algorithmic_GBps"):
+                            pp["algorithmic_over_measured_copy"] = round(pp["algorithmic_GBps"] / copy["GBps"], 5)
+                    hp = ((extra.get("cc_rmat24x16_symmetrised") or {}).get("shiloach_vishkin") or {}).get("hook_pass")
+                    if hp and hp.get("algorithmic_GBps"):
+                        hp["algorithmic_over_measured_copy"] = round(hp["algorithmic_GBps"] / copy["GBps"], 5)
+            except Exception as exc:                                   # (a reporting extra: never the reason a line is lost)
+                extra["hbm_copy_measured"] = {"error": str(exc)[:200]}
         if roofline:
             out["roofline"] = roofline
         if cpu_baseline:
