@@ -643,6 +643,21 @@ def leg_operator_api(scale, ef, extra):
             row["operator_api_over_fused"] = round(row["operator_api_mteps"] / row["fused_mteps"], 3)
         if row.get("operator_api_declared_mteps") and row.get("fused_mteps"):
             row["operator_api_declared_over_fused"] = round(row["operator_api_declared_mteps"] / row["fused_mteps"], 3)
+        if name == "sssp_bellman_ford_all_active_push":
+            # the app's `-fused -do` is another SCHEDULE (direction-optimising, a handful of sparse steps); what the operator forms run is the reference's
+            # all-active schedule, every edge in every super-step -- beside it the library's runs of THAT schedule (this bench's SSSP leg, same graph size)
+            lib = extra.get("sssp") or {}
+            push = (lib.get("bellman_ford_push_all_active") or {}).get("teps")
+            blocked = (lib.get("bellman_ford_all_active_blocked") or {}).get("teps")
+            if push:
+                row["library_same_schedule_atomic_kernel_mteps"] = round(push / 1e6, 1)
+                if row.get("operator_api_mteps"):
+                    row["operator_api_over_library_same_schedule"] = round(row["operator_api_mteps"] / (push / 1e6), 3)
+            if blocked:
+                row["library_same_schedule_blocked_mteps"] = round(blocked / 1e6, 1)
+                if row.get("operator_api_declared_mteps"):
+                    row["operator_api_declared_over_library_same_schedule_blocked"] = round(row["operator_api_declared_mteps"] / (blocked / 1e6), 3)
+            row["fused_note"] = "`fused` = sssp_hip -fused -do: the direction-optimising schedule (plan outside its timer), not the schedule the operator forms run"
         if name == "pagerank_5_iterations":
             best = ((extra.get("pagerank_uniform25") or {}).get("teps") or 0.0) / 1e6
             if best > 0:
