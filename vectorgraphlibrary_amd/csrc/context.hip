@@ -1,5 +1,6 @@
 // context.hip -- context, error reporting, device memory, kernel timing hooks.
 #include "vgl_hip_internal.h"
+#include <unordered_set>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -42,6 +43,17 @@ hipMemPool_t vgl_lib_pool(int device)
     }
     return g_lib_pool[device];
 }
+
+// blocks that vgl_pool_alloc took from hipMalloc (see vgl_hip_internal.h)
+static std::mutex g_big_mutex;
+static std::unordered_set<void *> g_big_blocks;
+size_t vgl_pool_block_limit()
+{
+    static const size_t limit = [] { const char *e = getenv("VGL_POOL_MAX_MB"); return (e ? (size_t)strtoull(e, nullptr, 10) : (size_t)64) << 20; }();
+    return limit;
+}
+void vgl_big_block_remember(void *p) { std::lock_guard<std::mutex> lock(g_big_mutex); g_big_blocks.insert(p); }
+bool vgl_big_block_forget(void *p) { std::lock_guard<std::mutex> lock(g_big_mutex); return g_big_blocks.erase(p) != 0; }
 
 extern char **environ;
 // setenv / putenv / unsetenv replace or move entries of `environ`: the pointers change, so a hash of the pointers tells whether anything was set

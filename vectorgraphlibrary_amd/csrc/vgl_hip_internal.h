@@ -197,31 +197,43 @@ static inline int64_t vgl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / 
 // hipMalloc right after tens of GB were hipFree'd was measured to stall for 0.5 - 1.3 s on this driver, and fresh mappings cost ~14 ms
 // per GB on first touch; pool memory that has been used once costs neither.  vgl_hip_ctx_trim / vgl_hip_ctx_destroy hand it back.
 hipMemPool_t vgl_lib_pool(int device);          // context.hip; nullptr when the pool could not be created (callers fall back to hipMallocAsync)
+// LARGE blocks do not come from the pool (round 5, late).  Kernels that touched a freshly grown multi-GB pool block ended in a GPU memory fault in
+// 2 - 12 % of the processes that built an RMAT-24 graph (apps/bin/*_hip -s 24: `GPU coredump`, exit by SIGPIPE, the bench's operator leg lost a row;
+// profiles/r05_pool_fault_ab.log: 7 of 60 runs with the scratch of vgl_hip_coo_to_csr from the pool, 0 of 60 with it from hipMalloc; ROCm 7.2; the
+// round's first workaround drew the line at 2^33 bytes, where the fault was first seen).  Blocks of at least vgl_pool_block_limit() bytes
+// (VGL_POOL_MAX_MB, default 64 MiB) are plain hipMalloc blocks, remembered so that vgl_pool_free hands them to hipFree after a stream
+// synchronisation; the pool keeps what it is good at, the many small buffers of a plan build.
+size_t vgl_pool_block_limit();                  // context.hip
+void vgl_big_block_remember(void *p);           // context.hip: p came from hipMalloc
+bool vgl_big_block_forget(void *p);             // context.hip: true (and forgotten) when p came from hipMalloc
 static inline hipError_t vgl_pool_alloc(hipStream_t st, void **p, size_t bytes)
 {
+    if (bytes >= vgl_pool_block_limit()) {
+        const hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) vgl_big_block_remember(*p);
+        return e;
+    }
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess)
         if (hipMemPool_t pool = vgl_lib_pool(dev)) return hipMallocFromPoolAsync(p, bytes ? bytes : 16, pool, st);
     return hipMallocAsync(p, bytes ? bytes : 16, st);
 }
-static inline void vgl_pool_free(hipStream_t st, void *p) { if (p) (void)hipFreeAsync(p, st); }
-// scratch of the graph builders: from the pool below 8 GiB, plain hipMalloc from there on -- a pool allocation of exactly 2^33 bytes (the 8-byte
-// index arrays of uniform-25's 2^30 edges) ended in a GPU memory fault inside the first kernel that touched it (round 5, ROCm 7.2; the plan
-// builders' pool allocations stop at 5.7 GB and never showed it).  The tag in the low bit of `tag` remembers where the block came from.
+static inline void vgl_pool_free(hipStream_t st, void *p)
+{
+    if (!p) return;
+    if (vgl_big_block_forget(p)) { (void)hipStreamSynchronize(st); (void)hipFree(p); }      // (kernels of this stream may still use it)
+    else (void)hipFreeAsync(p, st);
+}
+// scratch of the graph builders (a block and where it came from: kept as a type of its own for the cleanup guards of gen.hip)
 struct vgl_scratch {
     void *p = nullptr;
     bool pooled = false;
 };
-static inline hipError_t vgl_scratch_alloc(hipStream_t st, vgl_scratch *b, size_t bytes)
-{
-    b->pooled = bytes < (1ull << 33);
-    return b->pooled ? vgl_pool_alloc(st, &b->p, bytes) : hipMalloc(&b->p, bytes ? bytes : 16);
-}
+static inline hipError_t vgl_scratch_alloc(hipStream_t st, vgl_scratch *b, size_t bytes) { b->pooled = true; return vgl_pool_alloc(st, &b->p, bytes); }
 static inline void vgl_scratch_free(hipStream_t st, vgl_scratch *b)
 {
     if (!b->p) return;
-    if (b->pooled) (void)hipFreeAsync(b->p, st);
-    else { (void)hipStreamSynchronize(st); (void)hipFree(b->p); }
+    vgl_pool_free(st, b->p);
     b->p = nullptr;
 }
 
