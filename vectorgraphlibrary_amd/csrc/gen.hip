@@ -211,7 +211,9 @@ int vgl_hip_coo_to_csr(vgl_hip_ctx *c, int32_t V, int64_t count, const int32_t *
     // 1. stable selection of the input indices whose source row is owned
     // whatever is still allocated when the function leaves -- normally or through VGL_HIP_TRY on a failed allocation -- is freed (an
     // out-of-memory in the middle of a scale-27 shard build must not leak the multi-GB temporaries of the piece before it).
-    // Round 5: the temporaries (about 26 bytes per edge) come from the library's stream-ordered pool, like those of the plan builders: what the graph
+    // Round 5, late: the multi-GB temporaries (about 26 bytes per edge) are plain hipMalloc blocks again -- vgl_pool_alloc sends blocks of 64 MiB and more
+    // there since kernels touching a freshly grown pool block of that size faulted in 2 - 12 % of the processes (vgl_hip_internal.h).  The idea it replaces:
+    // the temporaries (about 26 bytes per edge) come from the library's stream-ordered pool, like those of the plan builders: what the graph
     // build has touched once is what the blocked-plan build of the same graph gets next -- the PageRank plan of uniform-25 paid 1.2 s for FRESH memory
     // (first touch, ~14 ms per GB, and the allocator's stalls) in front of 60 ms of kernels while the build before it took and returned device memory directly
     vgl_scratch b_kept, b_sorted, b_nkept, b_keys, b_keys_sorted, b_temp;
